@@ -1,0 +1,193 @@
+/* nmfx -- MI355X-native NMF multiplicative-update engine: C ABI (libnmfx.so).
+ *
+ * The reference (colinvaz/nmf-toolbox) is pure MATLAB and has no FFI; the boundary a maintainer
+ * would bind is therefore the MATLAB call surface itself.  Each entry point below states the
+ * reference interface it replaces (file:line under the reference tree).  The MEX gateway and the
+ * `.m` wrappers that keep the toolbox signatures are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every matrix is COLUMN-MAJOR (MATLAB order): V[i + m*j], W[i + m*k + m*K*t], H[k + K*j]
+ *   - no torch / C++ types cross this boundary: plain pointers, sizes, enums
+ *   - every function returns nmfx_status; on failure nmfx_last_error() (thread-local) holds the
+ *     message a wrapper turns into MATLAB error() / a Python exception
+ *   - the library never frees or retains caller memory; one call = one blocking computation,
+ *     except the nmfx_engine_* phase API, which is asynchronous on the caller's HIP stream
+ *   - there is NO CPU fallback: without a usable gfx950 device compute calls fail with
+ *     NMFX_ERR_NO_DEVICE
+ *   - device arithmetic is fp32 (MFMA v_mfma_f32_32x32x2_f32) with fp64 scalar/vector reductions;
+ *     eps is MATLAB's 2^-52, not FLT_EPSILON
+ */
+#ifndef NMFX_H
+#define NMFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMFX_VERSION 100
+
+typedef enum {
+    NMFX_OK = 0,
+    NMFX_ERR_INVALID = 1,     /* bad argument (wrapper -> error()) */
+    NMFX_ERR_NO_DEVICE = 2,   /* no HIP device / kernels not loadable: never a silent CPU path */
+    NMFX_ERR_HIP = 3,         /* a HIP runtime call failed */
+    NMFX_ERR_UNSUPPORTED = 4, /* valid in the reference, not implemented here yet */
+    NMFX_ERR_NOMEM = 5,
+    NMFX_ERR_NEGATIVE = 6     /* nmfsc.m:57-59 "Negative values in data!" */
+} nmfx_status;
+
+/* config.divergence strings of nmf.m:147-167 / cnmf.m:137-147 */
+typedef enum {
+    NMFX_DIV_EUCLIDEAN = 0,        /* 'euclidean' */
+    NMFX_DIV_KL = 1,               /* 'kl_divergence', 'kl' */
+    NMFX_DIV_IS = 2,               /* 'is_divergence', 'is' */
+    NMFX_DIV_AB = 3,               /* 'ab_divergence', 'ab' (alpha, beta) */
+    NMFX_DIV_EUCLIDEAN_NOCOST = 4  /* cnmf only: 'frobenius' or any unrecognised string -- euclidean
+                                      updates, cost stays 0 (cnmf.m:137-147 vs 239-248) */
+} nmfx_divergence;
+
+typedef enum { NMFX_F32 = 0, NMFX_F64 = 1 } nmfx_dtype;
+
+/* ------------------------------------------------------------------------------------------
+ * Problem / result of one blocking factorisation with HOST buffers (what the MEX gateway binds).
+ * Multi-source problems (cell-array arguments of nmf.m:114-117) are passed concatenated:
+ * W = [W_1 ... W_S] (K_total columns), H = [H_1; ...; H_S], with per-source arrays of length
+ * num_sources.  Random defaults (nmf.m:277,298) stay in the wrapper: W_init/H_init are required.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t m, n;             /* size(V) */
+    int32_t K_total;          /* sum of num_basis_elems */
+    int32_t T;                /* context_len (cnmf.m:1); 1 for nmf / nmfsc */
+    int32_t dtype;            /* nmfx_dtype of V, W_init, H_init and of the result W, H */
+    const void *V;            /* m x n */
+    const void *W_init;       /* m x K_total x T */
+    const void *H_init;       /* K_total x n */
+    int32_t divergence;       /* nmfx_divergence */
+    double alpha, beta;       /* used only for NMFX_DIV_AB */
+    int32_t num_sources;      /* S >= 1 */
+    const int32_t *K_s;       /* [S] basis elements per source; NULL iff S == 1 */
+    const double *W_sparsity; /* [S] additive lambda (nmf.m:168), already clamped >= 0; NULL = 0 */
+    const double *H_sparsity; /* [S] (nmf.m:199); NULL = 0 */
+    const uint8_t *W_fixed;   /* [S] (nmf.m:146); NULL = all false */
+    const uint8_t *H_fixed;   /* [S] (nmf.m:177); NULL = all false */
+    int32_t maxiter;          /* > 0 (wrapper applies the <=0 -> 100 rule, nmf.m:404-406) */
+    double tolerance;         /* > 0 (wrapper applies the <=0 -> 1e-3 rule, nmf.m:409-411);
+                                 NMFX extension: a NEGATIVE value disables the stop rule (benchmarks) */
+    int32_t device;           /* HIP device ordinal */
+    /* nmfsc only (nmfsc.m:87-110): Hoyer sparseness targets in [0,1]; <= 0 selects the MU branch */
+    double sc_W_sparsity, sc_H_sparsity;
+} nmfx_problem;
+
+typedef struct {
+    void *W;                  /* caller-allocated m*K_total*T elements of problem.dtype */
+    void *H;                  /* caller-allocated K_total*n */
+    double *cost;             /* caller-allocated: maxiter entries (nmf, cnmf), maxiter+1 (nmfsc) */
+    int32_t cost_len;         /* out: valid entries of cost (== iterations run; nmfsc: see nmfsc.m:137-139,238) */
+    int32_t iters_run;        /* out */
+    int32_t *tries_H;         /* nmfsc, optional [maxiter]: line-search tries per outer iteration (nmfsc.m:152-175) */
+    int32_t *tries_W;         /* nmfsc, optional [maxiter] (nmfsc.m:203-226) */
+    double stepsize_H, stepsize_W; /* out (nmfsc.m:133-134,178,228) */
+    int32_t converged_early;  /* out: nmfsc step-size underflow return (nmfsc.m:170-174) */
+} nmfx_result;
+
+/* [W,H,cost] = nmf(V, num_basis_elems, config)            -- replaces nmf.m:1 (hot loop nmf.m:143-225) */
+nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r);
+/* [W,H,cost] = cnmf(V, num_basis_elems, context_len, config) -- replaces cnmf.m:1 (hot loop cnmf.m:175-258) */
+nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r);
+/* [W,H,cost] = nmfsc(V, num_basis_elems, config)          -- replaces nmfsc.m:1 (hot loop nmfsc.m:141-245) */
+nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r);
+/* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
+nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
+                             const void *H, void *V_hat, int32_t device);
+/* [v,usediters] = projfunc(s, k1, k2, nn) applied to `count` vectors of length N (stride N) -- replaces projfunc.m:1 */
+nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2,
+                          int32_t nn, void *v, int32_t *usediters, int32_t device);
+
+const char *nmfx_last_error(void);
+int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */
+int32_t nmfx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Phase API on DEVICE buffers (fp32), asynchronous on the caller's HIP stream.  This is what
+ * bench.py and the one-process-per-GPU driver use: V is column-sharded, W replicated, and the
+ * caller all-reduces the packed W-step partials between wstep_partial and wstep_finish
+ * (SURVEY.md 8(e)).  nmfx_nmf()/nmfx_cnmf() are thin loops over exactly these calls.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nmfx_engine nmfx_engine;
+
+typedef struct {
+    int64_t m, n_local;       /* local column shard of V */
+    int32_t K_total, T;
+    int32_t divergence;
+    double alpha, beta;
+    const float *lamW_col;    /* host [K_total] per-column lambda (source value repeated); NULL = 0 */
+    const float *lamH_row;    /* host [K_total]; NULL = 0 */
+    const uint8_t *fixW_col;  /* host [K_total]; NULL = 0 */
+    const uint8_t *fixH_row;  /* host [K_total]; NULL = 0 */
+    int32_t device;
+    void *stream;             /* hipStream_t of the caller (NULL = default stream) */
+    int64_t col_offset;       /* global index of the first local column (cnmf halo logic; 0 on 1 GPU) */
+    int32_t path;             /* 0 = auto; 1 = force generic (materialised V_hat) path; 2 = force fused path */
+    int32_t algorithm;        /* 0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
+                                 (cnmf.m:157-166,196-199: slab Frobenius norm T, H rescaled at init only) */
+} nmfx_engine_desc;
+
+/* bytes of device scratch the engine needs (caller allocates: torch tensor / hipMalloc) */
+nmfx_status nmfx_engine_workspace_bytes(const nmfx_engine_desc *d, size_t *bytes);
+/* number of fp32 elements of the packed all-reduce buffer [N | P-or-rowsum | ...] */
+nmfx_status nmfx_engine_packed_count(const nmfx_engine_desc *d, size_t *count);
+/* V, W, H, workspace, packed: DEVICE pointers owned by the caller; W and H are updated in place */
+nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float *W, float *H, void *workspace,
+                               size_t workspace_bytes, float *packed, nmfx_engine **out);
+void nmfx_engine_destroy(nmfx_engine *e);
+/* nmf.m:130-139 / cnmf.m:155-171: normalise W (cnmf: and rescale H), form the initial V_hat state */
+nmfx_status nmfx_engine_init(nmfx_engine *e);
+/* W step, local part: fills packed[] with this shard's numerator/denominator sums (nmf.m:149-164, cnmf.m:187-192) */
+nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e);
+/* W step, replicated part after the all-reduce: ratio update + normalisation (nmf.m:168-169, cnmf.m:193-199) */
+nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e);
+/* H step (column-local, nmf.m:176-203 / cnmf.m:207-236) + this shard's cost partial of the iteration */
+nmfx_status nmfx_engine_hstep(nmfx_engine *e);
+/* device pointer to the fp64 cost of the last hstep for the local shard: data-fit partial + lambda*L1 terms
+ * (the W term is included only when the engine is rank 0, see nmfx_engine_set_rank0); sum over ranks = nmf.m:206-218 */
+nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost);
+/* enqueue an 8-byte device-to-device copy of that cost into dst_dev on the engine's stream */
+nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev);
+nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0);
+/* convenience for one GPU: `iters` full iterations, costs written to the DEVICE array dev_cost_out[iters] (may be NULL) */
+nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out);
+
+/* Measurement hooks (bench.py): when enabled, every launch group of an iteration is bracketed by a hipEvent
+ * pair on the engine's stream; after synchronising, read total ms and launch count per tag. */
+nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable);
+int32_t nmfx_engine_profile_ntags(void);
+const char *nmfx_engine_profile_tag_name(int32_t tag);
+nmfx_status nmfx_engine_profile_read(nmfx_engine *e, double *ms_per_tag, int32_t *count_per_tag);
+/* algorithmic work of ONE launch behind `tag`: flops = 2*M*N*Kc of the contraction(s) it issues (by formula),
+ * bytes = compulsory HBM traffic of its operands */
+nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, double *bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level entry points on device buffers (used by the parity tests to check each kernel
+ * against the oracle in isolation).  C (M x N) = op(A) * op(B), all column-major fp32.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum { NMFX_OP_N = 0, NMFX_OP_T = 1 } nmfx_op;
+typedef enum {
+    NMFX_PRO_NONE = 0,        /* x */
+    NMFX_PRO_RATIO = 1,       /* x ./ x2          (V ./ V_hat,      nmf.m:152) */
+    NMFX_PRO_RATIO_SQ = 2,    /* x ./ x2.^2       (V ./ V_hat.^2,   nmf.m:155) */
+    NMFX_PRO_RECIP2 = 3,      /* 1 ./ x2          (1 ./ V_hat,      nmf.m:156) */
+    NMFX_PRO_DIFF = 4         /* x2 - x           (V_hat - V: dH = W'*V_hat - W'*V, nmfsc.m:148) */
+} nmfx_prologue;
+nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t Kc,
+                          const float *A, const float *A2, int64_t lda, int32_t proA, const float *B,
+                          const float *B2, int64_t ldb, int32_t proB, float *C, int64_t ldc, int32_t accumulate,
+                          void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMFX_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libnmfx.so -- the C ABI declared in include/nmfx.h.
+
+There is no CPU fallback: if the library is missing it is an ImportError-style failure, and every
+compute entry point raises NmfxError when no MI355X is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmfx.so")
+
+NMFX_OK, NMFX_ERR_INVALID, NMFX_ERR_NO_DEVICE, NMFX_ERR_HIP, NMFX_ERR_UNSUPPORTED, NMFX_ERR_NOMEM, NMFX_ERR_NEGATIVE = range(7)
+DIV_EUCLIDEAN, DIV_KL, DIV_IS, DIV_AB, DIV_EUCLIDEAN_NOCOST = range(5)
+F32, F64 = 0, 1
+
+# every symbol include/nmfx.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "nmfx_nmf", "nmfx_cnmf", "nmfx_nmfsc", "nmfx_reconstruct", "nmfx_projfunc", "nmfx_last_error",
+    "nmfx_device_count", "nmfx_version", "nmfx_engine_workspace_bytes", "nmfx_engine_packed_count",
+    "nmfx_engine_create", "nmfx_engine_destroy", "nmfx_engine_init", "nmfx_engine_wstep_partial",
+    "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
+    "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
+    "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32",
+]
+
+
+class NmfxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64), ("n", C.c_int64), ("K_total", C.c_int32), ("T", C.c_int32), ("dtype", C.c_int32),
+        ("V", C.c_void_p), ("W_init", C.c_void_p), ("H_init", C.c_void_p),
+        ("divergence", C.c_int32), ("alpha", C.c_double), ("beta", C.c_double),
+        ("num_sources", C.c_int32), ("K_s", C.c_void_p), ("W_sparsity", C.c_void_p), ("H_sparsity", C.c_void_p),
+        ("W_fixed", C.c_void_p), ("H_fixed", C.c_void_p),
+        ("maxiter", C.c_int32), ("tolerance", C.c_double), ("device", C.c_int32),
+        ("sc_W_sparsity", C.c_double), ("sc_H_sparsity", C.c_double),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("W", C.c_void_p), ("H", C.c_void_p), ("cost", C.c_void_p), ("cost_len", C.c_int32), ("iters_run", C.c_int32),
+        ("tries_H", C.c_void_p), ("tries_W", C.c_void_p), ("stepsize_H", C.c_double), ("stepsize_W", C.c_double),
+        ("converged_early", C.c_int32),
+    ]
+
+
+class EngineDesc(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64), ("n_local", C.c_int64), ("K_total", C.c_int32), ("T", C.c_int32), ("divergence", C.c_int32),
+        ("alpha", C.c_double), ("beta", C.c_double),
+        ("lamW_col", C.c_void_p), ("lamH_row", C.c_void_p), ("fixW_col", C.c_void_p), ("fixH_row", C.c_void_p),
+        ("device", C.c_int32), ("stream", C.c_void_p), ("col_offset", C.c_int64), ("path", C.c_int32), ("algorithm", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libnmfx.so (building it is `python -m nmf_toolbox_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "nmf_toolbox_amd: %s not found. Build the HIP extension first (python -m nmf_toolbox_amd.build). "
+            "There is no CPU fallback." % LIB_PATH)
+    try:  # share ONE HIP runtime with torch when torch is around (see build.py)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.nmfx_last_error.restype = C.c_char_p
+    lib.nmfx_engine_profile_tag_name.restype = C.c_char_p
+    lib.nmfx_engine_profile_tag_name.argtypes = [C.c_int32]
+    lib.nmfx_engine_destroy.restype = None
+    lib.nmfx_engine_destroy.argtypes = [C.c_void_p]
+    for name in ("nmfx_nmf", "nmfx_cnmf", "nmfx_nmfsc"):
+        getattr(lib, name).argtypes = [C.POINTER(Problem), C.POINTER(Result)]
+    lib.nmfx_reconstruct.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nmfx_projfunc.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nmfx_engine_workspace_bytes.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
+    lib.nmfx_engine_packed_count.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
+    lib.nmfx_engine_create.argtypes = [C.POINTER(EngineDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+    for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.nmfx_engine_copy_cost.argtypes = [C.c_void_p, C.c_void_p]
+    lib.nmfx_engine_set_rank0.argtypes = [C.c_void_p, C.c_int32]
+    lib.nmfx_engine_iterate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.nmfx_engine_profile.argtypes = [C.c_void_p, C.c_int32]
+    lib.nmfx_engine_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.nmfx_engine_tag_work.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.nmfx_gemm_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != NMFX_OK:
+        raise NmfxError(status, load().nmfx_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(load().nmfx_device_count())

@@ -1,0 +1,77 @@
+"""Build libnmfx.so (hand-written HIP for gfx950 + the C ABI of include/nmfx.h), in-tree.
+
+    python -m nmf_toolbox_amd.build        # or nmf_toolbox_amd.build.build()
+
+hipcc cross-compiles without a GPU.  The library is linked against the HIP runtime that PyTorch
+ships (torch/lib/libamdhip64.so, no SONAME) when torch is importable, so that a process which also
+uses torch.distributed holds ONE HIP runtime and device pointers / streams can be shared; the
+rpath falls back to /opt/rocm/lib for consumers without torch (the MEX gateway).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(HERE, "libnmfx.so")
+SOURCES = ["gemm.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
+ARCH = "gfx950"
+
+
+def _torch_lib_dir():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            d = os.path.join(os.path.dirname(spec.origin), "lib")
+            if os.path.exists(os.path.join(d, "libamdhip64.so")):
+                return d
+    except Exception:
+        pass
+    return None
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, "nmfx_internal.h"), os.path.join(INC, "nmfx.h")]
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _newer([src] + hdrs, obj):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), 6)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or _newer(objs, OUT):
+        tl = _torch_lib_dir()
+        libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
+        cmd = ["g++", "-shared", "-o", OUT] + objs
+        for d in libdirs:
+            cmd += ["-L" + d]
+        cmd += ["-lamdhip64", "-Wl,-rpath," + ":".join(libdirs), "-Wl,--no-undefined", "-lstdc++", "-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,821 @@
+// C ABI of libnmfx (include/nmfx.h): error plumbing, the device-resident engine (phases of one
+// multiplicative-update iteration) and the blocking host-buffer entry points that the MEX gateway /
+// Python ctypes wrapper bind.  Kernels live in gemm.hip / fused.hip / aux.hip / projfunc.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static nmfx_status check_device(int device) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        set_error("nmfx: no usable HIP device (hipGetDeviceCount: %s). There is no CPU fallback.", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return NMFX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= cnt) {
+        set_error("nmfx: device %d out of range (have %d)", device, cnt);
+        return NMFX_ERR_INVALID;
+    }
+    NMFX_HIP(hipSetDevice(device));
+    return NMFX_OK;
+}
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *b) : base(static_cast<char *>(b)), off(0) {}
+    template <class T> T *take(size_t count) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += al256(sizeof(T) * count);
+        return p;
+    }
+};
+
+}  // namespace nmfx
+
+using namespace nmfx;
+
+// =============================================================================================
+// engine
+// =============================================================================================
+struct ProfEvent {
+    int tag;
+    hipEvent_t a, b;
+};
+
+struct nmfx_engine {
+    long m, n;
+    int K, T, KT, div, algo;
+    int device;
+    hipStream_t st;
+    const float *V;
+    float *W, *H, *packed;
+    int rank0;
+    bool any_lamW, any_lamH;
+    // workspace
+    float *Vhat, *Gn, *Gp, *gemm_scratch;
+    size_t gemm_scratch_bytes;
+    float *lamW, *lamH;
+    uint8_t *fixW, *fixH;
+    bool all_fixW, all_fixH;
+    double *sumsq, *f_out, *rowsum, *colsum, *Pvec, *Gpvec, *cost_partials, *cost, *l1W, *l1H;
+    void *rr_scratch;
+    int n_cost_partials, n_cost_used;
+    // profiling
+    bool prof;
+    std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used;
+};
+
+enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6, TAG_COUNT = 7 };
+static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'", "gemm:P=B*H'", "gemm:Gn=W'*A", "gemm:Gp=W'*B",
+                                                 "gemm:V_hat=W*H+cost", "small kernels"};
+
+namespace {
+
+struct Scope {
+    nmfx_engine *e;
+    int idx;
+    Scope(nmfx_engine *e_, int tag) : e(e_), idx(-1) {
+        if (!e->prof) return;
+        auto get = [&]() {
+            if (e->pool_used == e->pool.size()) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return (hipEvent_t) nullptr;
+                e->pool.push_back(ev);
+            }
+            return e->pool[e->pool_used++];
+        };
+        ProfEvent pe{tag, get(), get()};
+        if (!pe.a || !pe.b) return;
+        (void)hipEventRecord(pe.a, e->st);
+        e->events.push_back(pe);
+        idx = (int)e->events.size() - 1;
+    }
+    ~Scope() {
+        if (idx >= 0) (void)hipEventRecord(e->events[idx].b, e->st);
+    }
+};
+
+struct Layout {
+    size_t total;
+    size_t packed_count;
+};
+
+bool div_has_matrix_den(int div) { return div != NMFX_DIV_KL; }
+
+// carve (or just size, when ws == nullptr) the workspace
+Layout layout(nmfx_engine *e, void *ws) {
+    Carver c(ws);
+    const size_t mn = (size_t)e->m * e->n, Kn = (size_t)e->K * e->n, mKT = (size_t)e->m * e->KT;
+    e->Vhat = c.take<float>(mn);
+    e->Gn = c.take<float>(Kn);
+    e->Gp = div_has_matrix_den(e->div) ? c.take<float>(Kn) : nullptr;
+    size_t gs = gemm_scratch_bytes(e->m, e->KT, e->n);
+    size_t gs2 = gemm_scratch_bytes(e->K, e->n, (long)e->T * e->m);
+    size_t gs3 = gemm_scratch_bytes(e->m, e->n, e->KT);
+    if (gs2 > gs) gs = gs2;
+    if (gs3 > gs) gs = gs3;
+    e->gemm_scratch_bytes = gs;
+    e->gemm_scratch = gs ? c.take<float>(gs / sizeof(float)) : nullptr;
+    e->lamW = c.take<float>(e->K);
+    e->lamH = c.take<float>(e->K);
+    e->fixW = c.take<uint8_t>(e->K);
+    e->fixH = c.take<uint8_t>(e->K);
+    e->sumsq = c.take<double>(e->KT);
+    e->f_out = c.take<double>(e->K);
+    e->rowsum = c.take<double>(e->K);
+    e->colsum = c.take<double>(e->KT);
+    e->Pvec = c.take<double>(e->KT);
+    e->Gpvec = c.take<double>(e->K);
+    e->l1W = c.take<double>(e->KT);
+    e->l1H = c.take<double>(e->K);
+    e->cost = c.take<double>(4);
+    e->n_cost_partials = (int)gemm_grid_blocks(e->m, e->n);
+    e->cost_partials = c.take<double>(e->n_cost_partials);
+    e->rr_scratch = c.take<char>(row_reduce_scratch_bytes(e->K));
+    Layout L;
+    L.total = c.off;
+    L.packed_count = div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT;
+    (void)mKT;
+    return L;
+}
+
+nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
+    if (!d || d->m <= 0 || d->n_local <= 0 || d->K_total <= 0 || d->T <= 0) {
+        set_error("nmfx_engine: m, n_local, K_total, T must be positive");
+        return NMFX_ERR_INVALID;
+    }
+    if (d->divergence == NMFX_DIV_AB) {
+        set_error("nmfx_engine: alpha-beta divergence is not implemented yet");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (d->divergence < 0 || d->divergence > NMFX_DIV_EUCLIDEAN_NOCOST) {
+        set_error("nmfx_engine: unknown divergence %d", d->divergence);
+        return NMFX_ERR_INVALID;
+    }
+    if (d->T > 1 && d->n_local < d->T) {
+        set_error("nmfx_engine: context_len %d exceeds the number of columns %ld", d->T, (long)d->n_local);
+        return NMFX_ERR_INVALID;
+    }
+    e->m = d->m;
+    e->n = d->n_local;
+    e->K = d->K_total;
+    e->T = d->T;
+    e->KT = d->K_total * d->T;
+    e->div = d->divergence;
+    e->device = d->device;
+    e->st = static_cast<hipStream_t>(d->stream);
+    e->rank0 = 1;
+    e->algo = d->algorithm;
+    if (e->algo == 0 && e->T != 1) {
+        set_error("nmfx_engine: algorithm nmf requires T == 1");
+        return NMFX_ERR_INVALID;
+    }
+    return NMFX_OK;
+}
+
+inline int mdiv(const nmfx_engine *e) { return e->div == NMFX_DIV_EUCLIDEAN_NOCOST ? NMFX_DIV_EUCLIDEAN : e->div; }
+
+// element maps (V, V_hat) -> numerator operand A, denominator operand B   (nmf.m:149-156, cnmf.m:191-192)
+void num_view(const nmfx_engine *e, OpView &v) {
+    v.p = e->V;
+    v.p2 = nullptr;
+    v.func = NMFX_PRO_NONE;
+    if (mdiv(e) == NMFX_DIV_KL) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO; }
+    if (mdiv(e) == NMFX_DIV_IS) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO_SQ; }
+}
+void den_view(const nmfx_engine *e, OpView &v) {
+    v.p = e->Vhat;
+    v.p2 = nullptr;
+    v.func = NMFX_PRO_NONE;
+    if (mdiv(e) == NMFX_DIV_IS) { v.p = e->Vhat; v.p2 = e->Vhat; v.func = NMFX_PRO_RECIP2; }
+}
+
+// V_hat = sum_t W_t * rshift_t(H)    (RFD.m:31 / 36-38) ; optionally fused with the cost reduction
+nmfx_status recon(nmfx_engine *e, bool with_cost) {
+    Scope s(e, with_cost ? TAG_RECON_COST : TAG_RECON);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->m; g.N = e->n; g.Kc = e->KT;
+    g.A = OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE};
+    g.C = e->Vhat; g.ldc = e->m;
+    g.splitk = 1;
+    if (with_cost) {
+        g.epi = EPI_COST; g.store_c = 1; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
+        long blocks = 0;
+        nmfx_status rc = launch_gemm(e->st, g, &blocks);
+        e->n_cost_used = (int)blocks;
+        return rc;
+    }
+    g.epi = EPI_STORE;
+    return launch_gemm(e->st, g);
+}
+
+// out (m x KT) = X * H_stack'   with X given by view x   (nmf.m:149 V*H', cnmf.m:191)
+nmfx_status x_times_ht(nmfx_engine *e, OpView x, float *out, int tag) {
+    Scope s(e, tag);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->m; g.N = e->KT; g.Kc = e->n;
+    x.ld = e->m; x.mode = VIEW_RC; x.blk = 0; x.tstride = 0; x.lim = 0;
+    g.A = x;
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE};
+    g.C = out; g.ldc = e->m; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+// out (K x n) = sum_t W_t' * lshift_t(X)    (nmf.m:180 W'*V, cnmf.m:217-226)
+nmfx_status wt_times_x(nmfx_engine *e, OpView x, float *out, int tag) {
+    Scope s(e, tag);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->K; g.N = e->n; g.Kc = (long)e->T * e->m;
+    if (e->T == 1) {
+        g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        x.ld = e->m; x.mode = VIEW_KC; x.blk = 0; x.tstride = 0; x.lim = 0;
+    } else {
+        g.A = OpView{e->W, nullptr, e->m, VIEW_WSTACK_KC, (int)e->m, e->m * e->K, 0, NMFX_PRO_NONE};
+        x.ld = e->m; x.mode = VIEW_XSHIFT_KC; x.blk = (int)e->m; x.tstride = 0; x.lim = (int)e->n;
+    }
+    g.B = x;
+    g.C = out; g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+#define TRY(x) do { nmfx_status s_ = (x); if (s_ != NMFX_OK) return s_; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char *nmfx_last_error(void) { return g_err; }
+int32_t nmfx_version(void) { return NMFX_VERSION; }
+int32_t nmfx_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cnt;
+}
+
+nmfx_status nmfx_engine_workspace_bytes(const nmfx_engine_desc *d, size_t *bytes) {
+    nmfx_engine tmp{};
+    TRY(fill_from_desc(&tmp, d));
+    *bytes = layout(&tmp, nullptr).total;
+    return NMFX_OK;
+}
+nmfx_status nmfx_engine_packed_count(const nmfx_engine_desc *d, size_t *count) {
+    nmfx_engine tmp{};
+    TRY(fill_from_desc(&tmp, d));
+    *count = layout(&tmp, nullptr).packed_count;
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float *W, float *H, void *workspace, size_t workspace_bytes,
+                               float *packed, nmfx_engine **out) {
+    if (!out || !V || !W || !H || !workspace || !packed) { set_error("nmfx_engine_create: null pointer"); return NMFX_ERR_INVALID; }
+    TRY(check_device(d ? d->device : 0));
+    nmfx_engine *e = new nmfx_engine{};
+    nmfx_status s = fill_from_desc(e, d);
+    if (s != NMFX_OK) { delete e; return s; }
+    e->V = V; e->W = W; e->H = H; e->packed = packed;
+    Layout L = layout(e, workspace);
+    if (L.total > workspace_bytes) {
+        set_error("nmfx_engine_create: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        delete e;
+        return NMFX_ERR_INVALID;
+    }
+    std::vector<float> lw(e->K, 0.f), lh(e->K, 0.f);
+    std::vector<uint8_t> fw(e->K, 0), fh(e->K, 0);
+    e->all_fixW = e->all_fixH = true;
+    for (int k = 0; k < e->K; ++k) {
+        if (d->lamW_col) lw[k] = d->lamW_col[k];
+        if (d->lamH_row) lh[k] = d->lamH_row[k];
+        if (d->fixW_col) fw[k] = d->fixW_col[k] ? 1 : 0;
+        if (d->fixH_row) fh[k] = d->fixH_row[k] ? 1 : 0;
+        e->any_lamW |= lw[k] != 0.f;
+        e->any_lamH |= lh[k] != 0.f;
+        e->all_fixW &= fw[k] != 0;
+        e->all_fixH &= fh[k] != 0;
+    }
+    hipError_t he = hipMemcpyAsync(e->lamW, lw.data(), sizeof(float) * e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->lamH, lh.data(), sizeof(float) * e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->fixW, fw.data(), e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->fixH, fh.data(), e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->st);  // host vectors go out of scope
+    if (he != hipSuccess) { set_error("nmfx_engine_create: %s", hipGetErrorString(he)); delete e; return NMFX_ERR_HIP; }
+    *out = e;
+    return NMFX_OK;
+}
+
+void nmfx_engine_destroy(nmfx_engine *e) {
+    if (!e) return;
+    for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 = is_rank0; return NMFX_OK; }
+
+// nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
+nmfx_status nmfx_engine_init(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    {
+        Scope s(e, TAG_SMALL);
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 1, e->sumsq));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo == 1, e->f_out));
+        if (e->algo == 1) TRY(scale_rows(e->st, e->H, e->K, e->n, e->f_out));
+    }
+    return recon(e, false);
+}
+
+// local sums of the W step: packed = [N | P]  or  [N | Pvec]        nmf.m:149-164 / cnmf.m:187-192
+nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->all_fixW) return NMFX_OK;
+    const size_t mKT = (size_t)e->m * e->KT;
+    OpView a{}, b{};
+    num_view(e, a);
+    TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
+    if (div_has_matrix_den(e->div)) {
+        den_view(e, b);
+        TRY(x_times_ht(e, b, e->packed + mKT, TAG_WDEN));
+    } else {
+        Scope s(e, TAG_SMALL);
+        TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+        TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec));
+        TRY(d2f(e->st, e->Pvec, e->packed + mKT, e->KT));
+    }
+    return NMFX_OK;
+}
+
+// replicated part of the W step (after the all-reduce of packed): nmf.m:168-173 / cnmf.m:193-204
+nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (!e->all_fixW) {
+        Scope s(e, TAG_SMALL);
+        const size_t mKT = (size_t)e->m * e->KT;
+        WUpdateParams p{};
+        p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = e->T;
+        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
+        if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
+        else {
+            TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
+            p.Pvec = e->Pvec;
+        }
+        TRY(w_update(e->st, p));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, e->algo == 1, nullptr));
+    }
+    return recon(e, false);
+}
+
+// H step + V_hat refresh + local cost partial: nmf.m:176-218 / cnmf.m:207-251
+nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (!e->all_fixH) {
+        OpView a{}, b{};
+        num_view(e, a);
+        TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
+        if (div_has_matrix_den(e->div)) {
+            den_view(e, b);
+            TRY(wt_times_x(e, b, e->Gp, TAG_HDEN));
+        }
+        Scope s(e, TAG_SMALL);
+        if (!div_has_matrix_den(e->div)) {
+            TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+            TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
+        }
+        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, 1.0f));
+    }
+    const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
+    TRY(recon(e, !nocost));
+    Scope s(e, TAG_SMALL);
+    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    const double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    return finish_cost(e->st, e->cost_partials, nocost ? 0 : e->n_cost_used, scale, useW ? e->l1W : nullptr, e->KT, e->lamW,
+                       useH ? e->l1H : nullptr, e->K, e->lamH, e->cost);
+}
+
+nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
+nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
+    NMFX_HIP(hipMemcpyAsync(dst_dev, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
+    for (int it = 0; it < iters; ++it) {
+        TRY(nmfx_engine_wstep_partial(e));
+        TRY(nmfx_engine_wstep_finish(e));
+        TRY(nmfx_engine_hstep(e));
+        if (dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    }
+    return NMFX_OK;
+}
+
+// ---- profiling: hipEvent pairs around every launch group, on the engine's stream -----------------
+nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable) {
+    e->prof = enable != 0;
+    e->events.clear();
+    e->pool_used = 0;
+    return NMFX_OK;
+}
+int32_t nmfx_engine_profile_ntags(void) { return TAG_COUNT; }
+const char *nmfx_engine_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < TAG_COUNT) ? kTagNames[tag] : ""; }
+// after the stream is synchronised: total ms and launch count per tag
+nmfx_status nmfx_engine_profile_read(nmfx_engine *e, double *ms_per_tag, int32_t *count_per_tag) {
+    for (int t = 0; t < TAG_COUNT; ++t) { ms_per_tag[t] = 0.0; count_per_tag[t] = 0; }
+    for (const ProfEvent &pe : e->events) {
+        float ms = 0.f;
+        NMFX_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+        ms_per_tag[pe.tag] += ms;
+        count_per_tag[pe.tag] += 1;
+    }
+    return NMFX_OK;
+}
+// algorithmic flops of ONE launch of the GEMM behind `tag` (2*M*N*Kc by formula) and its algorithmic HBM bytes
+nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, double *bytes) {
+    const double m = (double)e->m, n = (double)e->n, KT = (double)e->KT;
+    const double f = 2.0 * m * n * KT;
+    const bool two_in = mdiv(e) != NMFX_DIV_EUCLIDEAN;
+    double b = 0.0;
+    switch (tag) {
+    case TAG_RECON: b = 4.0 * (m * n + m * KT + e->K * n); break;
+    case TAG_RECON_COST: b = 4.0 * (2.0 * m * n + m * KT + e->K * n); break;
+    case TAG_WNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + e->K * n); break;
+    case TAG_WDEN: b = 4.0 * (m * n + m * KT + e->K * n); break;
+    case TAG_HNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + 2.0 * e->K * n); break;
+    case TAG_HDEN: b = 4.0 * (m * n + m * KT + 2.0 * e->K * n); break;
+    default: *flops = 0; *bytes = 0; return NMFX_OK;
+    }
+    *flops = f;
+    *bytes = b;
+    return NMFX_OK;
+}
+
+// ---- kernel-level entry point (tests) -------------------------------------------------------------
+nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t Kc, const float *A, const float *A2,
+                          int64_t lda, int32_t proA, const float *B, const float *B2, int64_t ldb, int32_t proB, float *C, int64_t ldc,
+                          int32_t accumulate, void *workspace, size_t workspace_bytes) {
+    TRY(check_device(0));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.Kc = Kc;
+    g.A = OpView{A, A2, (long)lda, opA == NMFX_OP_N ? VIEW_RC : VIEW_KC, 0, 0, 0, proA};
+    g.B = OpView{B, B2, (long)ldb, opB == NMFX_OP_N ? VIEW_KC : VIEW_RC, 0, 0, 0, proB};
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// blocking host-buffer API
+// =============================================================================================
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    nmfx_status alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); p = nullptr; return NMFX_ERR_NOMEM; }
+        return NMFX_OK;
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+size_t dsize(int dtype) { return dtype == NMFX_F64 ? 8 : 4; }
+
+// host (f32/f64) -> device fp32, converted on the device through a staging buffer; out = in / divide_by
+nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by, DevBuf &stage, size_t stage_elems) {
+    const char *h = static_cast<const char *>(host);
+    for (size_t off = 0; off < count; off += stage_elems) {
+        size_t c = count - off < stage_elems ? count - off : stage_elems;
+        NMFX_HIP(hipMemcpyAsync(stage.p, h + off * dsize(dtype), c * dsize(dtype), hipMemcpyHostToDevice, st));
+        TRY(cvt_to_f32(st, stage.p, dtype, dev + off, (long)c, divide_by));
+        NMFX_HIP(hipStreamSynchronize(st));
+    }
+    return NMFX_OK;
+}
+nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count, DevBuf &stage, size_t stage_elems) {
+    char *h = static_cast<char *>(host);
+    if (dtype == NMFX_F32) {
+        NMFX_HIP(hipMemcpyAsync(h, dev, count * 4, hipMemcpyDeviceToHost, st));
+        NMFX_HIP(hipStreamSynchronize(st));
+        return NMFX_OK;
+    }
+    for (size_t off = 0; off < count; off += stage_elems) {
+        size_t c = count - off < stage_elems ? count - off : stage_elems;
+        TRY(cvt_to_f64(st, dev + off, stage.as<double>(), (long)c));
+        NMFX_HIP(hipMemcpyAsync(h + off * 8, stage.p, c * 8, hipMemcpyDeviceToHost, st));
+        NMFX_HIP(hipStreamSynchronize(st));
+    }
+    return NMFX_OK;
+}
+
+constexpr size_t STAGE_ELEMS = (size_t)8 << 20;  // 64 MiB of doubles
+
+nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc) {
+    if (!p || !r) { set_error("null problem/result"); return NMFX_ERR_INVALID; }
+    if (p->m <= 0 || p->n <= 0 || p->K_total <= 0 || p->T <= 0) { set_error("m, n, K_total, T must be positive"); return NMFX_ERR_INVALID; }
+    if (!p->V || !p->W_init || !p->H_init || !r->W || !r->H || !r->cost) { set_error("V, W_init, H_init, result.W, result.H, result.cost are required"); return NMFX_ERR_INVALID; }
+    if (p->dtype != NMFX_F32 && p->dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
+    if (p->maxiter <= 0) { set_error("maxiter must be positive (the wrapper applies the reference default)"); return NMFX_ERR_INVALID; }
+    if (!nmfsc) {
+        if (p->num_sources < 1) { set_error("num_sources must be >= 1"); return NMFX_ERR_INVALID; }
+        if (p->num_sources > 1 && !p->K_s) { set_error("K_s is required when num_sources > 1"); return NMFX_ERR_INVALID; }
+        if (p->K_s) {
+            long sum = 0;
+            for (int s = 0; s < p->num_sources; ++s) { if (p->K_s[s] <= 0) { set_error("K_s entries must be positive"); return NMFX_ERR_INVALID; } sum += p->K_s[s]; }
+            if (sum != p->K_total) { set_error("sum(K_s) = %ld != K_total = %d", sum, p->K_total); return NMFX_ERR_INVALID; }
+        }
+        if (p->divergence == NMFX_DIV_AB && p->alpha == 0 && p->beta == 0) {   // nmf.m:120-122
+            set_error("alpha = 0 and beta = 0 is not supported at this time.");
+            return NMFX_ERR_INVALID;
+        }
+    }
+    return NMFX_OK;
+}
+
+nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
+    TRY(validate_problem(p, r, false));
+    if (algorithm == 0 && p->T != 1) { set_error("nmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
+    TRY(check_device(p->device));
+    const int K = p->K_total, S = p->num_sources;
+    std::vector<float> lw(K, 0.f), lh(K, 0.f);
+    std::vector<uint8_t> fw(K, 0), fh(K, 0);
+    for (int s = 0, k0 = 0; s < S; ++s) {
+        const int Ks = p->K_s ? p->K_s[s] : K;
+        for (int k = k0; k < k0 + Ks; ++k) {
+            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
+            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
+            if (p->W_fixed) fw[k] = p->W_fixed[s];
+            if (p->H_fixed) fh[k] = p->H_fixed[s];
+        }
+        k0 += Ks;
+    }
+    nmfx_engine_desc d{};
+    d.m = p->m; d.n_local = p->n; d.K_total = K; d.T = p->T; d.divergence = p->divergence; d.alpha = p->alpha; d.beta = p->beta;
+    d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
+    d.device = p->device; d.stream = nullptr; d.algorithm = algorithm;
+    size_t ws_bytes = 0, packed_count = 0;
+    TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
+    TRY(nmfx_engine_packed_count(&d, &packed_count));
+    const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
+    DevBuf V, W, H, ws, packed, stage;
+    TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(ws.alloc(ws_bytes)); TRY(packed.alloc(packed_count * 4));
+    TRY(stage.alloc(STAGE_ELEMS * 8));
+    hipStream_t st = nullptr;
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    nmfx_engine *e = nullptr;
+    TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
+    nmfx_status s = nmfx_engine_init(e);
+    int it = 0;
+    r->iters_run = 0;
+    for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
+        if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
+        if ((s = nmfx_engine_wstep_finish(e)) != NMFX_OK) break;
+        if ((s = nmfx_engine_hstep(e)) != NMFX_OK) break;
+        hipError_t he = hipMemcpy(&r->cost[it], e->cost, sizeof(double), hipMemcpyDeviceToHost);   // syncs the iteration
+        if (he != hipSuccess) { set_error("cost readback: %s", hipGetErrorString(he)); s = NMFX_ERR_HIP; break; }
+        r->iters_run = it + 1;
+        // nmf.m:221-224 / cnmf.m:254-257
+        if (p->tolerance >= 0 && it > 0 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) break;
+    }
+    r->cost_len = r->iters_run;
+    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKT, stage, STAGE_ELEMS);
+    if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
+    nmfx_engine_destroy(e);
+    return s;
+}
+
+// 0.5*||V - V_hat||^2 from the per-block partials of an EPI_COST GEMM (host double)
+nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out) {
+    TRY(finish_cost(st, partials, count, 0.5, nullptr, 0, nullptr, nullptr, 0, nullptr, cost_dev));
+    NMFX_HIP(hipMemcpyAsync(out, cost_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipStreamSynchronize(st));
+    return NMFX_OK;
+}
+
+// nmfsc.m:57-245
+nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
+    TRY(validate_problem(p, r, true));
+    if (p->T != 1) { set_error("nmfsc: T must be 1"); return NMFX_ERR_INVALID; }
+    const long m = p->m, n = p->n;
+    const int K = p->K_total;
+    const size_t mn = (size_t)m * n, mK = (size_t)m * K, Kn = (size_t)K * n;
+    double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62
+    if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    TRY(check_device(p->device));
+    hipStream_t st = nullptr;
+    double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity;
+    double L1a = 0, L1s = 0;
+    if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // nmfsc.m:89-93
+    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // nmfsc.m:102-106
+    const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
+
+    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch;
+    TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W.alloc(mK * 4)); TRY(Wn.alloc(mK * 4)); TRY(Hk.alloc(Kn * 4)); TRY(HT.alloc(Kn * 4));
+    TRY(HnT.alloc(Kn * 4));
+    const size_t gmax = Kn > mK ? Kn : mK;
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));
+    TRY(stage.alloc(STAGE_ELEMS * 8));
+    const int nparts = (int)gemm_grid_blocks(m, n);
+    TRY(part.alloc(sizeof(double) * nparts)); TRY(costd.alloc(64 + sizeof(double) * K));
+    size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n);
+    if (sb2 > sb) sb = sb2;
+    TRY(scratch.alloc(sb));
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
+    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mK, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    float *Wd = W.as<float>(), *Wnew = Wn.as<float>(), *HTd = HT.as<float>(), *HnewT = HnT.as<float>();
+    TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
+    if (sW > 0) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96
+    if (sH > 0) TRY(projfunc_cols(st, HTd, n, K, L1s, 1.0, 1, nullptr));    // nmfsc.m:107-109
+
+    // V_hat = Wx * Hx (Hx given transposed, n x K) with the residual objective; returns 0.5*||V - V_hat||^2
+    auto recon_obj = [&](const float *Wx, const float *HxT, double *obj) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = m; g.N = n; g.Kc = K;
+        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+        g.B = OpView{HxT, nullptr, n, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+        g.C = Vh.as<float>(); g.ldc = m; g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = V.as<float>(); g.ldv = m;
+        g.cost_partials = part.as<double>(); g.splitk = 1;
+        long blocks = 0;
+        TRY(launch_gemm(st, g, &blocks));
+        return read_obj(st, part.as<double>(), (int)blocks, costd.as<double>(), obj);
+    };
+    // outT (n x K) = f(V, V_hat)' * W
+    auto xt_w = [&](const float *x, const float *x2, int func, float *outT) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = n; g.N = K; g.Kc = m;
+        g.A = OpView{x, x2, m, VIEW_KC, 0, 0, 0, func};
+        g.B = OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        g.C = outT; g.ldc = n; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+    // out (m x K) = f(V, V_hat) * H'
+    auto x_ht = [&](const float *x, const float *x2, int func, float *out) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = m; g.N = K; g.Kc = n;
+        g.A = OpView{x, x2, m, VIEW_RC, 0, 0, 0, func};
+        g.B = OpView{HTd, nullptr, n, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        g.C = out; g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+
+    double stepH = 1.0, stepW = 1.0;   // nmfsc.m:133-134
+    TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
+    int ncost = p->maxiter + 1, nH = 0, nW = 0;
+    bool early = false;
+    r->converged_early = 0;
+    for (int it = 1; it <= p->maxiter && !early; ++it) {
+        if (!fixH) {
+            if (sH > 0) {
+                TRY(xt_w(V.as<float>(), Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));   // dH' = (V_hat - V)' * W   nmfsc.m:144-148
+                const double begobj = r->cost[it - 1];                                      // nmfsc.m:149
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
+                    TRY(projfunc_cols(st, HnewT, n, K, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
+                    double newobj;
+                    TRY(recon_obj(Wd, HnewT, &newobj));                                         // nmfsc.m:160-161
+                    if (newobj <= begobj) break;                                                // nmfsc.m:164
+                    stepH /= 2;                                                                 // nmfsc.m:169
+                    if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
+                }
+                if (r->tries_H) r->tries_H[nH] = tries;
+                ++nH;
+                if (early) { ncost = it; break; }
+                stepH *= 1.2;                                                                   // nmfsc.m:178
+                std::swap(HTd, HnewT);                                                          // nmfsc.m:179
+            } else {
+                TRY(xt_w(V.as<float>(), nullptr, NMFX_PRO_NONE, G1.as<float>()));               // (W'*V)'       nmfsc.m:144
+                TRY(xt_w(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // (W'*V_hat)'   nmfsc.m:145
+                TRY(mu_plain(st, HTd, G1.as<float>(), G2.as<float>(), (long)Kn));               // nmfsc.m:182
+                double *nrm2 = costd.as<double>() + 8;
+                TRY(col_reduce(st, HTd, n, n, K, 1, nrm2));                                     // nmfsc.m:185
+                TRY(scale_cols(st, HTd, n, K, nrm2, 1, 1));                                     // nmfsc.m:186
+                TRY(scale_cols(st, Wd, m, K, nrm2, 1, 0));                                      // nmfsc.m:187
+            }
+        }
+        if (!fixW) {
+            double begobj;
+            TRY(recon_obj(Wd, HTd, &begobj));                                                   // nmfsc.m:193,197
+            if (sW > 0) {
+                TRY(x_ht(V.as<float>(), Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));        // dW = (V_hat - V) * H'   nmfsc.m:194-200
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    TRY(axpy_f32(st, (long)mK, (float)(-stepW), G1.as<float>(), Wd, Wnew));     // nmfsc.m:205
+                    TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
+                    double newobj;
+                    TRY(recon_obj(Wnew, HTd, &newobj));                                         // nmfsc.m:211-212
+                    if (newobj <= begobj) break;                                                // nmfsc.m:215
+                    stepW /= 2;
+                    if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
+                }
+                if (r->tries_W) r->tries_W[nW] = tries;
+                ++nW;
+                if (early) { ncost = it; break; }
+                stepW *= 1.2;                                                                   // nmfsc.m:228
+                std::swap(Wd, Wnew);                                                            // nmfsc.m:229
+            } else {
+                TRY(x_ht(V.as<float>(), nullptr, NMFX_PRO_NONE, G1.as<float>()));               // nmfsc.m:194
+                TRY(x_ht(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // nmfsc.m:195
+                TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
+            }
+        }
+        TRY(recon_obj(Wd, HTd, &r->cost[it]));                                                  // nmfsc.m:237-238
+        if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
+            ncost = it + 1;
+            break;
+        }
+    }
+    r->cost_len = ncost;
+    r->iters_run = ncost - 1;
+    r->stepsize_H = stepH; r->stepsize_W = stepW;
+    r->converged_early = early ? 1 : 0;
+    if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+    if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+    TRY(transpose_f32(st, HTd, n, K, Hk.as<float>()));
+    TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
+    TRY(download(st, Hk.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    return NMFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 0); }
+nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 1); }
+nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
+
+nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W, const void *H, void *V_hat,
+                             int32_t device) {
+    if (m <= 0 || n <= 0 || K <= 0 || T <= 0 || !W || !H || !V_hat) { set_error("nmfx_reconstruct: bad arguments"); return NMFX_ERR_INVALID; }
+    TRY(check_device(device));
+    const size_t mn = (size_t)m * n, mKT = (size_t)m * K * T, Kn = (size_t)K * n;
+    DevBuf Wd, Hd, Vd, stage;
+    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    hipStream_t st = nullptr;
+    TRY(upload(st, W, dtype, Wd.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, H, dtype, Hd.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = m; g.N = n; g.Kc = (long)K * T;
+    g.A = OpView{Wd.as<float>(), nullptr, (long)m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+    if (T == 1) g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+    else g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE};
+    g.C = Vd.as<float>(); g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
+    TRY(launch_gemm(st, g));
+    return download(st, Vd.as<float>(), dtype, V_hat, mn, stage, STAGE_ELEMS);
+}
+
+nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,
+                          int32_t *usediters, int32_t device) {
+    if (N <= 0 || count <= 0 || !s || !v) { set_error("nmfx_projfunc: bad arguments"); return NMFX_ERR_INVALID; }
+    TRY(check_device(device));
+    const size_t tot = (size_t)N * count;
+    DevBuf X, it, stage;
+    TRY(X.alloc(tot * 4)); TRY(it.alloc(sizeof(int) * count)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    hipStream_t st = nullptr;
+    TRY(upload(st, s, dtype, X.as<float>(), tot, 1.0, stage, STAGE_ELEMS));
+    TRY(projfunc_cols(st, X.as<float>(), N, count, k1, k2, nn, it.as<int>()));
+    if (usediters) NMFX_HIP(hipMemcpy(usediters, it.p, sizeof(int) * count, hipMemcpyDeviceToHost));
+    return download(st, X.as<float>(), dtype, v, tot, stage, STAGE_ELEMS);
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// Bandwidth-class kernels around the MFMA contractions: deterministic split-K reduction, fp64
+// column/row reductions, the multiplicative-update epilogues (nmf.m:168-169,199; cnmf.m:193-199,231)
+// and cost assembly (nmf.m:206-218).  All reductions accumulate in fp64 and are order-deterministic.
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum of up to 16 waves; result valid in every thread
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+}
+
+// ---- split-K slab reduction -------------------------------------------------------------------
+__global__ void reduce_slabs_kernel(const float *slabs, int nslab, long stride, long count, float *out, int accumulate) {
+    long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (idx + 3 < count && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0 && (stride & 3) == 0) {
+        float4 s = *reinterpret_cast<const float4 *>(slabs + idx);
+        for (int z = 1; z < nslab; ++z) {
+            float4 t = *reinterpret_cast<const float4 *>(slabs + z * stride + idx);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (accumulate) {
+            float4 o = *reinterpret_cast<float4 *>(out + idx);
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(out + idx) = s;
+    } else {
+        for (long e = idx; e < idx + 4 && e < count; ++e) {
+            float s = slabs[e];
+            for (int z = 1; z < nslab; ++z) s += slabs[z * stride + e];
+            if (accumulate) s += out[e];
+            out[e] = s;
+        }
+    }
+}
+nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out, int accumulate) {
+    if (count <= 0) return NMFX_OK;
+    long nthr = (count + 3) / 4;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, slabs, nslab, slab_stride, count, out, accumulate);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// ---- column reductions (one workgroup per column) ----------------------------------------------
+__device__ __forceinline__ double red_f(int mode, float x) {
+    return mode == 1 ? (double)x * (double)x : (mode == 2 ? (double)fabsf(x) : (double)x);
+}
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float *X, long rows, long ld, int mode, double *out) {
+    __shared__ double red[4];
+    const float *x = X + ld * blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < rows; i += 256) s += red_f(mode, x[i]);
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+nmfx_status col_reduce(hipStream_t st, const float *X, long rows, long ld, int ncols, int mode, double *out) {
+    if (ncols <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(col_reduce_kernel, dim3(ncols), dim3(256), 0, st, X, rows, ld, mode, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// ---- row reductions: out[k] = sum_j f(X[k + ld*j]); two deterministic stages ---------------------
+constexpr int RR_BLOCKS = 256;
+__global__ __launch_bounds__(256) void row_reduce_stage1(const float *X, int rows, long ld, long ncols, int mode, double *part) {
+    __shared__ double red[4][64];
+    const int kk = threadIdx.x & 63, jj = threadIdx.x >> 6;
+    const long per = (ncols + gridDim.x - 1) / gridDim.x;
+    const long j0 = per * blockIdx.x, j1 = (j0 + per < ncols) ? j0 + per : ncols;
+    for (int kb = 0; kb < rows; kb += 64) {
+        const int k = kb + kk;
+        double s = 0.0;
+        if (k < rows)
+            for (long j = j0 + jj; j < j1; j += 4) s += red_f(mode, X[k + ld * j]);
+        __syncthreads();
+        red[jj][kk] = s;
+        __syncthreads();
+        if (jj == 0 && k < rows) part[(long)blockIdx.x * rows + k] = red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk];
+    }
+}
+__global__ void row_reduce_stage2(const double *part, int rows, int nblk, double *out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rows) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * rows + k];
+    out[k] = s;
+}
+nmfx_status row_reduce(hipStream_t st, const float *X, int rows, long ld, long ncols, int mode, double *out, void *scratch) {
+    if (rows <= 0) return NMFX_OK;
+    double *part = static_cast<double *>(scratch);  // RR_BLOCKS * rows doubles
+    hipLaunchKernelGGL(row_reduce_stage1, dim3(RR_BLOCKS), dim3(256), 0, st, X, rows, ld, ncols, mode, part);
+    hipLaunchKernelGGL(row_reduce_stage2, dim3((rows + 63) / 64), dim3(64), 0, st, part, rows, RR_BLOCKS, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+size_t row_reduce_scratch_bytes(int rows) { return sizeof(double) * (size_t)RR_BLOCKS * rows; }
+
+// ---- W update: one workgroup per column c = k + K*t -------------------------------------------
+//   dn = sum_i W.*P  (= diag(H*B'*W)),  dp = sum_i W.*N
+//   W <- W .* ((N + W*dn).^e ./ max((P + W*dp).^e + lambda, eps))          nmf.m:168 / cnmf.m:193
+__global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const int k = c % p.K;
+    if (p.fixW && p.fixW[k]) return;
+    float *w = p.W + p.m * c;
+    const float *nn = p.N + p.m * c;
+    const float *pp = p.P ? p.P + p.m * c : nullptr;
+    const float pv = p.Pvec ? (float)p.Pvec[c] : 0.0f;
+    double dn = 0.0, dp = 0.0;
+    for (long i = threadIdx.x; i < p.m; i += 256) {
+        const float wi = w[i];
+        dn += (double)wi * (double)(pp ? pp[i] : pv);
+        dp += (double)wi * (double)nn[i];
+    }
+    dn = block_sum<4>(dn, red);
+    dp = block_sum<4>(dp, red);
+    const float fdn = (float)dn, fdp = (float)dp, lam = p.lamW ? p.lamW[k] : 0.0f;
+    double ss = 0.0;
+    for (long i = threadIdx.x; i < p.m; i += 256) {
+        const float wi = w[i];
+        float neg = fmaf(wi, fdn, nn[i]);
+        float pos = fmaf(wi, fdp, pp ? pp[i] : pv);
+        if (p.inv_exp != 1.0f) { neg = powf(neg, p.inv_exp); pos = powf(pos, p.inv_exp); }
+        const float wn = wi * (neg / fmaxf(pos + lam, NMFX_EPS_F));
+        w[i] = wn;
+        ss += (double)wn * (double)wn;
+    }
+    ss = block_sum<4>(ss, red);
+    if (threadIdx.x == 0) p.sumsq[c] = ss;
+}
+nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
+    hipLaunchKernelGGL(w_update_kernel, dim3(p.K * p.T), dim3(256), 0, st, p);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// nmf.m:169   W(:,k) <- W(:,k) * (1/sqrt(sum W(:,k).^2))
+// cnmf.m:196-199  W(:,k,:) <- W(:,k,:) / (norm(squeeze(W(:,k,:)),'fro') / T)
+__global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix,
+                                                          int cnmf_rule, double *f_out) {
+    const int c = blockIdx.x, k = c % K, t = c / K;
+    if (fix && fix[k]) return;
+    float *w = W + m * c;
+    if (cnmf_rule) {
+        double s = 0.0;
+        for (int tt = 0; tt < T; ++tt) s += sumsq[k + K * tt];
+        const double nrm = sqrt(s) / (double)T;
+        const float f = (float)nrm;
+        for (long i = threadIdx.x; i < m; i += 256) w[i] = w[i] / f;
+        if (f_out && t == 0 && threadIdx.x == 0) f_out[k] = nrm;
+    } else {
+        const float f = (float)(1.0 / sqrt(sumsq[c]));
+        for (long i = threadIdx.x; i < m; i += 256) w[i] = w[i] * f;
+    }
+}
+nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
+                        double *f_out) {
+    hipLaunchKernelGGL(w_normalize_kernel, dim3(K * T), dim3(256), 0, st, W, m, K, T, sumsq, fix, cnmf_rule, f_out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// H(k,:) *= s[k]   (cnmf.m:165)
+__global__ void scale_rows_kernel(float *H, int K, long count, const double *s) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) H[idx] = (float)s[idx % K] * H[idx];
+}
+nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s) {
+    long count = (long)K * n;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H, K, count, s);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// H <- H .* (Gn.^e ./ max(Gp.^e + lambda, eps))     nmf.m:199 / cnmf.m:231
+__global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long count,
+                                const float *lamH, const uint8_t *fixH, float inv_exp) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const int k = (int)(idx % K);
+    if (fixH && fixH[k]) return;
+    float neg = Gn[idx];
+    float pos = Gp ? Gp[idx] : (float)Gpvec[k];
+    if (inv_exp != 1.0f) { neg = powf(neg, inv_exp); pos = powf(pos, inv_exp); }
+    const float lam = lamH ? lamH[k] : 0.0f;
+    H[idx] = H[idx] * (neg / fmaxf(pos + lam, NMFX_EPS_F));
+}
+nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
+                     const float *lamH, const uint8_t *fixH, float inv_exp) {
+    long count = (long)K * n;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H, Gn, Gp, Gpvec, K, count, lamH, fixH, inv_exp);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// cost = scale * sum(partials) + sum_c lamW[c%K]*l1W[c] + sum_k lamH[k]*l1H[k]      nmf.m:206-218
+__global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials, int count, double scale, const double *l1W, int nW,
+                                                          const float *lamW, const double *l1H, int K, const float *lamH, double *out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
+    s = block_sum<4>(s, red) * scale;
+    if (threadIdx.x == 0) {
+        if (l1W) for (int c = 0; c < nW; ++c) s += (double)lamW[c % K] * l1W[c];
+        if (l1H) for (int k = 0; k < K; ++k) s += (double)lamH[k] * l1H[k];
+        *out = s;
+    }
+}
+nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
+                        const double *l1H, int K, const float *lamH, double *out) {
+    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, l1W, nW, lamW, l1H, K, lamH, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+__global__ void fill_kernel(float *p, long count, float v) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) p[idx] = v;
+}
+nmfx_status fill_f32(hipStream_t st, float *p, long count, float v) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, p, count, v);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// out = y + a*x   (nmfsc.m:154 Hnew = H - stepsize*dH)
+__global__ void axpy_kernel(long count, float a, const float *x, const float *y, float *out) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) out[idx] = y[idx] + a * x[idx];
+}
+nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, a, x, y, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// X <- X .* (neg ./ max(pos, eps))    nmfsc.m:182,232
+__global__ void mu_plain_kernel(float *X, const float *neg, const float *pos, long count) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) X[idx] = X[idx] * (neg[idx] / fmaxf(pos[idx], NMFX_EPS_F));
+}
+nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(mu_plain_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, X, neg, pos, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// column scaling by s[c] or 1/s[c] (nmfsc.m:185-187)
+__global__ void scale_cols_kernel(float *X, long rows, long count, const double *s, int use_sqrt, int divide) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    double f = s[idx / rows];
+    if (use_sqrt) f = sqrt(f);
+    X[idx] = divide ? (float)(1.0 / f) * X[idx] : X[idx] * (float)f;
+}
+nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide) {
+    long count = rows * ncols;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, X, rows, count, s, use_sqrt, divide);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// out (cols x rows, column-major) = in' ; 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float *in, long rows, long cols, float *out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+    for (int y = ty; y < 32; y += 8)
+        if (r0 + tx < rows && c0 + y < cols) tile[y][tx] = in[(r0 + tx) + rows * (c0 + y)];
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8)
+        if (c0 + tx < cols && r0 + y < rows) out[(c0 + tx) + cols * (r0 + y)] = tile[tx][y];
+}
+nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out) {
+    if (rows <= 0 || cols <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, st, in, rows, cols, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// broadcast vector helper for KL: Pvec[c = k + K*t] = sum_{j < n - t} H[k,j]  given full row sums and the tail columns
+//   (cnmf.m:191-192 with V_pos = ones: ones(m,n) * H_shifted' = rowsum of the first n-t columns)
+__global__ void kl_pvec_kernel(const double *rowsum, const float *H, int K, long n, int T, double *Pvec) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K * T) return;
+    const int k = c % K, t = c / K;
+    double s = rowsum[k];
+    for (int d = 0; d < t; ++d) s -= (double)H[k + K * (n - 1 - d)];
+    Pvec[c] = s;
+}
+nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec) {
+    hipLaunchKernelGGL(kl_pvec_kernel, dim3((K * T + 63) / 64), dim3(64), 0, st, rowsum, H, K, n, T, Pvec);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// Gpvec[k] = sum_t colsum(W_t)[k]   (cnmf.m:220-221: V_pos = ones is NOT shifted for KL)
+__global__ void sum_over_t_kernel(const double *colsum, int K, int T, double *out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += colsum[k + K * t];
+    out[k] = s;
+}
+nmfx_status sum_over_t(hipStream_t st, const double *colsum, int K, int T, double *out) {
+    hipLaunchKernelGGL(sum_over_t_kernel, dim3((K + 63) / 64), dim3(64), 0, st, colsum, K, T, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// packed buffer helpers for the multi-GPU exchange: doubles <-> floats
+__global__ void d2f_kernel(const double *in, float *out, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (float)in[i];
+}
+__global__ void f2d_kernel(const float *in, double *out, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (double)in[i];
+}
+nmfx_status d2f(hipStream_t st, const double *in, float *out, int count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(d2f_kernel, dim3((count + 255) / 256), dim3(256), 0, st, in, out, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+nmfx_status f2d(hipStream_t st, const float *in, double *out, int count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(f2d_kernel, dim3((count + 255) / 256), dim3(256), 0, st, in, out, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+
+// host dtype <-> device fp32 conversion (device side, so uploads of float64 MATLAB arrays stay PCIe-bound)
+__global__ void cvt_d2f_kernel(const double *in, float *out, long count, double inv_scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (float)(inv_scale == 1.0 ? in[i] : in[i] / inv_scale);
+}
+__global__ void cvt_f2f_kernel(const float *in, float *out, long count, double inv_scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = inv_scale == 1.0 ? in[i] : (float)((double)in[i] / inv_scale);
+}
+__global__ void cvt_f2d_kernel(const float *in, double *out, long count) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (double)in[i];
+}
+nmfx_status cvt_to_f32(hipStream_t st, const void *in, int dtype, float *out, long count, double divide_by) {
+    if (count <= 0) return NMFX_OK;
+    dim3 g((unsigned)((count + 255) / 256)), b(256);
+    if (dtype == NMFX_F64) hipLaunchKernelGGL(cvt_d2f_kernel, g, b, 0, st, static_cast<const double *>(in), out, count, divide_by);
+    else hipLaunchKernelGGL(cvt_f2f_kernel, g, b, 0, st, static_cast<const float *>(in), out, count, divide_by);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(cvt_f2d_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, out, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+}  // namespace nmfx

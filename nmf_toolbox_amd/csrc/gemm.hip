@@ -1,0 +1,381 @@
+// General fp32 MFMA GEMM with operand views, fused element-wise prologues and a fused divergence
+// epilogue (gfx950).  C (M x N, column-major) = op(A) * op(B).
+//
+// This is the "materialised V_hat" building block of the engine: every contraction of
+// nmf.m:149-203, cnmf.m:187-236, nmfsc.m:144-238 and ReconstructFromDecomposition.m:31-38 is one
+// launch of it -- the convolutive shift-sums are expressed as stacked/shifted operand VIEWS
+// (nmfx_internal.h), never as padded copies, and V./V_hat style element maps are applied while
+// the tile is staged into LDS.
+//
+// Structure: 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2)x(BN/2) built from
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Operands are staged through LDS as
+// S[k][r] (r contiguous) so each MFMA operand register is one conflict-free ds_read_b32; the next
+// tile's global loads are issued before the current tile's MFMAs and written to the other LDS
+// buffer after them (one barrier per k-tile).  The MFMA roles are swapped (B tile feeds the "A"
+// port) so that lanes 0-31 of an accumulator register hold 32 CONSECUTIVE ROWS i of one column of
+// C: stores to C and loads of V in the epilogue are 128-byte contiguous segments.
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g) {
+    switch (v.mode) {
+    case VIEW_RC: off = r; g = 0; break;
+    case VIEW_HSTACK_RC: { int t = r / v.blk; int k = r - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
+    case VIEW_HSTACK_KC: off = v.ld * r; g = r; break;
+    case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
+    default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
+    }
+}
+__device__ __forceinline__ void dec_k(const OpView &v, int kc, long &off, int &g) {
+    switch (v.mode) {
+    case VIEW_RC: off = v.ld * kc; g = 0; break;
+    case VIEW_HSTACK_RC: off = v.ld * kc; g = kc; break;
+    case VIEW_HSTACK_KC: { int t = kc / v.blk; int k = kc - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
+    case VIEW_WSTACK_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.tstride * t; g = 0; } break;
+    case VIEW_XSHIFT_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.ld * t; g = -t; } break;
+    default: off = kc; g = 0; break;  // VIEW_KC
+    }
+}
+
+__device__ __forceinline__ float pro1(int func, float x, float y) {
+    switch (func) {
+    case NMFX_PRO_RATIO: return x / y;
+    case NMFX_PRO_RATIO_SQ: return x / (y * y);
+    case NMFX_PRO_RECIP2: return 1.0f / y;
+    case NMFX_PRO_DIFF: return y - x;
+    default: return x;
+    }
+}
+__device__ __forceinline__ float4 pro4(int func, float4 x, float4 y) {
+    return make_float4(pro1(func, x.x, y.x), pro1(func, x.y, y.y), pro1(func, x.z, y.z), pro1(func, x.w, y.w));
+}
+
+// one thread's share of a BR x BK operand tile: NCH chunks of 4 elements along the contiguous direction
+template <int BR, bool KC, bool FAST>
+struct Loader {
+    static constexpr int NCH = BR * BK / 4 / NTHREADS;
+    static constexpr int LDS_STRIDE = BR + (KC ? 1 : 0);
+    // RC: chunk = rows 4c..4c+3 of k-row (kq + p*KSTEP);  KC: chunk = k 4c..4c+3 of row (rq + p*RSTEP)
+    static constexpr int CPR = KC ? (BK / 4) : (BR / 4);  // chunks per line
+    static constexpr int LSTEP = NTHREADS / CPR;          // lines covered per pass
+    float4 reg[NCH];
+    long offr[KC ? NCH : 1];
+    int gr[KC ? NCH : 1];
+    int c, q;
+
+    __device__ __forceinline__ void init(const OpView &v, int tid, int r_tile0, long R) {
+        c = tid % CPR;
+        q = tid / CPR;
+        if (FAST) {
+            if (KC) {
+#pragma unroll
+                for (int p = 0; p < NCH; ++p) dec_r(v, r_tile0 + q + p * LSTEP, offr[p], gr[p]);
+            } else {
+                dec_r(v, r_tile0 + 4 * c, offr[0], gr[0]);
+            }
+        }
+    }
+    __device__ __forceinline__ float elem(const OpView &v, int r, int kc, long R, long Kend) {
+        if (r >= R || kc >= Kend) return 0.0f;
+        long o1, o2; int g1, g2;
+        dec_r(v, r, o1, g1);
+        dec_k(v, kc, o2, g2);
+        if (g1 + g2 < 0) return 0.0f;
+        float x = v.p[o1 + o2];
+        float y = v.p2 ? v.p2[o1 + o2] : 1.0f;
+        return pro1(v.func, x, y);
+    }
+    __device__ __forceinline__ void load(const OpView &v, int r_tile0, int k0, long R, long Kend) {
+        if (FAST) {
+            if (KC) {
+                long ok; int gk;
+                dec_k(v, k0 + 4 * c, ok, gk);
+#pragma unroll
+                for (int p = 0; p < NCH; ++p) {
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gr[p] + gk >= 0) {
+                        x = *reinterpret_cast<const float4 *>(v.p + offr[p] + ok);
+                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[p] + ok));
+                    }
+                    reg[p] = x;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NCH; ++p) {
+                    long ok; int gk;
+                    dec_k(v, k0 + q + p * LSTEP, ok, gk);
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gr[0] + gk >= 0) {
+                        x = *reinterpret_cast<const float4 *>(v.p + offr[0] + ok);
+                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[0] + ok));
+                    }
+                    reg[p] = x;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NCH; ++p) {
+                int line = q + p * LSTEP;
+                float4 x;
+                if (KC) {
+                    int r = r_tile0 + line, kc = k0 + 4 * c;
+                    x = make_float4(elem(v, r, kc, R, Kend), elem(v, r, kc + 1, R, Kend), elem(v, r, kc + 2, R, Kend),
+                                    elem(v, r, kc + 3, R, Kend));
+                } else {
+                    int r = r_tile0 + 4 * c, kc = k0 + line;
+                    x = make_float4(elem(v, r, kc, R, Kend), elem(v, r + 1, kc, R, Kend), elem(v, r + 2, kc, R, Kend),
+                                    elem(v, r + 3, kc, R, Kend));
+                }
+                reg[p] = x;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float *S) const {
+#pragma unroll
+        for (int p = 0; p < NCH; ++p) {
+            int line = q + p * LSTEP;
+            if (KC) {
+                S[(4 * c + 0) * LDS_STRIDE + line] = reg[p].x;
+                S[(4 * c + 1) * LDS_STRIDE + line] = reg[p].y;
+                S[(4 * c + 2) * LDS_STRIDE + line] = reg[p].z;
+                S[(4 * c + 3) * LDS_STRIDE + line] = reg[p].w;
+            } else {
+                *reinterpret_cast<float4 *>(&S[line * LDS_STRIDE + 4 * c]) = reg[p];
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ double div_term(int div, float v, float s) {
+    switch (div) {
+    case NMFX_DIV_KL: return (double)(v * logf(v / s)) - (double)v + (double)s;     // nmf.m:210
+    case NMFX_DIV_IS: return (double)(logf(s / v) + v / s) - 1.0;                   // nmf.m:212
+    default: { float d = v - s; return (double)d * (double)d; }                     // nmf.m:208 (0.5 applied later)
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using LA = Loader<BM, A_KC, FAST>;
+    using LB = Loader<BN, B_KC, FAST>;
+    constexpr int LDA_S = LA::LDS_STRIDE, LDB_S = LB::LDS_STRIDE;
+    constexpr int A_SZ = BK * LDA_S, B_SZ = BK * LDB_S;
+    constexpr int A_SZ_AL = (A_SZ + 3) & ~3, B_SZ_AL = (B_SZ + 3) & ~3;
+    constexpr int BUF_SZ = A_SZ_AL + B_SZ_AL;  // buffer b: [A tile | B tile] at smem + b*BUF_SZ
+    constexpr int MR = BM / 64, NR = BN / 64;  // 32x32 MFMA tiles per wave along i / j
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wi0 = (wave & 1) * (BM / 2), wj0 = (wave >> 1) * (BN / 2);
+    const int i_tile0 = blockIdx.x * BM, j_tile0 = blockIdx.y * BN;
+
+    long kbeg = 0, kend = p.Kc;
+    float *C = p.C;
+    if (p.splitk > 1) {
+        kbeg = (long)blockIdx.z * p.kc_per_split;
+        kend = kbeg + p.kc_per_split < p.Kc ? kbeg + p.kc_per_split : p.Kc;
+        C += (long)blockIdx.z * p.slab_stride;
+    }
+
+    LA la; LB lb;
+    la.init(p.A, tid, i_tile0, p.M);
+    lb.init(p.B, tid, j_tile0, p.N);
+
+    f32x16 acc[NR][MR];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+    if (ntiles > 0) {
+        la.load(p.A, i_tile0, (int)kbeg, p.M, kend);
+        lb.load(p.B, j_tile0, (int)kbeg, p.N, kend);
+        la.store(smem);
+        lb.store(smem + A_SZ_AL);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) {
+            la.load(p.A, i_tile0, (int)kbeg + (t + 1) * BK, p.M, kend);
+            lb.load(p.B, j_tile0, (int)kbeg + (t + 1) * BK, p.N, kend);
+        }
+        const float *Ac = smem + cur * BUF_SZ, *Bc = Ac + A_SZ_AL;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float fa[NR], fb[MR];
+#pragma unroll
+            for (int a = 0; a < NR; ++a) fa[a] = Bc[(2 * kk + h) * LDB_S + wj0 + 32 * a + l31];
+#pragma unroll
+            for (int b = 0; b < MR; ++b) fb[b] = Ac[(2 * kk + h) * LDA_S + wi0 + 32 * b + l31];
+#pragma unroll
+            for (int a = 0; a < NR; ++a)
+#pragma unroll
+                for (int b = 0; b < MR; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            la.store(smem + (cur ^ 1) * BUF_SZ);
+            lb.store(smem + (cur ^ 1) * BUF_SZ + A_SZ_AL);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[a][b][e] = C[i][j], i = i_tile0+wi0+32b+l31, j = j_tile0+wj0+32a+(e&3)+8(e>>2)+4h
+    double part = 0.0;
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b) {
+            const long i = i_tile0 + wi0 + 32 * b + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long j = j_tile0 + wj0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (FAST || (i < p.M && j < p.N)) {
+                    float s = acc[a][b][e];
+                    if (p.epi == EPI_COST) {
+                        part += div_term(p.cost_div, p.Vref[i + p.ldv * j], s);
+                        if (p.store_c) C[i + p.ldc * j] = s;
+                    } else {
+                        if (p.accumulate) s += C[i + p.ldc * j];
+                        C[i + p.ldc * j] = s;
+                    }
+                }
+            }
+        }
+    if (p.epi == EPI_COST) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        double *red = reinterpret_cast<double *>(smem);
+        __syncthreads();
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
+static nmfx_status launch_cfg(hipStream_t st, const GemmParams &p) {
+    using LA = Loader<BM, A_KC, FAST>;
+    using LB = Loader<BN, B_KC, FAST>;
+    constexpr int A_SZ_AL = (BK * LA::LDS_STRIDE + 3) & ~3, B_SZ_AL = (BK * LB::LDS_STRIDE + 3) & ~3;
+    const size_t lds = sizeof(float) * 2 * (A_SZ_AL + B_SZ_AL);
+    auto kern = gemm_kernel<BM, BN, A_KC, B_KC, FAST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN), (unsigned)(p.splitk > 1 ? p.splitk : 1));
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, p);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+static bool is_kc(int mode) { return mode == VIEW_KC || mode == VIEW_HSTACK_KC || mode == VIEW_WSTACK_KC || mode == VIEW_XSHIFT_KC; }
+
+static bool view_fast_ok(const OpView &v) {
+    if ((reinterpret_cast<uintptr_t>(v.p) & 15) || (v.p2 && (reinterpret_cast<uintptr_t>(v.p2) & 15))) return false;
+    if (v.ld % 4) return false;
+    if (v.mode >= VIEW_HSTACK_KC && (v.blk % 4)) return false;
+    if (v.mode == VIEW_WSTACK_KC && (v.tstride % 4)) return false;
+    return true;
+}
+
+template <int BM, int BN, bool FAST>
+static nmfx_status dispatch_views(hipStream_t st, const GemmParams &p) {
+    const bool akc = is_kc(p.A.mode), bkc = is_kc(p.B.mode);
+    if (akc && bkc) return launch_cfg<BM, BN, true, true, FAST>(st, p);
+    if (akc) return launch_cfg<BM, BN, true, false, FAST>(st, p);
+    if (bkc) return launch_cfg<BM, BN, false, true, FAST>(st, p);
+    return launch_cfg<BM, BN, false, false, FAST>(st, p);
+}
+
+void gemm_tile_shape(long M, long N, int &bm, int &bn) {
+    bm = 128; bn = 128;
+    if (M % 128 != 0 && M % 64 == 0 && M <= 192) bm = 64;
+    if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
+}
+
+nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
+    if (blocks_out) *blocks_out = 0;
+    if (p.M <= 0 || p.N <= 0) return NMFX_OK;
+    int bm, bn;
+    gemm_tile_shape(p.M, p.N, bm, bn);
+    const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
+    bool fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && view_fast_ok(p.A) &&
+                view_fast_ok(p.B);
+    if (!fast) bm = bn = 128;
+    if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    if (bm == 64) return fast ? dispatch_views<64, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
+    if (bn == 64) return fast ? dispatch_views<128, 64, true>(st, p) : dispatch_views<128, 128, false>(st, p);
+    return fast ? dispatch_views<128, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
+}
+
+long gemm_grid_blocks(long M, long N) {   // upper bound over the tile shapes launch_gemm may pick
+    return ((M + 63) / 64) * ((N + 63) / 64);
+}
+
+int gemm_pick_split(long M, long N, long Kc) {
+    int bm, bn;
+    gemm_tile_shape(M, N, bm, bn);
+    const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const long ktiles = (Kc + BK - 1) / BK;
+    int split = 1;
+    if (tiles < 256 && ktiles >= 8) {
+        split = (int)((512 + tiles - 1) / tiles);
+        if (split > 16) split = 16;
+        if (split > ktiles / 4) split = (int)(ktiles / 4);
+    }
+    return split < 1 ? 1 : split;
+}
+
+size_t gemm_scratch_bytes(long M, long N, long Kc) {
+    const int split = gemm_pick_split(M, N, Kc);
+    return split > 1 ? sizeof(float) * (size_t)M * (size_t)N * split : 0;
+}
+
+nmfx_status gemm_auto(hipStream_t st, GemmParams p, void *scratch, size_t scratch_bytes) {
+    const long ktiles = (p.Kc + BK - 1) / BK;
+    int split = 1;
+    if (p.epi == EPI_STORE && scratch) {
+        split = gemm_pick_split(p.M, p.N, p.Kc);
+        while (split > 1 && sizeof(float) * (size_t)p.M * p.N * split > scratch_bytes) --split;
+    }
+    if (split <= 1) {
+        p.splitk = 1;
+        return launch_gemm(st, p);
+    }
+    long per = ((ktiles + split - 1) / split) * BK;
+    split = (int)((p.Kc + per - 1) / per);
+    float *Cout = p.C;
+    const long ldc_out = p.ldc;
+    const int acc_out = p.accumulate;
+    p.splitk = split;
+    p.kc_per_split = per;
+    p.C = static_cast<float *>(scratch);
+    p.ldc = p.M;
+    p.slab_stride = p.M * p.N;
+    p.accumulate = 0;
+    nmfx_status s = launch_gemm(st, p);
+    if (s != NMFX_OK) return s;
+    if (ldc_out == p.M) return reduce_slabs(st, p.C, split, p.slab_stride, p.M * p.N, Cout, acc_out);
+    for (long j = 0; j < p.N; ++j) {  // strided destination (rare): column by column
+        s = reduce_slabs(st, p.C + j * p.M, split, p.slab_stride, p.M, Cout + j * ldc_out, acc_out);
+        if (s != NMFX_OK) return s;
+    }
+    return NMFX_OK;
+}
+
+}  // namespace nmfx

@@ -1,0 +1,120 @@
+// Internal declarations shared by the HIP translation units of libnmfx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "nmfx.h"
+
+#define NMFX_EPS_F 2.220446049250313e-16f /* MATLAB eps = 2^-52, representable in fp32 */
+
+namespace nmfx {
+
+void set_error(const char *fmt, ...);
+#define NMFX_HIP(call)                                                                    \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            nmfx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NMFX_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+// ---- operand views of the general MFMA GEMM (gemm.hip) ------------------------------------
+// An operand element is addressed by (r, kc): r = its non-contracted index (row of op(A) /
+// column of op(B)), kc = the contraction index.  RC = memory-contiguous along r, KC = along kc.
+enum ViewMode {
+    VIEW_RC = 0,         // p[r + ld*kc]
+    VIEW_KC = 1,         // p[kc + ld*r]
+    VIEW_HSTACK_KC = 2,  // kc=(t,k): H[k + K*(r - t)],  r>=t      : B of  V_hat = W_flat * H_stack   (RFD.m:36-38)
+    VIEW_HSTACK_RC = 3,  // r=(t,k):  H[k + K*(kc - t)], kc>=t     : B of  N_all = X * H_stack'       (cnmf.m:191)
+    VIEW_WSTACK_KC = 4,  // kc=(t,i): W[i + m*r + m*K*t]           : A of  G = sum_t W_t' * lshift(X) (cnmf.m:225)
+    VIEW_XSHIFT_KC = 5   // kc=(t,i): X[i + m*(r + t)], r+t<lim    : B of the same product            (cnmf.m:219)
+};
+
+struct OpView {
+    const float *p;   // primary input
+    const float *p2;  // second input of the prologue (same addressing) or nullptr
+    long ld;          // leading dimension (elements)
+    int mode;         // ViewMode
+    int blk;          // length of the inner index of a stacked (t, inner) index
+    long tstride;     // VIEW_WSTACK_KC: m*K
+    int lim;          // VIEW_XSHIFT_KC: n
+    int func;         // nmfx_prologue (+ PRO_DIFF)
+};
+
+enum EpiMode {
+    EPI_STORE = 0,       // C = acc  (or C += acc)
+    EPI_COST = 1,        // per-block fp64 partial of the divergence between Vref and acc (+ optional store of acc)
+};
+
+struct GemmParams {
+    OpView A, B;
+    long M, N, Kc;
+    float *C;
+    long ldc;
+    int accumulate;      // C += acc
+    int store_c;         // EPI_COST: also store acc to C
+    int epi;             // EpiMode
+    int cost_div;        // nmfx_divergence for EPI_COST
+    const float *Vref;   // EPI_COST: reference matrix (M x N, ld = ldv)
+    long ldv;
+    double *cost_partials;  // EPI_COST: one fp64 partial per block [gridDim.x*gridDim.y]
+    int splitk;          // >1: partial sums written to slabs C + z*slab_stride, reduced by reduce_slabs
+    long slab_stride;
+    long kc_per_split;   // multiple of BK
+};
+
+nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out = nullptr);
+// picks split-K, runs the GEMM and the deterministic slab reduction; scratch >= gemm_scratch_bytes(M,N,Kc)
+nmfx_status gemm_auto(hipStream_t st, GemmParams p, void *scratch, size_t scratch_bytes);
+int gemm_pick_split(long M, long N, long Kc);
+long gemm_grid_blocks(long M, long N);   // upper bound of the (x,y) blocks (== cost partials) of an EPI_COST launch
+size_t gemm_scratch_bytes(long M, long N, long Kc);
+
+// ---- small kernels (aux.hip) ----------------------------------------------------------------
+nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out,
+                         int accumulate);
+// column reductions in fp64: out[c] = sum_i f(X[i + ld*c]); mode 0 sum, 1 sum of squares, 2 sum of |x|
+nmfx_status col_reduce(hipStream_t st, const float *X, long rows, long ld, int ncols, int mode, double *out);
+// row reductions: out[k] = sum_j f(X[k + ld*j]); scratch >= row_reduce_scratch_bytes(rows)
+nmfx_status row_reduce(hipStream_t st, const float *X, int rows, long ld, long ncols, int mode, double *out, void *scratch);
+size_t row_reduce_scratch_bytes(int rows);
+// W update of one W step for all (k,t) columns: nmf.m:168 / cnmf.m:193 with the diag terms as column sums
+struct WUpdateParams {
+    float *W;            // m x (K*T)
+    const float *N;      // m x (K*T) numerator GEMM result
+    const float *P;      // m x (K*T) denominator GEMM result, or nullptr when Pvec is used
+    const double *Pvec;  // [K*T] broadcast denominator (KL: rowsum of (shifted) H), or nullptr
+    const float *lamW;   // [K] device or nullptr
+    const uint8_t *fixW; // [K] device or nullptr
+    long m;
+    int K, T;
+    double *sumsq;       // out [K*T]: sum of squares of the updated (un-normalised) columns
+    float inv_exp;       // outer exponent 1/alpha (1 = none)
+};
+nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
+nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
+                        double *f_out);
+nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
+nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
+nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
+                     const float *lamH, const uint8_t *fixH, float inv_exp);
+nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
+                        const double *l1H, int K, const float *lamH, double *out);
+nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
+nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
+nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
+nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out);    // out (cols x rows)
+nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec);
+nmfx_status sum_over_t(hipStream_t st, const double *colsum, int K, int T, double *out);
+nmfx_status d2f(hipStream_t st, const double *in, float *out, int count);
+nmfx_status f2d(hipStream_t st, const float *in, double *out, int count);
+// in: DEVICE staging buffer of `dtype`; out = (float)(in / divide_by)
+nmfx_status cvt_to_f32(hipStream_t st, const void *in, int dtype, float *out, long count, double divide_by);
+nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count);
+
+// ---- Hoyer projection (projfunc.hip): vectors are the COLUMNS of X (len x count), in place ----
+nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev);
+
+}  // namespace nmfx

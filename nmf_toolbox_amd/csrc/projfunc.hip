@@ -1,0 +1,132 @@
+// Hoyer's L1/L2 projection (projfunc.m:13-65) for `count` vectors stored as the columns of X
+// (len x count, column-major), in place.  One 1024-thread workgroup per vector; the vector lives in
+// registers as fp64 for the whole iteration (len <= 1024*EPT), every reduction (sum, w'w, w'v, v'v,
+// |Z|, all(v>=0)) is a wave-shuffle + LDS tree in fp64 so the discrete branches (v<=0 sets,
+// nmfsc.m:164 objective test downstream) follow the float64 reference.  Bandwidth-class: the only
+// HBM traffic is one read and one write of the vector.
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+constexpr int PF_THREADS = 1024;
+constexpr int PF_WAVES = PF_THREADS / 64;
+constexpr int PF_MAX_ITERS = 100000;  // safety cap: the reference loops forever on NaN input
+
+struct Red4 { double a, b, c, d; };
+
+__device__ __forceinline__ Red4 block_red4(Red4 v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v.a += __shfl_xor(v.a, o);
+        v.b += __shfl_xor(v.b, o);
+        v.c += __shfl_xor(v.c, o);
+        v.d += __shfl_xor(v.d, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[wave * 4 + 0] = v.a; red[wave * 4 + 1] = v.b; red[wave * 4 + 2] = v.c; red[wave * 4 + 3] = v.d; }
+    __syncthreads();
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < PF_WAVES; ++w) { r.a += red[w * 4 + 0]; r.b += red[w * 4 + 1]; r.c += red[w * 4 + 2]; r.d += red[w * 4 + 3]; }
+    return r;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len, double k1, double k2, int nn, int *usediters) {
+    __shared__ double red[PF_WAVES * 4];
+    float *x = X + len * blockIdx.x;
+    const int tid = threadIdx.x;
+    const double N = (double)len;
+    double v[EPT];
+    unsigned long long zmask = 0ull, negmask = 0ull;
+
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const long i = tid + (long)e * PF_THREADS;
+        double s = 0.0;
+        if (i < len) {
+            s = (double)x[i];
+            if (!nn) { if (s < 0) negmask |= 1ull << e; s = fabs(s); }   // projfunc.m:16-19
+        }
+        v[e] = s;
+        r.a += s;
+    }
+    r = block_red4(r, red);
+    const double shift0 = (k1 - r.a) / N;                                  // projfunc.m:22
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) v[e] += shift0;
+
+    double nz = 0.0;
+    int j = 0;
+    for (;;) {
+        const double mid = k1 / (N - nz);                                  // projfunc.m:31-32
+        r.a = r.b = r.c = r.d = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long i = tid + (long)e * PF_THREADS;
+            if (i < len) {
+                const double w = v[e] - (((zmask >> e) & 1ull) ? 0.0 : mid); // projfunc.m:33
+                r.a += w * w;                                              // projfunc.m:34
+                r.b += w * v[e];                                           // projfunc.m:35
+                r.c += v[e] * v[e];                                        // projfunc.m:36
+            }
+        }
+        r = block_red4(r, red);
+        const double a = r.a, b = 2.0 * r.b, c = r.c - k2;
+        const double disc = b * b - 4.0 * a * c;
+        const double alphap = (-b + (disc > 0.0 ? sqrt(disc) : 0.0)) / (2.0 * a);   // projfunc.m:37 real(sqrt(.))
+        r.a = r.b = r.c = r.d = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long i = tid + (long)e * PF_THREADS;
+            if (i < len) {
+                const double w = v[e] - (((zmask >> e) & 1ull) ? 0.0 : mid);
+                v[e] = alphap * w + v[e];                                  // projfunc.m:38
+                if (!(v[e] >= 0.0)) r.a += 1.0;                            // projfunc.m:40 all(v>=0)
+            }
+        }
+        r = block_red4(r, red);
+        if (r.a == 0.0 || j >= PF_MAX_ITERS) break;                        // projfunc.m:40-44
+        ++j;                                                               // projfunc.m:46
+        zmask = 0ull;
+        r.a = r.b = r.c = r.d = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long i = tid + (long)e * PF_THREADS;
+            if (i < len) {
+                if (v[e] <= 0.0) { zmask |= 1ull << e; v[e] = 0.0; r.b += 1.0; }   // projfunc.m:49-50
+                r.a += v[e];                                                       // projfunc.m:51
+            }
+        }
+        r = block_red4(r, red);
+        nz = r.b;
+        const double shift = (k1 - r.a) / (N - nz);                        // projfunc.m:52
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (!((zmask >> e) & 1ull)) v[e] += shift;                     // projfunc.m:52-53
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const long i = tid + (long)e * PF_THREADS;
+        if (i < len) x[i] = (float)(((negmask >> e) & 1ull) ? -v[e] : v[e]);       // projfunc.m:58-60
+    }
+    if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
+}
+
+nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
+    if (count <= 0 || len <= 0) return NMFX_OK;
+    dim3 g(count), b(PF_THREADS);
+    if (len <= 4L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<4>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
+    else if (len <= 16L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<16>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
+    else if (len <= 64L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<64>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
+    else {
+        set_error("projfunc: vector length %ld exceeds the register-resident limit %d", len, 64 * PF_THREADS);
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+}  // namespace nmfx

@@ -1,0 +1,141 @@
+"""Device-resident engine: the phase API of include/nmfx.h on buffers that already live in HBM.
+
+PyTorch is plumbing here -- it owns the device allocations, the HIP stream and (for N > 1)
+`torch.distributed` over RCCL; every numeric step is a libnmfx kernel.  Column-major (MATLAB) buffers
+are carried as torch tensors of the *reversed* shape, i.e. V (m x n, column-major) is a contiguous
+torch tensor of shape (n, m).
+
+Multi-GPU: V and H are column-sharded, W is replicated; per iteration ONE all-reduce
+of the packed W-step partials [N | P] (KL: [N | rowsum(H)]).  Everything after the all-reduce is
+computed redundantly and identically on every rank, so W stays bit-identical across ranks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+DIV_CODES = {"euclidean": _lib.DIV_EUCLIDEAN, "kl": _lib.DIV_KL, "kl_divergence": _lib.DIV_KL, "is": _lib.DIV_IS,
+             "is_divergence": _lib.DIV_IS, "frobenius": _lib.DIV_EUCLIDEAN_NOCOST}
+
+
+def colmajor_to_torch(a, device):
+    """NumPy array (MATLAB shape) -> fp32 torch tensor holding its column-major image (reversed shape)."""
+    import torch
+    a = np.asarray(a)
+    t = torch.from_numpy(np.ascontiguousarray(a.transpose(), dtype=np.float32))
+    return t.to(device)
+
+
+def torch_to_colmajor(t):
+    """inverse of colmajor_to_torch -> float64 NumPy array of MATLAB shape"""
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float64).transpose())
+
+
+def shard_columns(n, world, rank):
+    """contiguous column block of rank `rank` (first n % world ranks get one extra column)"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Engine:
+    """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
+
+    def __init__(self, V, W, H, divergence="euclidean", T=1, algorithm="nmf", lamW=None, lamH=None, fixW=None, fixH=None,
+                 group=None, use_dist=None):
+        import torch
+        self.torch = torch
+        if not (V.is_cuda and W.is_cuda and H.is_cuda):
+            raise _lib.NmfxError(_lib.NMFX_ERR_NO_DEVICE, "Engine needs CUDA/HIP tensors: there is no CPU fallback")
+        self.lib = _lib.load()
+        self.V, self.W, self.H = V.contiguous(), W.contiguous(), H.contiguous()
+        self.n, self.m = self.V.shape
+        self.K = self.H.shape[1]
+        self.T = int(T)
+        assert self.H.shape[0] == self.n and self.W.numel() == self.m * self.K * self.T
+        dist = torch.distributed
+        self.dist = dist if (use_dist if use_dist is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)) else None
+        self.group = group
+        self.rank = dist.get_rank(group) if self.dist else 0
+        d = _lib.EngineDesc()
+        d.m, d.n_local, d.K_total, d.T = self.m, self.n, self.K, self.T
+        d.divergence = DIV_CODES[divergence] if isinstance(divergence, str) else int(divergence)
+        d.alpha = d.beta = 1.0
+        self._keep = []
+        for name, val, dt in (("lamW_col", lamW, np.float32), ("lamH_row", lamH, np.float32), ("fixW_col", fixW, np.uint8), ("fixH_row", fixH, np.uint8)):
+            if val is not None:
+                arr = np.ascontiguousarray(np.broadcast_to(np.asarray(val, dtype=dt), (self.K,)))
+                self._keep.append(arr)
+                setattr(d, name, arr.ctypes.data_as(C.c_void_p))
+        d.device = self.V.device.index or 0
+        d.stream = C.c_void_p(torch.cuda.current_stream(self.V.device).cuda_stream)
+        d.algorithm = {"nmf": 0, "cnmf": 1}[algorithm]
+        self.desc = d
+        nbytes, count = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
+        _lib.check(self.lib.nmfx_engine_packed_count(C.byref(d), C.byref(count)))
+        self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.V.device)
+        self.packed = torch.zeros(count.value, dtype=torch.float32, device=self.V.device)
+        self.cost_buf = None
+        h = C.c_void_p()
+        _lib.check(self.lib.nmfx_engine_create(C.byref(d), self.V.data_ptr(), self.W.data_ptr(), self.H.data_ptr(), self.workspace.data_ptr(),
+                                               nbytes.value, self.packed.data_ptr(), C.byref(h)))
+        self.h = h
+        _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
+        self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nmfx_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def init(self):
+        _lib.check(self.lib.nmfx_engine_init(self.h))
+
+    def iterate(self, iters, cost_out=None):
+        """`iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration."""
+        if self.dist is None:
+            ptr = cost_out.data_ptr() if cost_out is not None else None
+            _lib.check(self.lib.nmfx_engine_iterate(self.h, int(iters), ptr))
+            return
+        for it in range(iters):
+            _lib.check(self.lib.nmfx_engine_wstep_partial(self.h))
+            self.dist.all_reduce(self.packed, group=self.group)          # the ONE exchange step of an iteration
+            _lib.check(self.lib.nmfx_engine_wstep_finish(self.h))
+            _lib.check(self.lib.nmfx_engine_hstep(self.h))
+            if cost_out is not None:
+                tmp = cost_out[it:it + 1]
+                self._copy_cost(tmp)
+                self.dist.all_reduce(tmp, group=self.group)
+
+    def _copy_cost(self, dst):
+        _lib.check(self.lib.nmfx_engine_copy_cost(self.h, dst.data_ptr()))
+
+    def cost(self):
+        """global cost of the last iteration as a Python float (synchronises)"""
+        self._copy_cost(self._cost_t)
+        if self.dist is not None:
+            self.dist.all_reduce(self._cost_t, group=self.group)
+        return float(self._cost_t.item())
+
+    # ---- measurement hooks -------------------------------------------------------------------
+    def profile(self, enable=True):
+        _lib.check(self.lib.nmfx_engine_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """after torch.cuda.synchronize(): {tag_name: dict(ms_total, launches, flops, bytes)}"""
+        nt = self.lib.nmfx_engine_profile_ntags()
+        ms = (C.c_double * nt)()
+        cnt = (C.c_int32 * nt)()
+        _lib.check(self.lib.nmfx_engine_profile_read(self.h, ms, cnt))
+        out = {}
+        for t in range(nt):
+            f, b = C.c_double(0), C.c_double(0)
+            _lib.check(self.lib.nmfx_engine_tag_work(self.h, t, C.byref(f), C.byref(b)))
+            out[self.lib.nmfx_engine_profile_tag_name(t).decode()] = dict(ms_total=ms[t], launches=cnt[t], flops=f.value, bytes=b.value)
+        return out

@@ -1,0 +1,103 @@
+"""Kernel-level parity (-m gpu): each HIP kernel against NumPy float64 on the same inputs, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(lib, torch, opA, opB, M, N, Kc, A, B, A2=None, B2=None, proA=0, proB=0, accumulate=0, C0=None):
+    """A, B given in their STORED MATLAB shapes; returns C (M x N) as float64 NumPy."""
+    from nmf_toolbox_amd.engine import colmajor_to_torch, torch_to_colmajor
+    from nmf_toolbox_amd import _lib
+    dev = "cuda:0"
+    tA, tB = colmajor_to_torch(A, dev), colmajor_to_torch(B, dev)
+    tA2 = colmajor_to_torch(A2, dev) if A2 is not None else None
+    tB2 = colmajor_to_torch(B2, dev) if B2 is not None else None
+    tC = colmajor_to_torch(C0 if C0 is not None else np.zeros((M, N)), dev)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.nmfx_gemm_f32(st, opA, opB, M, N, Kc, tA.data_ptr(), tA2.data_ptr() if tA2 is not None else None, A.shape[0], proA,
+                                 tB.data_ptr(), tB2.data_ptr() if tB2 is not None else None, B.shape[0], proB, tC.data_ptr(), M, accumulate,
+                                 ws.data_ptr(), ws.numel()))
+    torch.cuda.synchronize()
+    return torch_to_colmajor(tC)
+
+
+@pytest.mark.parametrize("M,N,Kc", [(128, 128, 64), (256, 384, 96), (64, 256, 4096), (512, 64, 2048), (100, 37, 53), (129, 131, 33), (1, 1, 1), (8192, 128, 512)])
+@pytest.mark.parametrize("opA,opB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_plain(gpu_lib, M, N, Kc, opA, opB):
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(M + 7 * N + 13 * Kc + opA + 2 * opB)
+    Aop = rs.rand(M, Kc) - 0.3
+    Bop = rs.rand(Kc, N) - 0.3
+    A = Aop if opA == 0 else Aop.T.copy()
+    B = Bop if opB == 0 else Bop.T.copy()
+    got = _gemm(lib, torch, opA, opB, M, N, Kc, A, B)
+    ref = Aop.astype(np.float32).astype(np.float64) @ Bop.astype(np.float32).astype(np.float64)
+    assert rel_fro(got, ref) < 2e-6  # fp32 fmaf chains, contraction up to 4096
+
+
+def test_gemm_is_transpose_safe(gpu_lib):
+    """A = I with an ASYMMETRIC B catches a swapped C write (guide rule 16)."""
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    n = 128
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) / 100.0
+    got = _gemm(lib, torch, 0, 0, n, n, n, np.eye(n), B)
+    assert np.array_equal(got.astype(np.float32), B.astype(np.float32))
+
+
+@pytest.mark.parametrize("pro", [1, 2, 3, 4])
+def test_gemm_prologue_and_accumulate(gpu_lib, pro):
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(pro)
+    M, N, Kc = 256, 128, 320
+    X, X2 = rs.rand(M, Kc) + 0.1, rs.rand(M, Kc) + 0.1
+    B = rs.rand(Kc, N)
+    C0 = rs.rand(M, N)
+    f = {1: X / X2, 2: X / X2 ** 2, 3: 1.0 / X2, 4: X2 - X}[pro]
+    got = _gemm(lib, torch, 0, 0, M, N, Kc, X, B, A2=X2, proA=pro, accumulate=1, C0=C0)
+    assert rel_fro(got, f @ B + C0) < 2e-6
+    # same element map on the B operand
+    Y, Y2 = rs.rand(Kc, N) + 0.1, rs.rand(Kc, N) + 0.1
+    A = rs.rand(M, Kc)
+    g = {1: Y / Y2, 2: Y / Y2 ** 2, 3: 1.0 / Y2, 4: Y2 - Y}[pro]
+    got = _gemm(lib, torch, 0, 0, M, N, Kc, A, Y, B2=Y2, proB=pro)
+    assert rel_fro(got, A @ g) < 2e-6
+
+
+@pytest.mark.parametrize("N,count,sparse", [(200, 3, 0.6), (1024, 8, 0.5), (4096, 4, 0.8), (5000, 2, 0.3), (32768, 2, 0.5), (40000, 1, 0.5)])
+def test_projfunc(gpu_lib, N, count, sparse):
+    from oracle import nmf_oracle as O
+    import ctypes as C
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(N + count)
+    S = np.abs(rs.randn(count, N))
+    k1 = np.sqrt(N) - (np.sqrt(N) - 1) * sparse
+    out = np.zeros_like(S)
+    its = np.zeros(count, dtype=np.int32)
+    _lib.check(lib.nmfx_projfunc(N, count, _lib.F64, S.ctypes.data_as(C.c_void_p), k1, 1.0, 1, out.ctypes.data_as(C.c_void_p), its.ctypes.data_as(C.c_void_p), 0))
+    for c in range(count):
+        v, it = O.projfunc(S[c].astype(np.float32).astype(np.float64), k1, 1.0, True)
+        assert it == its[c]
+        assert rel_fro(out[c], v) < 1e-6
+        assert abs(out[c].sum() - k1) < 1e-4 * k1 and abs((out[c] ** 2).sum() - 1.0) < 1e-5 and out[c].min() >= 0
+        assert np.array_equal(out[c] == 0, v == 0)   # identical zero set (discrete branch)
+
+
+def test_projfunc_signed(gpu_lib):
+    from oracle import nmf_oracle as O
+    v, it = gpu_lib.projfunc(np.random.RandomState(5).randn(300), 6.0, 1.0, False)
+    s = np.random.RandomState(5).randn(300).astype(np.float32).astype(np.float64)
+    v0, it0 = O.projfunc(s, 6.0, 1.0, False)
+    assert it == it0 and rel_fro(v, v0) < 1e-6

@@ -1,0 +1,122 @@
+"""Parity proper (-m gpu): the HIP path behind the reference call surface vs the float64 oracle on the same
+seeded inputs.  Tolerance is the north-star contract: <= 1e-5 relative Frobenius on W, H and W*H; cost rel <= 1e-6
+(1e-5 where noted); identical iteration counts / line-search try counts."""
+import numpy as np
+import pytest
+
+from conftest import rel_fro, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _check(got, ref, tol=TOL, cost_tol=1e-6):
+    (W, H, c), (W0, H0, c0) = got, ref
+    cat = lambda x, ax: np.concatenate(x, axis=ax) if isinstance(x, list) else x
+    assert type(W) is type(W0) and type(H) is type(H0)
+    W, W0, H, H0 = cat(W, 1), cat(W0, 1), cat(H, 0), cat(H0, 0)
+    assert W.shape == W0.shape and H.shape == H0.shape
+    assert len(c) == len(c0), (len(c), len(c0))
+    assert rel_fro(W, W0) <= tol, rel_fro(W, W0)
+    assert rel_fro(H, H0) <= tol, rel_fro(H, H0)
+    if np.linalg.norm(c0) > 0:
+        assert rel_fro(c, c0) <= cost_tol, rel_fro(c, c0)
+    else:
+        assert np.all(c == 0)
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl_divergence", "is"])
+@pytest.mark.parametrize("m,n,K,iters", [(512, 1024, 16, 50), (192, 200, 7, 30), (128, 256, 32, 20)])
+def test_nmf_matches_oracle(gpu_lib, div, m, n, K, iters):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-12)
+    _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg), cost_tol=1e-6 if div != "is" else 1e-5)
+
+
+def test_nmf_stop_rule_and_defaults(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(96, 160, 8, planted=True)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=400, tolerance=2e-2)
+    got, ref = gpu_lib.nmf(V, 8, cfg), O.nmf(V, 8, cfg)
+    assert len(ref[2]) < 400            # the stop rule fired in the oracle ...
+    assert abs(len(got[2]) - len(ref[2])) <= 1   # ... and at the same place (+-1: fp32 cost differences at the threshold)
+    W, H, cost = gpu_lib.nmf(V, 8, dict(maxiter=0, tolerance=-5, seed=3))   # <=0 -> defaults 100 / 1e-3 (nmf.m:404-411)
+    assert len(cost) <= 100 and W.shape == (96, 8) and H.shape == (8, 160)
+    assert np.allclose(np.sqrt((W ** 2).sum(0)), 1.0, atol=1e-5)            # unit-L2 columns (nmf.m:169)
+    assert np.all(np.diff(cost) <= 1e-6 * cost[0])                          # monotone non-increasing
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+def test_nmf_multi_source_sparsity_fixed(gpu_lib, div):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(160, 224, 12)
+    Ks = [3, 4, 5]
+    cfg = dict(divergence=div, W_init=[W0[:, :3], W0[:, 3:7], W0[:, 7:]], H_init=[H0[:3], H0[3:7], H0[7:]], W_sparsity=[0.1, 0.0, 0.05],
+               H_sparsity=[0.0, 0.2, 0.0], W_fixed=[False, True, False], H_fixed=[False, False, True], maxiter=25, tolerance=1e-12)
+    got, ref = gpu_lib.nmf(V, Ks, cfg), O.nmf(V, Ks, cfg)
+    _check(got, ref)
+    assert rel_fro(got[0][1], W0[:, 3:7] / np.sqrt((W0[:, 3:7] ** 2).sum(0))) < 1e-6   # fixed source: only the init normalisation
+    assert rel_fro(got[1][2], H0[7:]) < 1e-7
+
+
+def test_nmf_errors(gpu_lib):
+    V, W0, H0 = synth(32, 40, 4)
+    with pytest.raises(ValueError, match="No update equations defined"):
+        gpu_lib.nmf(V, 4, dict(divergence="bogus"))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 1 initial encoding matrices."):
+        gpu_lib.nmf(V, [2, 2], dict(H_init=[H0]))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 3 sparsity levels."):
+        gpu_lib.nmf(V, [2, 2], dict(W_sparsity=[0.1, 0.2, 0.3]))
+    with pytest.raises(ValueError, match="alpha = 0 and beta = 0"):
+        gpu_lib.nmf(V, 4, dict(divergence="ab", alpha=0, beta=0))
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl", "is", "frobenius"])
+@pytest.mark.parametrize("m,n,K,T,iters", [(256, 1024, 16, 8, 30), (96, 130, 5, 3, 20), (128, 256, 8, 1, 15)])
+def test_cnmf_matches_oracle(gpu_lib, div, m, n, K, T, iters):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0 if T > 1 else W0[:, :, 0], H_init=H0, maxiter=iters, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    got, ref = gpu_lib.cnmf(V, K, T, cfg), O.cnmf(V, K, T, cfg)
+    _check(got, ref, cost_tol=1e-5 if div == "is" else 1e-6)
+    W = got[0].reshape(m, K, -1)
+    assert np.allclose(np.sqrt((W ** 2).sum((0, 2))), T, rtol=1e-5)   # slab Frobenius norm == T (cnmf.m:196-199)
+
+
+def test_cnmf_multi_source(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(128, 192, 8, T=4)
+    cfg = dict(divergence="kl", W_init=[W0[:, :3], W0[:, 3:]], H_init=[H0[:3], H0[3:]], W_fixed=[True, False], H_sparsity=[0.1, 0.0], maxiter=15, tolerance=1e-12)
+    _check(gpu_lib.cnmf(V, [3, 5], 4, cfg), O.cnmf(V, [3, 5], 4, cfg))
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
+def test_nmfsc_matches_oracle(gpu_lib, sW, sH):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 2048, 16)
+    V = 3.0 * V     # exercises the V / max(V) rescale (nmfsc.m:62)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=30, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1 = {}, {}
+    got = gpu_lib.nmfsc(V, 16, cfg, info=i1)
+    ref = O.nmfsc(V, 16, cfg, info=i0)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]      # identical line-search branches
+    _check(got, ref)
+    assert abs(i1["stepsizeH"] - i0["stepsizeH"]) <= 1e-12 * i0["stepsizeH"]
+
+
+def test_nmfsc_negative_data(gpu_lib):
+    with pytest.raises(ValueError, match="Negative values in data!"):
+        gpu_lib.nmfsc(-np.ones((4, 4)), 2)
+
+
+def test_reconstruct(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(200, 300, 6, T=5)
+    assert rel_fro(gpu_lib.ReconstructFromDecomposition(W0, H0), O.reconstruct_from_decomposition(W0, H0)) < 1e-6
+    assert rel_fro(gpu_lib.ReconstructFromDecomposition(W0[:, :, 0], H0), W0[:, :, 0] @ H0) < 1e-6
+    assert rel_fro(gpu_lib.ReconstructFromDecomposition([W0[:, :2], W0[:, 2:]], [H0[:2], H0[2:]]), O.reconstruct_from_decomposition(W0, H0)) < 1e-6
