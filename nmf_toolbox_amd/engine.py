@@ -41,6 +41,25 @@ def shard_columns(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
+    """The N > 1 iteration loop, independent of what computes the phases.
+
+    `backend` provides wstep_partial(), wstep_finish(), hstep(), the tensor `packed` (this rank's W-step sums, in place
+    all-reducible) and _copy_cost(dst) (this rank's cost partial into a 1-element fp64 tensor).  One all-reduce of
+    `packed` per iteration is the only data-path collective; the 8-byte cost all-reduce exists because nmf.m returns
+    the cost vector and evaluates its stop rule on it (nmf.m:206-224).
+    """
+    for it in range(iters):
+        backend.wstep_partial()
+        dist.all_reduce(backend.packed, group=group)          # the ONE exchange step of an iteration
+        backend.wstep_finish()
+        backend.hstep()
+        if cost_out is not None:
+            tmp = cost_out[it:it + 1]
+            backend._copy_cost(tmp)
+            dist.all_reduce(tmp, group=group)
+
+
 class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
@@ -97,21 +116,23 @@ class Engine:
     def init(self):
         _lib.check(self.lib.nmfx_engine_init(self.h))
 
+    # ---- the four phases (HIP kernels on this rank's shard) -------------------------------------
+    def wstep_partial(self):
+        _lib.check(self.lib.nmfx_engine_wstep_partial(self.h))
+
+    def wstep_finish(self):
+        _lib.check(self.lib.nmfx_engine_wstep_finish(self.h))
+
+    def hstep(self):
+        _lib.check(self.lib.nmfx_engine_hstep(self.h))
+
     def iterate(self, iters, cost_out=None):
         """`iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration."""
         if self.dist is None:
             ptr = cost_out.data_ptr() if cost_out is not None else None
             _lib.check(self.lib.nmfx_engine_iterate(self.h, int(iters), ptr))
             return
-        for it in range(iters):
-            _lib.check(self.lib.nmfx_engine_wstep_partial(self.h))
-            self.dist.all_reduce(self.packed, group=self.group)          # the ONE exchange step of an iteration
-            _lib.check(self.lib.nmfx_engine_wstep_finish(self.h))
-            _lib.check(self.lib.nmfx_engine_hstep(self.h))
-            if cost_out is not None:
-                tmp = cost_out[it:it + 1]
-                self._copy_cost(tmp)
-                self.dist.all_reduce(tmp, group=self.group)
+        run_sharded_iterations(self, iters, self.dist, self.group, cost_out)
 
     def _copy_cost(self, dst):
         _lib.check(self.lib.nmfx_engine_copy_cost(self.h, dst.data_ptr()))
