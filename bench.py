@@ -114,7 +114,7 @@ def main():
     W = torch.rand((T * K, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)      # identical on every rank
     g.manual_seed(2 + rank)
     H = torch.rand((nl, K), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
-    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg)
+    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path)
     eng.init()
     costs = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
 
@@ -166,7 +166,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.m %s MU, V=%dx%d K=%d%s fp32, V column-sharded over %d GPU(s)" % (alg, div, m, n, K, (" T=%d" % T) if T > 1 else "", world),
-                       "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True},
+                       "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
+                       "path": "fused (V_hat never materialised)" if eng.cost_lags else "generic (materialised V_hat)"},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,

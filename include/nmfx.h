@@ -79,6 +79,7 @@ typedef struct {
     int32_t device;           /* HIP device ordinal */
     /* nmfsc only (nmfsc.m:87-110): Hoyer sparseness targets in [0,1]; <= 0 selects the MU branch */
     double sc_W_sparsity, sc_H_sparsity;
+    int32_t path;             /* NMFX extension: 0 = auto, 1 = generic kernels only, 2 = require the fused kernels */
 } nmfx_problem;
 
 typedef struct {
@@ -149,8 +150,13 @@ nmfx_status nmfx_engine_init(nmfx_engine *e);
 nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e);
 /* W step, replicated part after the all-reduce: ratio update + normalisation (nmf.m:168-169, cnmf.m:193-199) */
 nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e);
-/* H step (column-local, nmf.m:176-203 / cnmf.m:207-236) + this shard's cost partial of the iteration */
+/* H step (column-local, nmf.m:176-203 / cnmf.m:207-236).  On the generic path this also refreshes V_hat and leaves the
+ * shard's cost of the iteration in the engine; on the fused path V_hat is never formed and the cost of iteration i is a
+ * by-product of the W-step pass of iteration i+1 (same W, H), or of nmfx_engine_cost_pass(). */
 nmfx_status nmfx_engine_hstep(nmfx_engine *e);
+/* make the engine's cost refer to the CURRENT (W, H): no-op when it already does, else one fused S = W*H pass */
+nmfx_status nmfx_engine_cost_pass(nmfx_engine *e);
+int32_t nmfx_engine_is_fused(nmfx_engine *e);
 /* device pointer to the fp64 cost of the last hstep for the local shard: data-fit partial + lambda*L1 terms
  * (the W term is included only when the engine is rank 0, see nmfx_engine_set_rank0); sum over ranks = nmf.m:206-218 */
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost);

@@ -20,7 +20,7 @@ EXPORTS = [
     "nmfx_nmf", "nmfx_cnmf", "nmfx_nmfsc", "nmfx_reconstruct", "nmfx_projfunc", "nmfx_last_error",
     "nmfx_device_count", "nmfx_version", "nmfx_engine_workspace_bytes", "nmfx_engine_packed_count",
     "nmfx_engine_create", "nmfx_engine_destroy", "nmfx_engine_init", "nmfx_engine_wstep_partial",
-    "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
+    "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32",
 ]
@@ -40,7 +40,7 @@ class Problem(C.Structure):
         ("num_sources", C.c_int32), ("K_s", C.c_void_p), ("W_sparsity", C.c_void_p), ("H_sparsity", C.c_void_p),
         ("W_fixed", C.c_void_p), ("H_fixed", C.c_void_p),
         ("maxiter", C.c_int32), ("tolerance", C.c_double), ("device", C.c_int32),
-        ("sc_W_sparsity", C.c_double), ("sc_H_sparsity", C.c_double),
+        ("sc_W_sparsity", C.c_double), ("sc_H_sparsity", C.c_double), ("path", C.c_int32),
     ]
 
 
@@ -90,7 +90,8 @@ def load():
     lib.nmfx_engine_workspace_bytes.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_packed_count.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_create.argtypes = [C.POINTER(EngineDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
-    for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep"):
+    lib.nmfx_engine_is_fused.argtypes = [C.c_void_p]
+    for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.nmfx_engine_copy_cost.argtypes = [C.c_void_p, C.c_void_p]

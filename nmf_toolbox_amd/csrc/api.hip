@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,6 +80,10 @@ struct nmfx_engine {
     double *sumsq, *f_out, *rowsum, *colsum, *Pvec, *Gpvec, *cost_partials, *cost, *l1W, *l1H;
     void *rr_scratch;
     int n_cost_partials, n_cost_used;
+    // fused path (fused.hip): V_hat is never materialised
+    bool fused, cost_valid;
+    int nsplit_w, isplit_h;
+    float *WT, *slabs, *Pbuf, *GW;
     // profiling
     bool prof;
     std::vector<ProfEvent> events;
@@ -86,9 +91,12 @@ struct nmfx_engine {
     size_t pool_used;
 };
 
-enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6, TAG_COUNT = 7 };
+enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6,
+               TAG_FUSED_W = 7, TAG_FUSED_H = 8, TAG_FUSED_COST = 9, TAG_GRAM = 10, TAG_COUNT = 11 };
 static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'", "gemm:P=B*H'", "gemm:Gn=W'*A", "gemm:Gp=W'*B",
-                                                 "gemm:V_hat=W*H+cost", "small kernels"};
+                                                 "gemm:V_hat=W*H+cost", "small kernels", "fused:W-step (S=W*H -> R -> R*H')",
+                                                 "fused:H-step (S=W*H -> R -> W'*R + update)", "fused:cost pass (S=W*H -> D(V||S))",
+                                                 "gemm:Gram/K x K products"};
 
 namespace {
 
@@ -154,9 +162,34 @@ Layout layout(nmfx_engine *e, void *ws) {
     e->cost_partials = c.take<double>(e->n_cost_partials);
     e->rr_scratch = c.take<char>(row_reduce_scratch_bytes(e->K));
     Layout L;
+    if (e->fused) {
+        // V_hat, Gn/Gp of the generic path are not needed: rewind and carve the fused buffers instead
+        Carver f(ws);
+        e->Vhat = nullptr;
+        e->WT = f.take<float>(mKT);
+        e->slabs = f.take<float>(std::max((size_t)e->nsplit_w * mKT, (size_t)e->isplit_h * Kn));
+        e->Gn = f.take<float>(Kn);
+        const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
+        e->Gp = euc ? f.take<float>(Kn) : nullptr;
+        e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
+        e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
+        size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m);
+        e->gemm_scratch_bytes = euc ? std::max(g1, g2) : 0;
+        e->gemm_scratch = e->gemm_scratch_bytes ? f.take<float>(e->gemm_scratch_bytes / sizeof(float)) : nullptr;
+        e->lamW = f.take<float>(e->K); e->lamH = f.take<float>(e->K);
+        e->fixW = f.take<uint8_t>(e->K); e->fixH = f.take<uint8_t>(e->K);
+        e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
+        e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
+        e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
+        e->n_cost_partials = (int)((e->m / 128) * e->nsplit_w);
+        e->cost_partials = f.take<double>(e->n_cost_partials);
+        e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
+        L.total = f.off;
+        L.packed_count = euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT;
+        return L;
+    }
     L.total = c.off;
     L.packed_count = div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT;
-    (void)mKT;
     return L;
 }
 
@@ -190,6 +223,24 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     if (e->algo == 0 && e->T != 1) {
         set_error("nmfx_engine: algorithm nmf requires T == 1");
         return NMFX_ERR_INVALID;
+    }
+    // fused path eligibility: nmf rules, KL or euclidean, K in {64,128,256}, tileable shard
+    const bool eligible = e->algo == 0 && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
+                          e->m % 128 == 0 && e->n % 128 == 0;
+    if (d->path == 2 && !eligible) {
+        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K in {64,128,256}, m %% 128 == 0, n %% 128 == 0)");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    e->fused = eligible && d->path != 1;
+    e->nsplit_w = e->isplit_h = 1;
+    if (e->fused) {
+        auto pick = [](long blocks, long extent) {   // grid.y so that blocks*split >= 256 while extent/split stays a multiple of 64
+            int s = 1;
+            while (blocks * s < 256 && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
+            return s;
+        };
+        e->nsplit_w = pick(e->m / 128, e->n);
+        e->isplit_h = pick(e->n / 128, e->m);
     }
     return NMFX_OK;
 }
@@ -266,6 +317,54 @@ nmfx_status wt_times_x(nmfx_engine *e, OpView x, float *out, int tag) {
 }
 
 #define TRY(x) do { nmfx_status s_ = (x); if (s_ != NMFX_OK) return s_; } while (0)
+
+// C (M x N) = A (M x Kc) * B (Kc x N) with plain views; small K x K products of the euclidean Gram form
+nmfx_status small_gemm(nmfx_engine *e, long M, long N, long Kc, OpView A, OpView B, float *C, long ldc) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.Kc = Kc; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+nmfx_status cost_from_partials(nmfx_engine *e, int nparts) {
+    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    const double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
+                       e->lamH, e->cost);
+}
+
+// fused W-step pass (K2) or cost-only pass over the local shard; cost refers to the CURRENT (W, H)
+nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
+    FusedParams f;
+    memset(&f, 0, sizeof(f));
+    f.X = e->W; f.xs_r = 1; f.xs_k = e->m;
+    f.Y = e->H; f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->K;
+    f.c_per_split = e->n / e->nsplit_w;
+    f.out = e->nsplit_w == 1 ? e->packed : e->slabs;
+    f.slab_stride = e->m * (long)e->K; f.os_r = 1; f.os_k = e->m;
+    f.cost_partials = e->cost_partials;
+    const int func = e->div == NMFX_DIV_KL ? 3 : 1;
+    {
+        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        TRY(launch_fused(e->st, f, e->nsplit_w, true, func, do_g2, 0));
+    }
+    Scope s(e, TAG_SMALL);
+    if (do_g2 && e->nsplit_w > 1) TRY(reduce_slabs(e->st, e->slabs, e->nsplit_w, f.slab_stride, f.slab_stride, e->packed, 0));
+    TRY(cost_from_partials(e, (int)((e->m / 128) * e->nsplit_w)));
+    e->cost_valid = true;
+    return NMFX_OK;
+}
+
+nmfx_status refresh_w_derived(nmfx_engine *e) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
+    TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
+    if (e->div == NMFX_DIV_KL) {
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->colsum));
+        TRY(sum_over_t(e->st, e->colsum, e->K, 1, e->Gpvec));
+    }
+    return NMFX_OK;
+}
 
 }  // namespace
 
@@ -345,6 +444,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 1, e->sumsq));
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo == 1, e->f_out));
         if (e->algo == 1) TRY(scale_rows(e->st, e->H, e->K, e->n, e->f_out));
+        if (e->fused) { e->cost_valid = false; return refresh_w_derived(e); }
     }
     return recon(e, false);
 }
@@ -352,8 +452,22 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
 // local sums of the W step: packed = [N | P]  or  [N | Pvec]        nmf.m:149-164 / cnmf.m:187-192
 nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
-    if (e->all_fixW) return NMFX_OK;
     const size_t mKT = (size_t)e->m * e->KT;
+    if (e->fused) {
+        // one pass over V: N = (V./(W*H)) * H' (KL) or V*H' (euclidean), and the cost of the current (W, H) as a by-product
+        TRY(fused_wpass(e, true));
+        if (e->div == NMFX_DIV_KL) {
+            Scope s(e, TAG_SMALL);
+            TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+            TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));
+        } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
+            Scope s(e, TAG_GRAM);
+            TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
+                           OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE}, e->packed + mKT, e->K));
+        }
+        return NMFX_OK;
+    }
+    if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
     TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
@@ -372,6 +486,28 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
 // replicated part of the W step (after the all-reduce of packed): nmf.m:168-173 / cnmf.m:193-204
 nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) {
+        if (e->all_fixW) return NMFX_OK;
+        const size_t mK = (size_t)e->m * e->K;
+        WUpdateParams p{};
+        p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = 1;
+        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
+        if (e->div == NMFX_DIV_KL) {
+            Scope s(e, TAG_SMALL);
+            TRY(f2d(e->st, e->packed + mK, e->Pvec, e->K));
+            p.Pvec = e->Pvec;
+        } else {
+            Scope s(e, TAG_GRAM);   // P = W * (H*H')
+            TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
+                           OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->Pbuf, e->m));
+            p.P = e->Pbuf;
+        }
+        Scope s(e, TAG_SMALL);
+        TRY(w_update(e->st, p));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, 0, nullptr));
+        e->cost_valid = false;
+        return refresh_w_derived(e);
+    }
     if (!e->all_fixW) {
         Scope s(e, TAG_SMALL);
         const size_t mKT = (size_t)e->m * e->KT;
@@ -392,6 +528,39 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
 // H step + V_hat refresh + local cost partial: nmf.m:176-218 / cnmf.m:207-251
 nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) {
+        if (e->all_fixH) return NMFX_OK;
+        if (e->div == NMFX_DIV_EUCLIDEAN) {   // W'*V_hat = (W'*W)*H   
+            Scope s(e, TAG_GRAM);
+            TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE},
+                           OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->GW, e->K));
+            TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
+                           OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->Gp, e->K));
+        }
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = e->H; f.xs_r = e->K; f.xs_k = 1;
+        f.Y = e->WT; f.D = e->V; f.ldd = e->m; f.R = e->n; f.Cn = e->m; f.K = e->K;
+        f.c_per_split = e->m / e->isplit_h;
+        const int func = e->div == NMFX_DIV_KL ? 2 : 0;
+        const bool kl = e->div == NMFX_DIV_KL;
+        if (e->isplit_h == 1) {
+            f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
+            Scope s(e, TAG_FUSED_H);
+            TRY(launch_fused(e->st, f, 1, false, func, true, 1));
+        } else {
+            f.out = e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
+            {
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+            TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        }
+        e->cost_valid = false;
+        return NMFX_OK;
+    }
     if (!e->all_fixH) {
         OpView a{}, b{};
         num_view(e, a);
@@ -410,13 +579,20 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     TRY(recon(e, !nocost));
     Scope s(e, TAG_SMALL);
-    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
-    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
-    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
-    const double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
-    return finish_cost(e->st, e->cost_partials, nocost ? 0 : e->n_cost_used, scale, useW ? e->l1W : nullptr, e->KT, e->lamW,
-                       useH ? e->l1H : nullptr, e->K, e->lamH, e->cost);
+    e->cost_valid = true;
+    return cost_from_partials(e, nocost ? 0 : e->n_cost_used);
 }
+
+// make e->cost hold the cost of the CURRENT (W, H): free on the generic path (hstep already did it), one S = W*H pass on the
+// fused path unless the last wstep_partial just produced it
+nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->cost_valid) return NMFX_OK;
+    if (e->fused) return fused_wpass(e, false);
+    set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
+    return NMFX_ERR_INVALID;
+}
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : 0; }
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
@@ -427,9 +603,16 @@ nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
     for (int it = 0; it < iters; ++it) {
         TRY(nmfx_engine_wstep_partial(e));
+        // fused path: the W-step pass has just produced the cost of the state it started from, i.e. of iteration it-1
+        if (e->fused && it > 0 && dev_cost_out)
+            NMFX_HIP(hipMemcpyAsync(dev_cost_out + it - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
         TRY(nmfx_engine_wstep_finish(e));
         TRY(nmfx_engine_hstep(e));
-        if (dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+        if (!e->fused && dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    }
+    if (e->fused && iters > 0 && dev_cost_out) {   // cost of the last iteration: one extra S = W*H pass
+        TRY(nmfx_engine_cost_pass(e));
+        NMFX_HIP(hipMemcpyAsync(dev_cost_out + iters - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
     }
     return NMFX_OK;
 }
@@ -467,6 +650,10 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_WDEN: b = 4.0 * (m * n + m * KT + e->K * n); break;
     case TAG_HNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + 2.0 * e->K * n); break;
     case TAG_HDEN: b = 4.0 * (m * n + m * KT + 2.0 * e->K * n); break;
+    // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
+    case TAG_FUSED_W: *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK;
+    case TAG_FUSED_H: *flops = (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
     }
     *flops = f;
@@ -580,7 +767,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     nmfx_engine_desc d{};
     d.m = p->m; d.n_local = p->n; d.K_total = K; d.T = p->T; d.divergence = p->divergence; d.alpha = p->alpha; d.beta = p->beta;
     d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
-    d.device = p->device; d.stream = nullptr; d.algorithm = algorithm;
+    d.device = p->device; d.stream = nullptr; d.algorithm = algorithm; d.path = p->path;
     size_t ws_bytes = 0, packed_count = 0;
     TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
     TRY(nmfx_engine_packed_count(&d, &packed_count));
@@ -597,15 +784,33 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     nmfx_status s = nmfx_engine_init(e);
     int it = 0;
     r->iters_run = 0;
+    auto read_cost = [&](int idx) -> nmfx_status {
+        hipError_t he = hipMemcpy(&r->cost[idx], e->cost, sizeof(double), hipMemcpyDeviceToHost);   // syncs the iteration
+        if (he != hipSuccess) { set_error("cost readback: %s", hipGetErrorString(he)); return NMFX_ERR_HIP; }
+        r->iters_run = idx + 1;
+        return NMFX_OK;
+    };
+    // nmf.m:221-224 / cnmf.m:254-257
+    auto stop = [&](int idx) { return p->tolerance >= 0 && idx > 0 && r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance; };
+    bool stopped = false;
     for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
         if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
+        if (e->fused && it > 0) {
+            // the fused W-step pass of iteration it also yields cost(it-1); W and H are untouched until wstep_finish, so
+            // stopping here returns exactly the state of iteration it-1 (the numerators just computed are discarded)
+            if ((s = read_cost(it - 1)) != NMFX_OK) break;
+            if (stop(it - 1)) { stopped = true; break; }
+        }
         if ((s = nmfx_engine_wstep_finish(e)) != NMFX_OK) break;
         if ((s = nmfx_engine_hstep(e)) != NMFX_OK) break;
-        hipError_t he = hipMemcpy(&r->cost[it], e->cost, sizeof(double), hipMemcpyDeviceToHost);   // syncs the iteration
-        if (he != hipSuccess) { set_error("cost readback: %s", hipGetErrorString(he)); s = NMFX_ERR_HIP; break; }
-        r->iters_run = it + 1;
-        // nmf.m:221-224 / cnmf.m:254-257
-        if (p->tolerance >= 0 && it > 0 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) break;
+        if (!e->fused) {
+            if ((s = read_cost(it)) != NMFX_OK) break;
+            if (stop(it)) { stopped = true; break; }
+        }
+    }
+    if (s == NMFX_OK && e->fused && !stopped) {
+        s = nmfx_engine_cost_pass(e);
+        if (s == NMFX_OK) s = read_cost(p->maxiter - 1);
     }
     r->cost_len = r->iters_run;
     if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKT, stage, STAGE_ELEMS);

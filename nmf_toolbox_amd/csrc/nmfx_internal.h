@@ -72,6 +72,29 @@ int gemm_pick_split(long M, long N, long Kc);
 long gemm_grid_blocks(long M, long N);   // upper bound of the (x,y) blocks (== cost partials) of an EPI_COST launch
 size_t gemm_scratch_bytes(long M, long N, long Kc);
 
+// ---- fused two-stage kernel (fused.hip) -------------------------------------------------------------
+struct FusedParams {
+    const float *X;       // stationary factor: X(r, k) = X[r*xs_r + k*xs_k]   (W step: W; H step: H^T i.e. H with xs_r = K, xs_k = 1)
+    long xs_r, xs_k;
+    const float *Y;       // streamed factor: row c = K contiguous floats at Y + c*K  (W step: columns of H; H step: rows of W = W^T copy)
+    const float *D;       // V (m x n, ld = ldd); W step reads V(r, c) = D[r + ldd*c], H step V(c, r) = D[c + ldd*r]
+    long ldd;
+    long R, Cn;           // stationary rows (multiple of 128), streamed rows (multiple of 64)
+    long c_per_split;     // streamed rows per grid.y slice (multiple of 64)
+    int K;
+    float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
+    long slab_stride, os_r, os_k;
+    double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr
+    float *Hio;           // EPI 1: H updated in place
+    const float *den;     // EPI 1: K x n denominator matrix, or nullptr -> denvec
+    const double *denvec; // EPI 1: [K]
+    const float *lam;     // [K] or nullptr
+    const uint8_t *fix;   // [K] or nullptr
+};
+bool fused_supported(int K);
+// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost;  do_g2=false: cost-only pass
+nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
+
 // ---- small kernels (aux.hip) ----------------------------------------------------------------
 nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out,
                          int accumulate);

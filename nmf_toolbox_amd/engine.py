@@ -48,23 +48,35 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
     all-reducible) and _copy_cost(dst) (this rank's cost partial into a 1-element fp64 tensor).  One all-reduce of
     `packed` per iteration is the only data-path collective; the 8-byte cost all-reduce exists because nmf.m returns
     the cost vector and evaluates its stop rule on it (nmf.m:206-224).
+    On the fused path (backend.cost_lags == True) the cost of iteration i is a by-product of the W-step pass of iteration
+    i+1; the last one needs backend.cost_pass().
     """
+    lag = bool(getattr(backend, "cost_lags", False))
+
+    def emit(idx):
+        tmp = cost_out[idx:idx + 1]
+        backend._copy_cost(tmp)
+        dist.all_reduce(tmp, group=group)
+
     for it in range(iters):
         backend.wstep_partial()
+        if lag and it > 0 and cost_out is not None:
+            emit(it - 1)
         dist.all_reduce(backend.packed, group=group)          # the ONE exchange step of an iteration
         backend.wstep_finish()
         backend.hstep()
-        if cost_out is not None:
-            tmp = cost_out[it:it + 1]
-            backend._copy_cost(tmp)
-            dist.all_reduce(tmp, group=group)
+        if not lag and cost_out is not None:
+            emit(it)
+    if lag and iters > 0 and cost_out is not None:
+        backend.cost_pass()
+        emit(iters - 1)
 
 
 class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
     def __init__(self, V, W, H, divergence="euclidean", T=1, algorithm="nmf", lamW=None, lamH=None, fixW=None, fixH=None,
-                 group=None, use_dist=None):
+                 group=None, use_dist=None, path=0):
         import torch
         self.torch = torch
         if not (V.is_cuda and W.is_cuda and H.is_cuda):
@@ -92,6 +104,7 @@ class Engine:
         d.device = self.V.device.index or 0
         d.stream = C.c_void_p(torch.cuda.current_stream(self.V.device).cuda_stream)
         d.algorithm = {"nmf": 0, "cnmf": 1}[algorithm]
+        d.path = int(path)
         self.desc = d
         nbytes, count = C.c_size_t(0), C.c_size_t(0)
         _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
@@ -105,6 +118,7 @@ class Engine:
         self.h = h
         _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
+        self.cost_lags = bool(self.lib.nmfx_engine_is_fused(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -126,6 +140,9 @@ class Engine:
     def hstep(self):
         _lib.check(self.lib.nmfx_engine_hstep(self.h))
 
+    def cost_pass(self):
+        _lib.check(self.lib.nmfx_engine_cost_pass(self.h))
+
     def iterate(self, iters, cost_out=None):
         """`iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration."""
         if self.dist is None:
@@ -138,7 +155,8 @@ class Engine:
         _lib.check(self.lib.nmfx_engine_copy_cost(self.h, dst.data_ptr()))
 
     def cost(self):
-        """global cost of the last iteration as a Python float (synchronises)"""
+        """global cost of the current (W, H) as a Python float (synchronises)"""
+        self.cost_pass()
         self._copy_cost(self._cost_t)
         if self.dist is not None:
             self.dist.all_reduce(self._cost_t, group=self.group)

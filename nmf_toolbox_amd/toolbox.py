@@ -153,6 +153,7 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     p.maxiter = maxiter
     p.tolerance = -1.0 if cfg.get("nmfx_disable_stop", False) else float(cfg["tolerance"])
     p.device = int(device)
+    p.path = int(cfg.get("nmfx_path", 0))       # extension: 0 auto, 1 generic kernels only, 2 require the fused kernels
     r = _lib.Result()
     r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
     _lib.check(fn(C.byref(p), C.byref(r)))

@@ -120,3 +120,32 @@ def test_reconstruct(gpu_lib):
     assert rel_fro(gpu_lib.ReconstructFromDecomposition(W0, H0), O.reconstruct_from_decomposition(W0, H0)) < 1e-6
     assert rel_fro(gpu_lib.ReconstructFromDecomposition(W0[:, :, 0], H0), W0[:, :, 0] @ H0) < 1e-6
     assert rel_fro(gpu_lib.ReconstructFromDecomposition([W0[:, :2], W0[:, 2:]], [H0[:2], H0[2:]]), O.reconstruct_from_decomposition(W0, H0)) < 1e-6
+
+
+# ---- fused kernels (S = W*H never stored): eligible shapes, both split and un-split epilogues -----------------------
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
+@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10)])
+def test_nmf_fused_matches_oracle_and_generic(gpu_lib, div, m, n, K, iters):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-12)
+    ref = O.nmf(V, K, cfg)
+    fused = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=2))
+    generic = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1))
+    _check(fused, ref)
+    _check(generic, ref)
+    _check(fused, generic)
+
+
+def test_nmf_fused_multi_source_and_stop(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 512, 64, planted=True)
+    Ks = [24, 40]
+    cfg = dict(divergence="kl", W_init=[W0[:, :24], W0[:, 24:]], H_init=[H0[:24], H0[24:]], W_sparsity=[0.05, 0.0], H_sparsity=[0.0, 0.1],
+               W_fixed=[False, True], H_fixed=[False, False], maxiter=40, tolerance=1e-12, nmfx_path=2)
+    _check(gpu_lib.nmf(V, Ks, cfg), O.nmf(V, Ks, cfg))
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=300, tolerance=5e-2, nmfx_path=2)
+    got, ref = gpu_lib.nmf(V, 64, cfg), O.nmf(V, 64, cfg)
+    assert len(ref[2]) < 300 and abs(len(got[2]) - len(ref[2])) <= 1
+    k = min(len(got[2]), len(ref[2]))
+    assert rel_fro(got[2][:k], ref[2][:k]) < 1e-6
