@@ -1,0 +1,103 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/nmfx.h declares; the host-side mirror validates
+arguments exactly like the reference's local ValidateParameters; without a GPU every compute call fails LOUDLY."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth
+
+
+def _lib():
+    from nmf_toolbox_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from nmf_toolbox_amd import build
+        build.build()
+    return _lib
+
+
+def test_header_symbols_are_exported():
+    L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "nmfx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(nmfx_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = L.load()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(set(L.EXPORTS)) == declared          # the Python binding list tracks the header
+    assert lib.nmfx_version() == 100
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of nmfx_problem / nmfx_result / nmfx_engine_desc have the sizes the C compiler gives."""
+    L = _lib()
+    import subprocess
+    import tempfile
+    src = '#include "nmfx.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(nmfx_problem), sizeof(nmfx_result), sizeof(nmfx_engine_desc));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [C.sizeof(L.Problem), C.sizeof(L.Result), C.sizeof(L.EngineDesc)]
+
+
+def test_no_silent_cpu_fallback():
+    L = _lib()
+    import nmf_toolbox_amd as A
+    if A.device_count() > 0:
+        pytest.skip("a GPU is present: the loud-failure path is only observable without one")
+    V, W0, H0 = synth(16, 24, 3)
+    for call in (lambda: A.nmf(V, 3, dict(W_init=W0, H_init=H0)), lambda: A.cnmf(V, 3, 2), lambda: A.nmfsc(V, 3),
+                 lambda: A.ReconstructFromDecomposition(W0, H0), lambda: A.projfunc(np.ones(8), 2.0, 1.0, True)):
+        with pytest.raises(A.NmfxError) as ei:
+            call()
+        assert ei.value.status == L.NMFX_ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
+    from nmf_toolbox_amd.engine import Engine
+    import torch
+    t = torch.zeros(4, 4)
+    with pytest.raises(A.NmfxError):
+        Engine(t, t, t)
+
+
+def test_host_validation_mirrors_reference_errors():
+    import nmf_toolbox_amd as A
+    V, W0, H0 = synth(16, 24, 4)
+    with pytest.raises(ValueError, match="No update equations defined for cost function with divergence type bogus"):   # nmf.m:166
+        A.nmf(V, 4, dict(divergence="bogus"))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 1 initial encoding matrices."):                    # nmf.m:280
+        A.nmf(V, [2, 2], dict(H_init=[H0]))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 3 initial basis matrices."):                       # nmf.m:302
+        A.nmf(V, [2, 2], dict(W_init=[W0, W0, W0]))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 3 sparsity levels."):                              # nmf.m:318
+        A.nmf(V, [2, 2], dict(W_sparsity=[0.1, 0.2, 0.3]))
+    with pytest.raises(ValueError, match="Requested 2 sources. Given 3 update switches."):                              # nmf.m:368
+        A.nmf(V, [2, 2], dict(W_fixed=[True, False, True]))
+    with pytest.raises(ValueError, match="alpha = 0 and beta = 0 is not supported at this time."):                      # nmf.m:121
+        A.nmf(V, 4, dict(divergence="ab", alpha=0, beta=0))
+    with pytest.raises(ValueError, match="alpha = 0 and beta = 0"):                                                      # cnmf.m:134
+        A.cnmf(V, 4, 2, dict(divergence="ab_divergence", alpha=0, beta=0))
+    with pytest.raises(ValueError, match="Negative values in data!"):                                                    # nmfsc.m:58
+        A.nmfsc(-V, 4)
+
+
+def test_validate_defaults():
+    from nmf_toolbox_amd import toolbox as T
+    V, W0, H0 = synth(16, 24, 4)
+    cfg, W, H, wc, hc = T._validate(V, [4], 1, dict(maxiter=-1, tolerance=0, W_sparsity=-3, alpha=5, seed=1), False)
+    assert cfg["maxiter"] == 100 and cfg["tolerance"] == 1e-3 and cfg["W_sparsity"] == [0.0] and cfg["alpha"] == 1.0 and not wc and not hc
+    assert np.allclose(np.sqrt((W[0] ** 2).sum(0)), 1.0) and H[0].shape == (4, 24) and H[0].min() >= 2.0 ** -52          # nmf.m:277,298-299
+    cfg, W, H, wc, hc = T._validate(V, [1, 3], 3, dict(divergence="ab", alpha=0.5, H_sparsity=[0.1], W_fixed=True, seed=1), True)
+    assert cfg["alpha"] == 0.5 and cfg["H_sparsity"] == [0.1, 0.1] and cfg["W_fixed"] == [True, True] and wc and hc
+    assert W[1].shape == (16, 3, 3) and np.allclose(np.sqrt((W[1] ** 2).sum((0, 2))), 3.0)                               # cnmf.m:331-335
+
+
+def test_shard_columns():
+    from nmf_toolbox_amd.engine import shard_columns
+    for n in (8, 13, 65536):
+        for w in (1, 2, 3, 8):
+            parts = [shard_columns(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n and all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1

@@ -1,0 +1,145 @@
+"""CPU suite: the N > 1 iteration loop (nmf_toolbox_amd.engine.run_sharded_iterations) under torch.distributed/gloo,
+world_size 2.  The phases are computed by a float64 NumPy stand-in that follows the engine's packed all-reduce layouts
+([N | P] generic, [N | rowsum(H)] fused KL, [N | H*H'] fused euclidean); the test proves that column-sharding V/H,
+all-reducing only the packed W-step sums and finishing redundantly on every rank reproduces the unsharded oracle, with
+bit-identical W on all ranks, for both cost schedules (in-step and lagged)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import EPS, synth
+
+
+class NumpyShard:
+    """one rank's phases in float64 (mirrors nmf_toolbox_amd/csrc/api.hip's engine, same packed layouts)"""
+
+    def __init__(self, V, W, H, div, layout, lamW, lamH, fixW, fixH, rank0):
+        self.V, self.W, self.H, self.div, self.layout = V, W.copy(), H.copy(), div, layout
+        self.m, self.n = V.shape
+        self.K = W.shape[1]
+        self.lamW, self.lamH, self.fixW, self.fixH, self.rank0 = lamW, lamH, fixW.astype(bool), fixH.astype(bool), rank0
+        self.cost_lags = layout == "fused"
+        mk = self.m * self.K
+        tail = mk if layout == "generic" and div != "kl" else (self.K * self.K if (layout == "fused" and div == "euclidean") else self.K)
+        self.packed = torch.zeros(mk + tail, dtype=torch.float64)
+        self.cost_local = 0.0
+        self.W *= 1.0 / np.sqrt((self.W ** 2).sum(0))[None, :]                       # nmf.m:130-134
+
+    def _cost(self):
+        S = self.W @ self.H
+        c = 0.5 * np.sum((self.V - S) ** 2) if self.div == "euclidean" else np.sum(self.V * np.log(self.V / S) - self.V + S)
+        c += float(np.sum(self.lamH * np.abs(self.H).sum(1)))
+        if self.rank0:
+            c += float(np.sum(self.lamW * np.abs(self.W).sum(0)))
+        self.cost_local = c
+
+    def wstep_partial(self):
+        mk = self.m * self.K
+        S = self.W @ self.H
+        A = self.V / S if self.div == "kl" else self.V
+        N = A @ self.H.T
+        if self.cost_lags:
+            self._cost()
+        p = self.packed.numpy()
+        p[:mk] = N.ravel(order="F")
+        if self.div == "kl":
+            p[mk:] = self.H.sum(1)
+        elif self.layout == "fused":
+            p[mk:] = (self.H @ self.H.T).ravel(order="F")
+        else:
+            p[mk:] = (S @ self.H.T).ravel(order="F")
+
+    def wstep_finish(self):
+        mk = self.m * self.K
+        p = self.packed.numpy()
+        N = p[:mk].reshape(self.m, self.K, order="F")
+        if self.div == "kl":
+            P = np.broadcast_to(p[mk:][None, :], N.shape)
+        elif self.layout == "fused":
+            P = self.W @ p[mk:].reshape(self.K, self.K, order="F")
+        else:
+            P = p[mk:].reshape(self.m, self.K, order="F")
+        W = self.W
+        dn, dp = (W * P).sum(0), (W * N).sum(0)
+        Wn = W * ((N + W * dn) / np.fmax(P + W * dp + self.lamW[None, :], EPS))
+        Wn *= 1.0 / np.sqrt((Wn ** 2).sum(0))[None, :]
+        self.W = np.where(self.fixW[None, :], W, Wn)
+
+    def hstep(self):
+        S = self.W @ self.H
+        if self.div == "kl":
+            neg, pos = self.W.T @ (self.V / S), np.broadcast_to(self.W.sum(0)[:, None], self.H.shape)
+        else:
+            neg, pos = self.W.T @ self.V, self.W.T @ S
+        Hn = self.H * (neg / np.fmax(pos + self.lamH[:, None], EPS))
+        self.H = np.where(self.fixH[:, None], self.H, Hn)
+        if not self.cost_lags:
+            self._cost()
+
+    def cost_pass(self):
+        self._cost()
+
+    def _copy_cost(self, dst):
+        dst[0] = self.cost_local
+
+
+def _worker(rank, world, port, div, layout, iters, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_toolbox_amd.engine import run_sharded_iterations, shard_columns
+    m, n, K = 48, 90, 6
+    V, W0, H0 = synth(m, n, K)
+    lamW = np.array([0.05] * 2 + [0.0] * 4)
+    lamH = np.array([0.0] * 2 + [0.1] * 4)
+    fixW = np.array([0, 0, 0, 0, 1, 1])
+    fixH = np.array([1, 1, 0, 0, 0, 0])
+    lo, hi = shard_columns(n, world, rank)
+    be = NumpyShard(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0)
+    cost = torch.zeros(iters, dtype=torch.float64)
+    run_sharded_iterations(be, iters, dist, None, cost)
+    q.put((rank, lo, hi, be.W, be.H, cost.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+@pytest.mark.parametrize("layout", ["generic", "fused"])
+def test_sharded_loop_matches_unsharded_oracle(div, layout):
+    from oracle import nmf_oracle as O
+    world, iters = 2, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m, n, K = 48, 90, 6
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=[W0[:, :2], W0[:, 2:4], W0[:, 4:]], H_init=[H0[:2], H0[2:4], H0[4:]], W_sparsity=[0.05, 0.0, 0.0],
+               H_sparsity=[0.0, 0.1, 0.1], W_fixed=[False, False, True], H_fixed=[True, False, False], maxiter=iters, tolerance=1e-300)
+    W, H, cost = O.nmf(V, [2, 2, 2], cfg)
+    W, H = np.hstack(W), np.vstack(H)
+    assert np.array_equal(res[0][3], res[1][3])                     # W bit-identical on both ranks
+    Hs = np.concatenate([r[4] for r in res], axis=1)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(res[0][3], W) < 1e-11 and rel(Hs, H) < 1e-11
+    for r in res:
+        assert rel(r[5], cost) < 1e-12                              # every rank holds the global cost vector
