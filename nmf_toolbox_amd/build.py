@@ -44,7 +44,7 @@ def _newer(src_list, target):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "nmfx_internal.h"), os.path.join(INC, "nmfx.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INC, "nmfx.h")]
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

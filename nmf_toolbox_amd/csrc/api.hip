@@ -84,6 +84,7 @@ struct nmfx_engine {
     bool fused, cost_valid;
     int nsplit_w, isplit_h;
     float *WT, *slabs, *Pbuf, *GW;
+    double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
     // profiling
     bool prof;
     std::vector<ProfEvent> events;
@@ -184,6 +185,8 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->n_cost_partials = (int)((e->m / 128) * e->nsplit_w);
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
+        e->sumV = f.take<double>(1);
+        e->colV = f.take<double>(e->n);
         L.total = f.off;
         L.packed_count = euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT;
         return L;
@@ -326,13 +329,14 @@ nmfx_status small_gemm(nmfx_engine *e, long M, long N, long Kc, OpView A, OpView
     return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
 }
 
-nmfx_status cost_from_partials(nmfx_engine *e, int nparts) {
+nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form = false) {
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
     if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
     const double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
-                       e->lamH, e->cost);
+                       e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV);
 }
 
 // fused W-step pass (K2) or cost-only pass over the local shard; cost refers to the CURRENT (W, H)
@@ -352,7 +356,9 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
     }
     Scope s(e, TAG_SMALL);
     if (do_g2 && e->nsplit_w > 1) TRY(reduce_slabs(e->st, e->slabs, e->nsplit_w, f.slab_stride, f.slab_stride, e->packed, 0));
-    TRY(cost_from_partials(e, (int)((e->m / 128) * e->nsplit_w)));
+    const bool kl = e->div == NMFX_DIV_KL;
+    if (kl) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));   // also the W-step denominator (nmf.m:153)
+    TRY(cost_from_partials(e, (int)((e->m / 128) * e->nsplit_w), kl));
     e->cost_valid = true;
     return NMFX_OK;
 }
@@ -444,7 +450,14 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 1, e->sumsq));
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo == 1, e->f_out));
         if (e->algo == 1) TRY(scale_rows(e->st, e->H, e->K, e->n, e->f_out));
-        if (e->fused) { e->cost_valid = false; return refresh_w_derived(e); }
+        if (e->fused) {
+            e->cost_valid = false;
+            if (e->div == NMFX_DIV_KL) {   // sum(V_local), once
+                TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
+                TRY(sum_vec(e->st, e->colV, e->n, e->sumV));
+            }
+            return refresh_w_derived(e);
+        }
     }
     return recon(e, false);
 }
@@ -458,8 +471,7 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
         TRY(fused_wpass(e, true));
         if (e->div == NMFX_DIV_KL) {
             Scope s(e, TAG_SMALL);
-            TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
-            TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));
+            TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
         } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
             Scope s(e, TAG_GRAM);
             TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},

@@ -212,7 +212,8 @@ nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp,
 
 // cost = scale * sum(partials) + sum_c lamW[c%K]*l1W[c] + sum_k lamH[k]*l1H[k]      nmf.m:206-218
 __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials, int count, double scale, const double *l1W, int nW,
-                                                          const float *lamW, const double *l1H, int K, const float *lamH, double *out) {
+                                                          const float *lamW, const double *l1H, int K, const float *lamH, double *out,
+                                                          const double *dotA, const double *dotB, int ndot, const double *minus) {
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
@@ -220,12 +221,19 @@ __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials
     if (threadIdx.x == 0) {
         if (l1W) for (int c = 0; c < nW; ++c) s += (double)lamW[c % K] * l1W[c];
         if (l1H) for (int k = 0; k < K; ++k) s += (double)lamH[k] * l1H[k];
+        if (dotA) {   // closed-form sum(V_hat) - sum(V) of the KL cost
+            double t = 0.0;
+            for (int k = 0; k < ndot; ++k) t += dotA[k] * dotB[k];
+            s += t - (minus ? *minus : 0.0);
+        }
         *out = s;
     }
 }
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
-                        const double *l1H, int K, const float *lamH, double *out) {
-    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, l1W, nW, lamW, l1H, K, lamH, out);
+                        const double *l1H, int K, const float *lamH, double *out, const double *dotA, const double *dotB, int ndot,
+                        const double *minus) {
+    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, l1W, nW, lamW, l1H, K, lamH, out, dotA, dotB,
+                       ndot, minus);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -325,6 +333,20 @@ __global__ void sum_over_t_kernel(const double *colsum, int K, int T, double *ou
 }
 nmfx_status sum_over_t(hipStream_t st, const double *colsum, int K, int T, double *out) {
     hipLaunchKernelGGL(sum_over_t_kernel, dim3((K + 63) / 64), dim3(64), 0, st, colsum, K, T, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// out[0] = sum of v[0..count)   (fp64)
+__global__ __launch_bounds__(256) void sum_vec_kernel(const double *v, long count, double *out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < count; i += 256) s += v[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) *out = s;
+}
+nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out) {
+    hipLaunchKernelGGL(sum_vec_kernel, dim3(1), dim3(256), 0, st, v, count, out);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

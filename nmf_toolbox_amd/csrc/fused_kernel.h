@@ -1,0 +1,278 @@
+// The fused two-stage MFMA kernel template (included by fused.hip and by the dev-only probe_fused.hip).
+#pragma once
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FT_ROWS = 128;  // stationary rows per workgroup (32 per wave)
+constexpr int FT_C = 64;      // streamed rows (contraction tile of the second product) per step
+
+__device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit raw format
+__device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 s;
+    s.x = (int)(unsigned)b;
+    s.y = (int)((b >> 32) & 0xffffu);
+    s.z = (int)bytes;
+    s.w = 0x00020000;
+    return s;
+}
+
+// FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
+// PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
+template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0>
+__global__ __launch_bounds__(256, 1) void fused_kernel(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LDY = K + 4;
+    constexpr int NKB = K / 32;
+    constexpr int BUF = FT_C * LDY;
+    constexpr bool NEED_S = FUNC != 0;
+    constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
+    constexpr int ROWS_PER_WAVE = FT_C / 4;  // streamed rows each wave moves per tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const long r_wg0 = (long)blockIdx.x * FT_ROWS;
+    const long r0 = r_wg0 + 32 * w;   // this wave's rows r0 .. r0+31
+    const long r = r0 + l31;
+    const long cbeg = (long)blockIdx.y * p.c_per_split;
+    const long cend = cbeg + p.c_per_split < p.Cn ? cbeg + p.c_per_split : p.Cn;
+    const int ntiles = (int)((cend - cbeg) / FT_C);
+
+    // stationary operand: B-port register s holds X(r, k = 8*(s>>2) + 4*h + (s&3))
+    float xreg[NEED_S ? K / 2 : 1];
+    if (NEED_S) {
+#pragma unroll
+        for (int s = 0; s < K / 2; ++s) xreg[s] = p.X[r * p.xs_r + (long)(8 * (s >> 2) + 4 * h + (s & 3)) * p.xs_k];
+    }
+
+    f32x16 acc[DO_G2 ? NKB : 1];
+#pragma unroll
+    for (int kb = 0; kb < (DO_G2 ? NKB : 1); ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[kb][e] = 0.0f;
+
+    // ---- loads.  f32 MFMA shares the SIMD with VALU (every VALU instruction in the loop costs MFMA time), so all per-tile
+    // addressing is wave-uniform (SGPR buffer descriptor + SGPR offset) plus ONE per-lane byte offset computed here.
+    // Streamed tile: LDS-DMA (buffer_load_dwordx4 ... lds), one 1-KiB row of K floats per wave-instruction, wave w moves rows
+    // w, w+4, ...  Issued as inline asm so hipcc does not see an LDS write (with the builtin it drains vmcnt(0) before the next
+    // ds_read and serialises the DMA latency into every tile); completion = s_waitcnt vmcnt(0) + barrier at the tile top.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned y_voff = (unsigned)lane * 16u;
+    auto dma_row = [&](const i32x4 ysrd, int b, int c) {   // c-th row of this wave: tile row w + 4c
+        const int row = w + 4 * c;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((b * BUF + row * LDY) * 4));
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(row * K * 4));
+        unsigned keep;
+        if (lane < K / 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(y_voff), "s"(ysrd), "s"(dst), "s"(soff) : "memory");
+    };
+    auto y_srd = [&](int t) { return make_srd(p.Y + (cbeg + (long)t * FT_C) * K, (unsigned)(FT_C * K * 4)); };
+
+    // V tile of step t: d[jb*16 + reg] = V(r, c = c0 + 32*jb + rowmap(reg, h))
+    float d[32];
+    const unsigned d_voff = D_RC ? (unsigned)((r + 4 * h * p.ldd) * 4) : (unsigned)((p.ldd * (r - r_wg0) + 4 * h) * 4);
+    const __amdgpu_buffer_rsrc_t d_srd_fixed =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * r_wg0), 0, (int)(unsigned)(FT_ROWS * p.ldd * 4), 0x00020000);   // !D_RC
+    auto d_srd = [&](int t) {
+        if (D_RC) return __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(FT_C * p.ldd * 4), 0x00020000);
+        return d_srd_fixed;
+    };
+    // piece i of 16: D_RC two dwords (columns c0 + 32*jb + {(reg&3) + 8*(reg>>2)}), else half of the 8 float4 (one per even i)
+    auto load_d_piece = [&](const __amdgpu_buffer_rsrc_t srd, int t, int i) {
+        if (PROBE & 4) return;
+        if (D_RC) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = 2 * i + u, jb = e >> 4, reg = e & 15;
+                const int soff = (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4);
+                d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, soff, 0));
+            }
+        } else if ((i & 1) == 0) {
+            const int f = i >> 1, jb = f >> 2, q = f & 3;
+            const int soff = (int)((cbeg + (long)t * FT_C + 32 * jb + 8 * q) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                d[jb * 16 + 4 * q + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, soff + 4 * e, 0));
+        }
+    };
+
+    double cost = 0.0;
+    if (ntiles > 0) {
+        const i32x4 ys = y_srd(0);
+#pragma unroll
+        for (int c = 0; c < ROWS_PER_WAVE; ++c) dma_row(ys, 0, c);
+        const __amdgpu_buffer_rsrc_t ds0 = d_srd(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) load_d_piece(ds0, 0, i);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        const int b = (PROBE & 1) ? 0 : (t & 1);
+        const int tn = t + 1 < ntiles ? t + 1 : t;           // the last tile re-fetches itself: keeps the body branch-free
+        if (!(PROBE & 1) || t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA rows of tile t and the V registers have landed
+            __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
+        }
+        const float *Yt = lds + b * BUF;
+        const i32x4 ysn = y_srd(tn);
+        const __amdgpu_buffer_rsrc_t dsn = d_srd(tn);
+        int dma_c = 0;                                        // rows of tile tn issued so far (compile-time after unrolling)
+        auto dma_some = [&](int upto) {                       // issue rows until `upto` have been issued
+            if (PROBE & 1) return;
+#pragma unroll
+            for (int c = 0; c < ROWS_PER_WAVE; ++c)
+                if (c >= dma_c && c < upto) dma_row(ysn, b ^ 1, c);
+            dma_c = upto > dma_c ? upto : dma_c;
+        };
+
+        // ---- software-interleaved tile body -------------------------------------------------------------------------
+        // P1  first product, half 0     || LDS-DMA of the next tile, one row every other group
+        // P2  first product, half 1     || element map of half 0
+        // P3  second product, half 0    || element map of half 1
+        // P4  second product, half 1    || V loads of the next tile, two per step
+        // A wave issues in order and a 32x32x2 f32 MFMA occupies the pipe for 64 cycles, so whatever sits between two MFMAs
+        // in program order must finish (dependency latencies included) inside 64 cycles or the matrix pipe idles.  The
+        // element map is therefore cut into four micro-ops (rcp | mul | log | accumulate) that are placed behind DIFFERENT
+        // MFMAs, LDS operands are fetched one step ahead, and a sched_barrier after every MFMA pins this order (left
+        // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
+        f32x16 sacc[2];
+        float tc = 0.0f;
+        float es[2], er[2];                                   // element-map pipeline state: S value, reciprocal / quotient
+        auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
+            const int sl = reg & 1;
+            if (PROBE & 2) { if (u == 0) asm volatile("" : "+v"(sacc[jb][reg])); return; }
+            const float v = d[jb * 16 + reg];
+            if (FUNC >= 2) {
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
+                if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = er[sl]; }                    // q = V ./ V_hat
+                if (FUNC == 3) {
+                    if (u == 2) er[sl] = (PROBE & 8) ? er[sl] * 1.25f : __builtin_amdgcn_logf(er[sl]);   // log2(q)
+                    if (u == 3) tc = fmaf(v, er[sl], tc);   // sum(V_hat - V) is added in closed form by the caller (see FusedParams)
+                }
+            } else {
+                if (u == 0) {
+                    if (FUNC == 1) { const float e = v - sacc[jb][reg]; tc = fmaf(e, e, tc); }   // nmf.m:208
+                    sacc[jb][reg] = v;
+                }
+            }
+            if ((FUNC == 1 && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
+        };
+        // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements of half jb
+        auto emap_fill = [&](int jb, int i, int M) {
+            const int P = M / 16;                             // MFMAs per element (8 at K=256, 4 at 128, 2 at 64)
+            const int reg = i / P, rem = i % P;
+            if (P >= 4) {
+                if (rem % (P / 4) == 0) emap_u(jb, reg, rem / (P / 4));
+            } else {                                          // P == 2: two micro-ops behind each MFMA
+                emap_u(jb, reg, 2 * rem);
+                emap_u(jb, reg, 2 * rem + 1);
+            }
+        };
+        auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + 8 * g + 4 * h); };
+        if (NEED_S) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[jb][e] = 0.0f;
+            float4 a_cur = g1_read(0, 0);
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {                          // P1 (ph 0), P2 (ph 1)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float4 a_nxt = a_cur;
+                    if (g + 1 < NG) a_nxt = g1_read(ph, g + 1);
+                    else if (ph == 0) a_nxt = g1_read(1, 0);
+                    auto one = [&](int e, float av) {
+                        sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
+                        if (ph == 1) emap_fill(0, 4 * g + e, 4 * NG);
+                        if (ph == 0 && e == 0) dma_some(((g + 1) * ROWS_PER_WAVE + NG - 1) / NG);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    one(0, a_cur.x); one(1, a_cur.y); one(2, a_cur.z); one(3, a_cur.w);
+                    a_cur = a_nxt;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) emap_u(0, reg, 0);
+        }
+        if (DO_G2) {
+            auto g2_read = [&](int jb, int reg, float (&y)[NKB]) {
+                const float *yrow = Yt + (32 * jb + rowmap(reg, h)) * LDY + l31;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) y[kb] = yrow[32 * kb];
+            };
+            float y_cur[NKB], y_nxt[NKB];
+            g2_read(0, 0, y_cur);
+#pragma unroll
+            for (int st = 0; st < 32; ++st) {                        // P3 (st < 16) and P4
+                const int jb = st >> 4, reg = st & 15;
+                if (st + 1 < 32) g2_read((st + 1) >> 4, (st + 1) & 15, y_nxt);
+                const float rr = sacc[jb][reg];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
+                    if (jb == 0) emap_fill(1, reg * NKB + kb, 16 * NKB);       // element map of half 1 under the MFMAs of half 0
+                    if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 32);   // no first product: the DMA rides here
+                    if (kb == NKB / 2 && jb == 1) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) y_cur[kb] = y_nxt[kb];
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) emap_u(1, reg, u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
+        }
+        dma_some(ROWS_PER_WAVE);
+        cost += (double)tc;
+    }
+
+    // epilogue: acc[kb][reg] = O(k = 32*kb + rowmap(reg,h), r)
+    if (DO_G2) {
+        if (EPI == 0) {
+            float *out = p.out + (long)blockIdx.y * p.slab_stride;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) out[r * p.os_r + (long)(32 * kb + rowmap(reg, h)) * p.os_k] = acc[kb][reg];
+        } else {
+            // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int k = 32 * kb + rowmap(reg, h);
+                    if (p.fix && p.fix[k]) continue;
+                    const long idx = (long)k + (long)K * r;
+                    const float den = p.den ? p.den[idx] : (float)p.denvec[k];
+                    const float lam = p.lam ? p.lam[k] : 0.0f;
+                    p.Hio[idx] = p.Hio[idx] * (acc[kb][reg] / fmaxf(den + lam, NMFX_EPS_F));
+                }
+        }
+    }
+    if (p.cost_partials) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+        double *red = reinterpret_cast<double *>(lds);
+        __syncthreads();
+        if (lane == 0) red[w] = cost;
+        __syncthreads();
+        // KL: the kernel sums V.*log2(V./V_hat); ln 2 is applied here, sum(V_hat) - sum(V) by the caller in closed form
+        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (FUNC == 3 ? 0.6931471805599453 : 1.0);
+    }
+}
+
+}  // namespace nmfx

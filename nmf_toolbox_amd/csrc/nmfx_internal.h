@@ -84,7 +84,9 @@ struct FusedParams {
     int K;
     float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
     long slab_stride, os_r, os_k;
-    double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr
+    double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr.  Euclidean: sum (V-S)^2.  KL: sum V.*log(V./S) ONLY -- the caller adds
+                            // sum(S) - sum(V) = sum_k colsum(W)_k*rowsum(H)_k - sum(V) in closed form (two fewer VALU ops per element
+                            // inside the MFMA loop, and exact instead of summing rounded S values)
     float *Hio;           // EPI 1: H updated in place
     const float *den;     // EPI 1: K x n denominator matrix, or nullptr -> denvec
     const double *denvec; // EPI 1: [K]
@@ -124,7 +126,9 @@ nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const dou
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
                      const float *lamH, const uint8_t *fixH, float inv_exp);
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
-                        const double *l1H, int K, const float *lamH, double *out);
+                        const double *l1H, int K, const float *lamH, double *out, const double *dotA = nullptr, const double *dotB = nullptr,
+                        int ndot = 0, const double *minus = nullptr);   // + sum_k dotA[k]*dotB[k] - *minus
+nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
 nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
 nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
