@@ -39,6 +39,7 @@ WORKLOADS = {
     "c2": ("nmf", "euclidean", 8192, 32768, 128, 1, 12.0),
     "c4": ("cnmf", "euclidean", 4096, 16384, 64, 8, 12.0),
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
+    "c3_shard8": ("nmf", "kl", 16384, 8192, 256, 1, 8.0),     # what ONE of 8 ranks holds at c3 (dev aid for the small-kernel overheads)
 }
 
 

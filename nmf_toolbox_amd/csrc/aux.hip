@@ -64,7 +64,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float *X, long ro
     __shared__ double red[4];
     const float *x = X + ld * blockIdx.x;
     double s = 0.0;
-    for (long i = threadIdx.x; i < rows; i += 256) s += red_f(mode, x[i]);
+    if ((rows & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (long i = threadIdx.x; i < rows / 4; i += 256) {
+            const float4 v = x4[i];
+            s += (red_f(mode, v.x) + red_f(mode, v.y)) + (red_f(mode, v.z) + red_f(mode, v.w));
+        }
+    } else {
+        for (long i = threadIdx.x; i < rows; i += 256) s += red_f(mode, x[i]);
+    }
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
@@ -93,18 +101,18 @@ __global__ __launch_bounds__(256) void row_reduce_stage1(const float *X, int row
         if (jj == 0 && k < rows) part[(long)blockIdx.x * rows + k] = red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk];
     }
 }
-__global__ void row_reduce_stage2(const double *part, int rows, int nblk, double *out) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= rows) return;
+__global__ __launch_bounds__(64) void row_reduce_stage2(const double *part, int rows, int nblk, double *out) {
+    const int k = blockIdx.x;   // one wave per row; fixed summation order (deterministic)
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * rows + k];
-    out[k] = s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(long)b * rows + k];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[k] = s;
 }
 nmfx_status row_reduce(hipStream_t st, const float *X, int rows, long ld, long ncols, int mode, double *out, void *scratch) {
     if (rows <= 0) return NMFX_OK;
     double *part = static_cast<double *>(scratch);  // RR_BLOCKS * rows doubles
     hipLaunchKernelGGL(row_reduce_stage1, dim3(RR_BLOCKS), dim3(256), 0, st, X, rows, ld, ncols, mode, part);
-    hipLaunchKernelGGL(row_reduce_stage2, dim3((rows + 63) / 64), dim3(64), 0, st, part, rows, RR_BLOCKS, out);
+    hipLaunchKernelGGL(row_reduce_stage2, dim3(rows), dim3(64), 0, st, part, rows, RR_BLOCKS, out);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -123,23 +131,50 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     const float *pp = p.P ? p.P + p.m * c : nullptr;
     const float pv = p.Pvec ? (float)p.Pvec[c] : 0.0f;
     double dn = 0.0, dp = 0.0;
-    for (long i = threadIdx.x; i < p.m; i += 256) {
-        const float wi = w[i];
-        dn += (double)wi * (double)(pp ? pp[i] : pv);
-        dp += (double)wi * (double)nn[i];
-    }
-    dn = block_sum<4>(dn, red);
-    dp = block_sum<4>(dp, red);
-    const float fdn = (float)dn, fdp = (float)dp, lam = p.lamW ? p.lamW[k] : 0.0f;
-    double ss = 0.0;
-    for (long i = threadIdx.x; i < p.m; i += 256) {
-        const float wi = w[i];
-        float neg = fmaf(wi, fdn, nn[i]);
-        float pos = fmaf(wi, fdp, pp ? pp[i] : pv);
+    const float lam = p.lamW ? p.lamW[k] : 0.0f;
+    const bool vec = (p.m & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(nn) | reinterpret_cast<uintptr_t>(pp)) & 15) == 0;
+    auto upd = [&](float wi, float ni, float pi, float fdn, float fdp) {
+        float neg = fmaf(wi, fdn, ni);
+        float pos = fmaf(wi, fdp, pi);
         if (p.inv_exp != 1.0f) { neg = powf(neg, p.inv_exp); pos = powf(pos, p.inv_exp); }
-        const float wn = wi * (neg / fmaxf(pos + lam, NMFX_EPS_F));
-        w[i] = wn;
-        ss += (double)wn * (double)wn;
+        return wi * (neg / fmaxf(pos + lam, NMFX_EPS_F));
+    };
+    double ss = 0.0;
+    if (vec) {
+        const long m4 = p.m / 4;
+        float4 *w4 = reinterpret_cast<float4 *>(w);
+        const float4 *n4 = reinterpret_cast<const float4 *>(nn), *p4 = reinterpret_cast<const float4 *>(pp);
+        const float4 pvv = make_float4(pv, pv, pv, pv);
+        for (long i = threadIdx.x; i < m4; i += 256) {
+            const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
+            dn += ((double)a.x * c4.x + (double)a.y * c4.y) + ((double)a.z * c4.z + (double)a.w * c4.w);
+            dp += ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w);
+        }
+        dn = block_sum<4>(dn, red);
+        dp = block_sum<4>(dp, red);
+        const float fdn = (float)dn, fdp = (float)dp;
+        for (long i = threadIdx.x; i < m4; i += 256) {
+            const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
+            float4 o;
+            o.x = upd(a.x, b.x, c4.x, fdn, fdp); o.y = upd(a.y, b.y, c4.y, fdn, fdp);
+            o.z = upd(a.z, b.z, c4.z, fdn, fdp); o.w = upd(a.w, b.w, c4.w, fdn, fdp);
+            w4[i] = o;
+            ss += ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+        }
+    } else {
+        for (long i = threadIdx.x; i < p.m; i += 256) {
+            const float wi = w[i];
+            dn += (double)wi * (double)(pp ? pp[i] : pv);
+            dp += (double)wi * (double)nn[i];
+        }
+        dn = block_sum<4>(dn, red);
+        dp = block_sum<4>(dp, red);
+        const float fdn = (float)dn, fdp = (float)dp;
+        for (long i = threadIdx.x; i < p.m; i += 256) {
+            const float wn = upd(w[i], nn[i], pp ? pp[i] : pv, fdn, fdp);
+            w[i] = wn;
+            ss += (double)wn * (double)wn;
+        }
     }
     ss = block_sum<4>(ss, red);
     if (threadIdx.x == 0) p.sumsq[c] = ss;
@@ -166,7 +201,12 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
         if (f_out && t == 0 && threadIdx.x == 0) f_out[k] = nrm;
     } else {
         const float f = (float)(1.0 / sqrt(sumsq[c]));
-        for (long i = threadIdx.x; i < m; i += 256) w[i] = w[i] * f;
+        if ((m & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+            float4 *w4 = reinterpret_cast<float4 *>(w);
+            for (long i = threadIdx.x; i < m / 4; i += 256) { float4 v = w4[i]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; w4[i] = v; }
+        } else {
+            for (long i = threadIdx.x; i < m; i += 256) w[i] = w[i] * f;
+        }
     }
 }
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
@@ -217,17 +257,12 @@ __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials
     __shared__ double red[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
-    s = block_sum<4>(s, red) * scale;
-    if (threadIdx.x == 0) {
-        if (l1W) for (int c = 0; c < nW; ++c) s += (double)lamW[c % K] * l1W[c];
-        if (l1H) for (int k = 0; k < K; ++k) s += (double)lamH[k] * l1H[k];
-        if (dotA) {   // closed-form sum(V_hat) - sum(V) of the KL cost
-            double t = 0.0;
-            for (int k = 0; k < ndot; ++k) t += dotA[k] * dotB[k];
-            s += t - (minus ? *minus : 0.0);
-        }
-        *out = s;
-    }
+    s *= scale;
+    if (l1W) for (int c = threadIdx.x; c < nW; c += 256) s += (double)lamW[c % K] * l1W[c];
+    if (l1H) for (int k = threadIdx.x; k < K; k += 256) s += (double)lamH[k] * l1H[k];
+    if (dotA) for (int k = threadIdx.x; k < ndot; k += 256) s += dotA[k] * dotB[k];   // closed-form sum(V_hat) of the KL cost
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) *out = s - ((dotA && minus) ? *minus : 0.0);
 }
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA, const double *dotB, int ndot,
