@@ -43,7 +43,7 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(alg, div, m, n, K, T, budget_s=20.0):
+def cpu_baseline(alg, div, m, n, K, T, budget_s=40.0):
     """Reference CPU path: oracle (float64 literal restatement, same GEMM list as nmf.m) on a bounded column sample."""
     from oracle import nmf_oracle as O
     try:

@@ -186,7 +186,8 @@ typedef enum {
     NMFX_PRO_RATIO = 1,       /* x ./ x2          (V ./ V_hat,      nmf.m:152) */
     NMFX_PRO_RATIO_SQ = 2,    /* x ./ x2.^2       (V ./ V_hat.^2,   nmf.m:155) */
     NMFX_PRO_RECIP2 = 3,      /* 1 ./ x2          (1 ./ V_hat,      nmf.m:156) */
-    NMFX_PRO_DIFF = 4         /* x2 - x           (V_hat - V: dH = W'*V_hat - W'*V, nmfsc.m:148) */
+    NMFX_PRO_DIFF = 4,        /* x2 - x           (V_hat - V: dH = W'*V_hat - W'*V, nmfsc.m:148) */
+    NMFX_PRO_POWPROD = 5      /* x.^e1 .* x2.^e2  (alpha-beta divergence: V.^alpha .* V_hat.^(beta-1), nmf.m:162) */
 } nmfx_prologue;
 nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t Kc,
                           const float *A, const float *A2, int64_t lda, int32_t proA, const float *B,

@@ -65,6 +65,7 @@ struct ProfEvent {
 struct nmfx_engine {
     long m, n;
     int K, T, KT, div, algo;
+    double alpha, beta;       // NMFX_DIV_AB only; alpha == 0 selects the dual update equations (nmf.m:124-128)
     int device;
     hipStream_t st;
     const float *V;
@@ -201,9 +202,9 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         set_error("nmfx_engine: m, n_local, K_total, T must be positive");
         return NMFX_ERR_INVALID;
     }
-    if (d->divergence == NMFX_DIV_AB) {
-        set_error("nmfx_engine: alpha-beta divergence is not implemented yet");
-        return NMFX_ERR_UNSUPPORTED;
+    if (d->divergence == NMFX_DIV_AB && d->alpha == 0 && d->beta == 0) {   // nmf.m:120-122
+        set_error("alpha = 0 and beta = 0 is not supported at this time.");
+        return NMFX_ERR_INVALID;
     }
     if (d->divergence < 0 || d->divergence > NMFX_DIV_EUCLIDEAN_NOCOST) {
         set_error("nmfx_engine: unknown divergence %d", d->divergence);
@@ -223,6 +224,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->st = static_cast<hipStream_t>(d->stream);
     e->rank0 = 1;
     e->algo = d->algorithm;
+    e->alpha = d->divergence == NMFX_DIV_AB ? d->alpha : 1.0;
+    e->beta = d->divergence == NMFX_DIV_AB ? d->beta : 1.0;
     if (e->algo == 0 && e->T != 1) {
         set_error("nmfx_engine: algorithm nmf requires T == 1");
         return NMFX_ERR_INVALID;
@@ -257,12 +260,25 @@ void num_view(const nmfx_engine *e, OpView &v) {
     v.func = NMFX_PRO_NONE;
     if (mdiv(e) == NMFX_DIV_KL) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO; }
     if (mdiv(e) == NMFX_DIV_IS) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO_SQ; }
+    if (mdiv(e) == NMFX_DIV_AB) {   // nmf.m:159-163: V.^(a-1).*V_hat.^b (dual, a == 0)  |  V.^a.*V_hat.^(b-1)
+        v.p2 = e->Vhat; v.func = NMFX_PRO_POWPROD;
+        if (e->alpha == 0) { v.e1 = (float)(e->alpha - 1); v.e2 = (float)e->beta; }
+        else { v.e1 = (float)e->alpha; v.e2 = (float)(e->beta - 1); }
+    }
 }
 void den_view(const nmfx_engine *e, OpView &v) {
     v.p = e->Vhat;
     v.p2 = nullptr;
     v.func = NMFX_PRO_NONE;
     if (mdiv(e) == NMFX_DIV_IS) { v.p = e->Vhat; v.p2 = e->Vhat; v.func = NMFX_PRO_RECIP2; }
+    if (mdiv(e) == NMFX_DIV_AB) {   // V.^(a+b-1) (dual)  |  V_hat.^(a+b-1)
+        v.p = e->alpha == 0 ? e->V : e->Vhat; v.p2 = v.p; v.func = NMFX_PRO_POWPROD;
+        v.e1 = (float)(e->alpha + e->beta - 1); v.e2 = 0.f;
+    }
+}
+inline float outer_exp(const nmfx_engine *e) {   // the .^(1/alpha) (.^(1/beta) in the dual form) around both gradients, nmf.m:159-163
+    if (mdiv(e) != NMFX_DIV_AB) return 1.0f;
+    return (float)(1.0 / (e->alpha == 0 ? e->beta : e->alpha));
 }
 
 // V_hat = sum_t W_t * rshift_t(H)    (RFD.m:31 / 36-38) ; optionally fused with the cost reduction
@@ -271,13 +287,14 @@ nmfx_status recon(nmfx_engine *e, bool with_cost) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.M = e->m; g.N = e->n; g.Kc = e->KT;
-    g.A = OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
-    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
-    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE};
+    g.A = OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
     g.C = e->Vhat; g.ldc = e->m;
     g.splitk = 1;
     if (with_cost) {
         g.epi = EPI_COST; g.store_c = 1; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
+        g.cost_alpha = (float)e->alpha; g.cost_beta = (float)e->beta;
         long blocks = 0;
         nmfx_status rc = launch_gemm(e->st, g, &blocks);
         e->n_cost_used = (int)blocks;
@@ -295,8 +312,8 @@ nmfx_status x_times_ht(nmfx_engine *e, OpView x, float *out, int tag) {
     g.M = e->m; g.N = e->KT; g.Kc = e->n;
     x.ld = e->m; x.mode = VIEW_RC; x.blk = 0; x.tstride = 0; x.lim = 0;
     g.A = x;
-    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
-    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE};
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
     g.C = out; g.ldc = e->m; g.epi = EPI_STORE; g.splitk = 1;
     return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
 }
@@ -308,10 +325,10 @@ nmfx_status wt_times_x(nmfx_engine *e, OpView x, float *out, int tag) {
     memset(&g, 0, sizeof(g));
     g.M = e->K; g.N = e->n; g.Kc = (long)e->T * e->m;
     if (e->T == 1) {
-        g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         x.ld = e->m; x.mode = VIEW_KC; x.blk = 0; x.tstride = 0; x.lim = 0;
     } else {
-        g.A = OpView{e->W, nullptr, e->m, VIEW_WSTACK_KC, (int)e->m, e->m * e->K, 0, NMFX_PRO_NONE};
+        g.A = OpView{e->W, nullptr, e->m, VIEW_WSTACK_KC, (int)e->m, e->m * e->K, 0, NMFX_PRO_NONE, 0.f, 0.f};
         x.ld = e->m; x.mode = VIEW_XSHIFT_KC; x.blk = (int)e->m; x.tstride = 0; x.lim = (int)e->n;
     }
     g.B = x;
@@ -333,7 +350,8 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
     if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
-    const double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
     // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
                        e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV);
@@ -474,8 +492,8 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
             TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
         } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
             Scope s(e, TAG_GRAM);
-            TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
-                           OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE}, e->packed + mKT, e->K));
+            TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
         }
         return NMFX_OK;
     }
@@ -510,8 +528,8 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             p.Pvec = e->Pvec;
         } else {
             Scope s(e, TAG_GRAM);   // P = W * (H*H')
-            TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
-                           OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->Pbuf, e->m));
+            TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
             p.P = e->Pbuf;
         }
         Scope s(e, TAG_SMALL);
@@ -525,7 +543,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         const size_t mKT = (size_t)e->m * e->KT;
         WUpdateParams p{};
         p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = e->T;
-        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
+        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = outer_exp(e);
         if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
         else {
             TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
@@ -544,10 +562,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         if (e->all_fixH) return NMFX_OK;
         if (e->div == NMFX_DIV_EUCLIDEAN) {   // W'*V_hat = (W'*W)*H   
             Scope s(e, TAG_GRAM);
-            TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE},
-                           OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->GW, e->K));
-            TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE},
-                           OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE}, e->Gp, e->K));
+            TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->GW, e->K));
+            TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Gp, e->K));
         }
         FusedParams f;
         memset(&f, 0, sizeof(f));
@@ -586,7 +604,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
             TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
         }
-        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
     }
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     TRY(recon(e, !nocost));
@@ -681,8 +699,8 @@ nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.Kc = Kc;
-    g.A = OpView{A, A2, (long)lda, opA == NMFX_OP_N ? VIEW_RC : VIEW_KC, 0, 0, 0, proA};
-    g.B = OpView{B, B2, (long)ldb, opB == NMFX_OP_N ? VIEW_KC : VIEW_RC, 0, 0, 0, proB};
+    g.A = OpView{A, A2, (long)lda, opA == NMFX_OP_N ? VIEW_RC : VIEW_KC, 0, 0, 0, proA, 0.f, 0.f};
+    g.B = OpView{B, B2, (long)ldb, opB == NMFX_OP_N ? VIEW_KC : VIEW_RC, 0, 0, 0, proB, 0.f, 0.f};
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.epi = EPI_STORE; g.splitk = 1;
     return gemm_auto(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
 }
@@ -882,8 +900,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.M = m; g.N = n; g.Kc = K;
-        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
-        g.B = OpView{HxT, nullptr, n, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
+        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{HxT, nullptr, n, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         g.C = Vh.as<float>(); g.ldc = m; g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = V.as<float>(); g.ldv = m;
         g.cost_partials = part.as<double>(); g.splitk = 1;
         long blocks = 0;
@@ -895,8 +913,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.M = n; g.N = K; g.Kc = m;
-        g.A = OpView{x, x2, m, VIEW_KC, 0, 0, 0, func};
-        g.B = OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        g.A = OpView{x, x2, m, VIEW_KC, 0, 0, 0, func, 0.f, 0.f};
+        g.B = OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         g.C = outT; g.ldc = n; g.epi = EPI_STORE; g.splitk = 1;
         return gemm_auto(st, g, scratch.p, sb);
     };
@@ -905,8 +923,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         GemmParams g;
         memset(&g, 0, sizeof(g));
         g.M = m; g.N = K; g.Kc = n;
-        g.A = OpView{x, x2, m, VIEW_RC, 0, 0, 0, func};
-        g.B = OpView{HTd, nullptr, n, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
+        g.A = OpView{x, x2, m, VIEW_RC, 0, 0, 0, func, 0.f, 0.f};
+        g.B = OpView{HTd, nullptr, n, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         g.C = out; g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
         return gemm_auto(st, g, scratch.p, sb);
     };
@@ -1013,9 +1031,9 @@ nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.M = m; g.N = n; g.Kc = (long)K * T;
-    g.A = OpView{Wd.as<float>(), nullptr, (long)m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE};
-    if (T == 1) g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE};
-    else g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE};
+    g.A = OpView{Wd.as<float>(), nullptr, (long)m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    if (T == 1) g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
     g.C = Vd.as<float>(); g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
     TRY(launch_gemm(st, g));
     return download(st, Vd.as<float>(), dtype, V_hat, mn, stage, STAGE_ELEMS);

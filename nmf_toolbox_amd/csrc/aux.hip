@@ -255,14 +255,14 @@ __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials
                                                           const float *lamW, const double *l1H, int K, const float *lamH, double *out,
                                                           const double *dotA, const double *dotB, int ndot, const double *minus) {
     __shared__ double red[4];
-    double s = 0.0;
+    double s = 0.0, t = 0.0;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
-    s *= scale;
-    if (l1W) for (int c = threadIdx.x; c < nW; c += 256) s += (double)lamW[c % K] * l1W[c];
-    if (l1H) for (int k = threadIdx.x; k < K; k += 256) s += (double)lamH[k] * l1H[k];
-    if (dotA) for (int k = threadIdx.x; k < ndot; k += 256) s += dotA[k] * dotB[k];   // closed-form sum(V_hat) of the KL cost
-    s = block_sum<4>(s, red);
-    if (threadIdx.x == 0) *out = s - ((dotA && minus) ? *minus : 0.0);
+    s = block_sum<4>(s, red) * scale;   // scale may be -Inf (alpha-beta divergence with alpha*beta == 0, nmf.m:214): apply it to the SUM
+    if (l1W) for (int c = threadIdx.x; c < nW; c += 256) t += (double)lamW[c % K] * l1W[c];
+    if (l1H) for (int k = threadIdx.x; k < K; k += 256) t += (double)lamH[k] * l1H[k];
+    if (dotA) for (int k = threadIdx.x; k < ndot; k += 256) t += dotA[k] * dotB[k];   // closed-form sum(V_hat) of the KL cost
+    t = block_sum<4>(t, red);
+    if (threadIdx.x == 0) *out = (count > 0 ? s : 0.0) + t - ((dotA && minus) ? *minus : 0.0);
 }
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA, const double *dotB, int ndot,

@@ -43,8 +43,15 @@ __device__ __forceinline__ void dec_k(const OpView &v, int kc, long &off, int &g
     }
 }
 
-__device__ __forceinline__ float pro1(int func, float x, float y) {
+__device__ __forceinline__ float mpow(float x, float e) {   // MATLAB x.^e for the exponents that occur: exact for 0 and 1
+    if (e == 0.0f) return 1.0f;
+    if (e == 1.0f) return x;
+    if (e == -1.0f) return 1.0f / x;
+    return powf(x, e);
+}
+__device__ __forceinline__ float pro1(int func, float x, float y, float e1 = 0.f, float e2 = 0.f) {
     switch (func) {
+    case NMFX_PRO_POWPROD: return mpow(x, e1) * mpow(y, e2);
     case NMFX_PRO_RATIO: return x / y;
     case NMFX_PRO_RATIO_SQ: return x / (y * y);
     case NMFX_PRO_RECIP2: return 1.0f / y;
@@ -52,8 +59,8 @@ __device__ __forceinline__ float pro1(int func, float x, float y) {
     default: return x;
     }
 }
-__device__ __forceinline__ float4 pro4(int func, float4 x, float4 y) {
-    return make_float4(pro1(func, x.x, y.x), pro1(func, x.y, y.y), pro1(func, x.z, y.z), pro1(func, x.w, y.w));
+__device__ __forceinline__ float4 pro4(int func, float4 x, float4 y, float e1, float e2) {
+    return make_float4(pro1(func, x.x, y.x, e1, e2), pro1(func, x.y, y.y, e1, e2), pro1(func, x.z, y.z, e1, e2), pro1(func, x.w, y.w, e1, e2));
 }
 
 // one thread's share of a BR x BK operand tile: NCH chunks of 4 elements along the contiguous direction
@@ -89,7 +96,7 @@ struct Loader {
         if (g1 + g2 < 0) return 0.0f;
         float x = v.p[o1 + o2];
         float y = v.p2 ? v.p2[o1 + o2] : 1.0f;
-        return pro1(v.func, x, y);
+        return pro1(v.func, x, y, v.e1, v.e2);
     }
     __device__ __forceinline__ void load(const OpView &v, int r_tile0, int k0, long R, long Kend) {
         if (FAST) {
@@ -101,7 +108,7 @@ struct Loader {
                     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (gr[p] + gk >= 0) {
                         x = *reinterpret_cast<const float4 *>(v.p + offr[p] + ok);
-                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[p] + ok));
+                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[p] + ok), v.e1, v.e2);
                     }
                     reg[p] = x;
                 }
@@ -113,7 +120,7 @@ struct Loader {
                     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (gr[0] + gk >= 0) {
                         x = *reinterpret_cast<const float4 *>(v.p + offr[0] + ok);
-                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[0] + ok));
+                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[0] + ok), v.e1, v.e2);
                     }
                     reg[p] = x;
                 }
@@ -152,8 +159,10 @@ struct Loader {
     }
 };
 
-__device__ __forceinline__ double div_term(int div, float v, float s) {
+__device__ __forceinline__ double div_term(int div, float v, float s, float al, float be) {
     switch (div) {
+    case NMFX_DIV_AB:   // nmf.m:214 (the trailing "+ beta" is the reference's)
+        return (double)(powf(v, al) * powf(s, be)) - ((double)al * powf(v, al + be) + (double)be * powf(s, al + be) + (double)be) / ((double)al + (double)be);
     case NMFX_DIV_KL: return (double)(v * logf(v / s)) - (double)v + (double)s;     // nmf.m:210
     case NMFX_DIV_IS: return (double)(logf(s / v) + v / s) - 1.0;                   // nmf.m:212
     default: { float d = v - s; return (double)d * (double)d; }                     // nmf.m:208 (0.5 applied later)
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
                 if (FAST || (i < p.M && j < p.N)) {
                     float s = acc[a][b][e];
                     if (p.epi == EPI_COST) {
-                        part += div_term(p.cost_div, p.Vref[i + p.ldv * j], s);
+                        part += div_term(p.cost_div, p.Vref[i + p.ldv * j], s, p.cost_alpha, p.cost_beta);
                         if (p.store_c) C[i + p.ldc * j] = s;
                     } else {
                         if (p.accumulate) s += C[i + p.ldc * j];

@@ -40,7 +40,8 @@ struct OpView {
     int blk;          // length of the inner index of a stacked (t, inner) index
     long tstride;     // VIEW_WSTACK_KC: m*K
     int lim;          // VIEW_XSHIFT_KC: n
-    int func;         // nmfx_prologue (+ PRO_DIFF)
+    int func;         // nmfx_prologue
+    float e1, e2;     // NMFX_PRO_POWPROD exponents (MATLAB .^ semantics: x.^0 == 1, x.^1 == x)
 };
 
 enum EpiMode {
@@ -57,6 +58,7 @@ struct GemmParams {
     int store_c;         // EPI_COST: also store acc to C
     int epi;             // EpiMode
     int cost_div;        // nmfx_divergence for EPI_COST
+    float cost_alpha, cost_beta;   // NMFX_DIV_AB (nmf.m:214)
     const float *Vref;   // EPI_COST: reference matrix (M x N, ld = ldv)
     long ldv;
     double *cost_partials;  // EPI_COST: one fp64 partial per block [gridDim.x*gridDim.y]

@@ -187,8 +187,8 @@ def _cost(div, V, V_hat, alpha, beta):
         if div in ("is_divergence", "is"):                # nmf.m:211-212
             return np.sum(np.log(V_hat / V) + (V / V_hat) - 1.0)
         if div in ("ab_divergence", "ab"):                # nmf.m:213-214
-            a, b = alpha, beta
-            return (-1.0 / (a * b)) * np.sum(V ** a * V_hat ** b - (a * V ** (a + b) + b * V_hat ** (a + b) + b) / (a + b))
+            a, b = np.float64(alpha), np.float64(beta)     # IEEE division like MATLAB: alpha*beta == 0 gives -Inf, not an exception
+            return (np.float64(-1.0) / (a * b)) * np.sum(V ** a * V_hat ** b - (a * V ** (a + b) + b * V_hat ** (a + b) + b) / (a + b))
     return None
 
 
