@@ -929,7 +929,152 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         return gemm_auto(st, g, scratch.p, sb);
     };
 
+    // ---- fast path: the same algorithm on the fused kernels (V_hat never materialised) -----------------------------------
+    //   objective         0.5*||V - W*H||^2          fused cost-only pass (S = W*H in registers)
+    //   W'*V, V*H'        fused H-step / W-step passes with R = V
+    //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
+    const bool fast = p->path != 1 && fused_supported(K) && m % 128 == 0 && n % 128 == 0;
+    if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
+    DevBuf WTb, slabs, Gb, Denb, KKb, fparts;
+    int nsplit_w = 1, isplit_h = 1;
+    if (fast) {
+        auto pick = [](long blocks, long extent) { int s_ = 1; while (blocks * s_ < 256 && extent % (64L * s_ * 2) == 0 && extent / (s_ * 2) >= 64) s_ *= 2; return s_; };
+        nsplit_w = pick(m / 128, n);
+        isplit_h = pick(n / 128, m);
+        TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
+        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * (m / 128) * nsplit_w));
+    }
+    // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
+    auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.cost_partials = fparts.as<double>();
+        TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
+        return read_obj(st, fparts.as<double>(), (int)((m / 128) * nsplit_w), costd.as<double>(), obj);
+    };
+    auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = M_; g.N = N_; g.Kc = Kc_; g.A = A_; g.B = B_; g.C = C_; g.ldc = ldc_; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+    // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
+    auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
+        TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = V.as<float>(); f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = m / isplit_h;
+        f.out = isplit_h == 1 ? Gb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
+        TRY(launch_fused(st, f, isplit_h, false, 0, true, 0));
+        if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Gb.as<float>(), 0));
+        TRY(kk_gemm(K, K, m, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+        return kk_gemm(K, n, K, OpView{KKb.as<float>(), nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{Hx, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, Denb.as<float>(), K);
+    };
+    // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx')
+    auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
+        TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
+        if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));
+        TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+        return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{KKb.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
+    };
     double stepH = 1.0, stepW = 1.0;   // nmfsc.m:133-134
+    if (fast) {
+        DevBuf Hcb;
+        TRY(Hcb.alloc(Kn * 4));
+        float *Hcur = Hk.as<float>(), *Hcand = Hcb.as<float>();
+        double *nrm2 = costd.as<double>() + 8;
+        TRY(transpose_f32(st, HTd, n, K, Hcur));
+        TRY(fast_obj(Wd, Hcur, &r->cost[0]));                                                   // nmfsc.m:138-139
+        int ncost = p->maxiter + 1, nH = 0, nW = 0;
+        bool early = false;
+        for (int it = 1; it <= p->maxiter && !early; ++it) {
+            double cur_obj = r->cost[it - 1];
+            if (!fixH) {
+                TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
+                if (sH > 0) {
+                    TRY(axpy_f32(st, (long)Kn, -1.0f, Gb.as<float>(), Denb.as<float>(), Denb.as<float>()));   // dH = pos - neg   nmfsc.m:148
+                    TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));             // dH' (n x K): rows of H are contiguous there
+                    const double begobj = cur_obj;                                              // nmfsc.m:149
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
+                        TRY(projfunc_cols(st, HnewT, n, K, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
+                        TRY(transpose_f32(st, HnewT, n, K, Hcand));
+                        TRY(fast_obj(Wd, Hcand, &newobj));                                          // nmfsc.m:160-161
+                        if (newobj <= begobj) break;                                                // nmfsc.m:164
+                        stepH /= 2;                                                                 // nmfsc.m:169
+                        if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
+                    }
+                    if (r->tries_H) r->tries_H[nH] = tries;
+                    ++nH;
+                    if (early) { ncost = it; break; }
+                    stepH *= 1.2;                                                                   // nmfsc.m:178
+                    std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
+                    cur_obj = newobj;
+                } else {
+                    TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
+                    TRY(transpose_f32(st, Hcur, K, n, HTd));
+                    TRY(col_reduce(st, HTd, n, n, K, 1, nrm2));                                     // nmfsc.m:185
+                    TRY(scale_cols(st, HTd, n, K, nrm2, 1, 1));                                     // nmfsc.m:186
+                    TRY(scale_cols(st, Wd, m, K, nrm2, 1, 0));                                      // nmfsc.m:187
+                    TRY(transpose_f32(st, HTd, n, K, Hcur));
+                    cur_obj = NAN;
+                }
+            }
+            if (!fixW) {
+                if (sW > 0 && !(cur_obj == cur_obj)) TRY(fast_obj(Wd, Hcur, &cur_obj));            // nmfsc.m:193,197
+                TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                        // V*H', V_hat*H'       nmfsc.m:194-195
+                if (sW > 0) {
+                    const double begobj = cur_obj;
+                    TRY(axpy_f32(st, (long)mK, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dW = pos - neg     nmfsc.m:200
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        TRY(axpy_f32(st, (long)mK, (float)(-stepW), G2.as<float>(), Wd, Wnew));     // nmfsc.m:205
+                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
+                        TRY(fast_obj(Wnew, Hcur, &newobj));                                         // nmfsc.m:211-212
+                        if (newobj <= begobj) break;                                                // nmfsc.m:215
+                        stepW /= 2;
+                        if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
+                    }
+                    if (r->tries_W) r->tries_W[nW] = tries;
+                    ++nW;
+                    if (early) { ncost = it; break; }
+                    stepW *= 1.2;                                                                   // nmfsc.m:228
+                    std::swap(Wd, Wnew);                                                            // nmfsc.m:229
+                    cur_obj = newobj;
+                } else {
+                    TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
+                    cur_obj = NAN;
+                }
+            }
+            if (cur_obj == cur_obj) r->cost[it] = cur_obj;                                          // same (W, H) as the accepted objective
+            else TRY(fast_obj(Wd, Hcur, &r->cost[it]));                                             // nmfsc.m:237-238
+            if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
+                ncost = it + 1;
+                break;
+            }
+        }
+        r->cost_len = ncost;
+        r->iters_run = ncost - 1;
+        r->stepsize_H = stepH; r->stepsize_W = stepW;
+        r->converged_early = early ? 1 : 0;
+        if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+        if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+        TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
+        TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+        return NMFX_OK;
+    }
     TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
     int ncost = p->maxiter + 1, nH = 0, nW = 0;
     bool early = false;

@@ -120,6 +120,7 @@ nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double 
     dim3 g(count), b(PF_THREADS);
     if (len <= 4L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<4>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
     else if (len <= 16L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<16>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
+    else if (len <= 32L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<32>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
     else if (len <= 64L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<64>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
     else {
         set_error("projfunc: vector length %ld exceeds the register-resident limit %d", len, 64 * PF_THREADS);

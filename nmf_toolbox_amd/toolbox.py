@@ -249,6 +249,7 @@ def nmfsc(V, num_basis_elems, config=None, device=0, info=None):
     p.W_fixed, p.H_fixed = _fptr(fw), _fptr(fh)
     p.maxiter, p.tolerance, p.device = maxiter, (-1.0 if cfg.get("nmfx_disable_stop", False) else tol), int(device)
     p.sc_W_sparsity, p.sc_H_sparsity = sW, sH
+    p.path = int(cfg.get("nmfx_path", 0))
     r = _lib.Result()
     r.W, r.H, r.cost, r.tries_H, r.tries_W = _fptr(Wout), _fptr(Hout), _fptr(cost), _fptr(tH), _fptr(tW)
     _lib.check(_lib.load().nmfx_nmfsc(C.byref(p), C.byref(r)))

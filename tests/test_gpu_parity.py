@@ -171,3 +171,23 @@ def test_cnmf_ab_divergence(gpu_lib, alpha, beta):
     V, W0, H0 = synth(96, 130, 5, T=3)
     cfg = dict(divergence="ab", alpha=alpha, beta=beta, W_init=W0, H_init=H0, maxiter=15 if alpha != 0 else 2, tolerance=1e-12)
     _check(gpu_lib.cnmf(V, 5, 3, cfg), O.cnmf(V, 5, 3, cfg), tol=2e-5, cost_tol=2e-5)
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
+def test_nmfsc_fused_path_matches_oracle(gpu_lib, sW, sH):
+    """nmfsc on the fused kernels (objective = fused cost pass, gradients in Gram form) vs the oracle: identical line-search branches."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 1024, 64)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=20, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1, i2 = {}, {}, {}
+    ref = O.nmfsc(V, 64, cfg, info=i0)
+    got = gpu_lib.nmfsc(V, 64, dict(cfg, nmfx_path=2), info=i1)
+    gen = gpu_lib.nmfsc(V, 64, dict(cfg, nmfx_path=1), info=i2)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    assert i2["triesH"] == i0["triesH"] and i2["triesW"] == i0["triesW"]
+    _check(got, ref)
+    _check(gen, ref)
