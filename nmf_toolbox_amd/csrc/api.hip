@@ -83,6 +83,8 @@ struct nmfx_engine {
     int n_cost_partials, n_cost_used;
     // fused path (fused.hip): V_hat is never materialised
     bool fused, cost_valid;
+    bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
+    float *CC;                // KT x KT Gram of the stacked W (gram path)
     int nsplit_w, isplit_h;
     float *WT, *slabs, *Pbuf, *GW;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
@@ -192,8 +194,15 @@ Layout layout(nmfx_engine *e, void *ws) {
         L.packed_count = euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT;
         return L;
     }
+    if (e->gram) {
+        e->Pbuf = c.take<float>(mKT);
+        e->CC = c.take<float>((size_t)e->KT * e->KT);
+        size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
+        size_t gg = std::max(g4, g5);
+        if (gg > e->gemm_scratch_bytes) { e->gemm_scratch_bytes = gg; e->gemm_scratch = c.take<float>(gg / sizeof(float)); }
+    }
     L.total = c.off;
-    L.packed_count = div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT;
+    L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
     return L;
 }
 
@@ -238,6 +247,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
+    e->gram = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
         auto pick = [](long blocks, long extent) {   // grid.y so that blocks*split >= 256 while extent/split stays a multiple of 64
@@ -282,7 +292,7 @@ inline float outer_exp(const nmfx_engine *e) {   // the .^(1/alpha) (.^(1/beta) 
 }
 
 // V_hat = sum_t W_t * rshift_t(H)    (RFD.m:31 / 36-38) ; optionally fused with the cost reduction
-nmfx_status recon(nmfx_engine *e, bool with_cost) {
+nmfx_status recon(nmfx_engine *e, bool with_cost, bool store = true) {
     Scope s(e, with_cost ? TAG_RECON_COST : TAG_RECON);
     GemmParams g;
     memset(&g, 0, sizeof(g));
@@ -293,7 +303,7 @@ nmfx_status recon(nmfx_engine *e, bool with_cost) {
     g.C = e->Vhat; g.ldc = e->m;
     g.splitk = 1;
     if (with_cost) {
-        g.epi = EPI_COST; g.store_c = 1; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
+        g.epi = EPI_COST; g.store_c = store ? 1 : 0; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
         g.cost_alpha = (float)e->alpha; g.cost_beta = (float)e->beta;
         long blocks = 0;
         nmfx_status rc = launch_gemm(e->st, g, &blocks);
@@ -477,6 +487,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             return refresh_w_derived(e);
         }
     }
+    if (e->gram) return NMFX_OK;   // no V_hat state on the Gram path
     return recon(e, false);
 }
 
@@ -501,7 +512,11 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
     OpView a{}, b{};
     num_view(e, a);
     TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
-    if (div_has_matrix_den(e->div)) {
+    if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
+        Scope s(e, TAG_GRAM);
+        OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        TRY(small_gemm(e, e->KT, e->KT, e->n, hs, hs, e->packed + mKT, e->KT));
+    } else if (div_has_matrix_den(e->div)) {
         den_view(e, b);
         TRY(x_times_ht(e, b, e->packed + mKT, TAG_WDEN));
     } else {
@@ -544,7 +559,11 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         WUpdateParams p{};
         p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = e->T;
         p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = outer_exp(e);
-        if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
+        if (e->gram) {   // P_all = W_flat * (Hs*Hs')
+            TRY(small_gemm(e, e->m, e->KT, e->KT, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->packed + mKT, nullptr, (long)e->KT, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
+            p.P = e->Pbuf;
+        } else if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
         else {
             TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
             p.Pvec = e->Pvec;
@@ -552,6 +571,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         TRY(w_update(e->st, p));
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, e->algo == 1, nullptr));
     }
+    if (e->gram) return NMFX_OK;
     return recon(e, false);
 }
 
@@ -595,7 +615,21 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         OpView a{}, b{};
         num_view(e, a);
         TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
-        if (div_has_matrix_den(e->div)) {
+        if (e->gram) {
+            // sum_t W_t' * lshift_t(V_hat) = sum_t D_t * lshift_t(Hs),  D = W_flat' * W_flat  (cnmf.m:217-226 without V_hat)
+            Scope s(e, TAG_GRAM);
+            OpView wf{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+            TRY(small_gemm(e, e->KT, e->KT, e->m, wf, wf, e->CC, e->KT));
+            for (int t = 0; t < e->T; ++t) {
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
+                g.A = OpView{e->CC + (long)t * e->K, nullptr, (long)e->KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{e->H + (long)e->K * t, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->n - t, t, NMFX_PRO_NONE, 0.f, 0.f};
+                g.C = e->Gp; g.ldc = e->K; g.accumulate = t > 0; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(launch_gemm(e->st, g));
+            }
+        } else if (div_has_matrix_den(e->div)) {
             den_view(e, b);
             TRY(wt_times_x(e, b, e->Gp, TAG_HDEN));
         }
@@ -607,7 +641,8 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
     }
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    TRY(recon(e, !nocost));
+    if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
+    else TRY(recon(e, !nocost));
     Scope s(e, TAG_SMALL);
     e->cost_valid = true;
     return cost_from_partials(e, nocost ? 0 : e->n_cost_used);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g)
     switch (v.mode) {
     case VIEW_RC: off = r; g = 0; break;
     case VIEW_HSTACK_RC: { int t = r / v.blk; int k = r - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
-    case VIEW_HSTACK_KC: off = v.ld * r; g = r; break;
+    case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim; break;
     case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
     default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
     }
@@ -49,9 +49,10 @@ __device__ __forceinline__ float mpow(float x, float e) {   // MATLAB x.^e for t
     if (e == -1.0f) return 1.0f / x;
     return powf(x, e);
 }
+template <bool HEAVY>
 __device__ __forceinline__ float pro1(int func, float x, float y, float e1 = 0.f, float e2 = 0.f) {
+    if (HEAVY && func == NMFX_PRO_POWPROD) return mpow(x, e1) * mpow(y, e2);
     switch (func) {
-    case NMFX_PRO_POWPROD: return mpow(x, e1) * mpow(y, e2);
     case NMFX_PRO_RATIO: return x / y;
     case NMFX_PRO_RATIO_SQ: return x / (y * y);
     case NMFX_PRO_RECIP2: return 1.0f / y;
@@ -59,12 +60,14 @@ __device__ __forceinline__ float pro1(int func, float x, float y, float e1 = 0.f
     default: return x;
     }
 }
+template <bool HEAVY>
 __device__ __forceinline__ float4 pro4(int func, float4 x, float4 y, float e1, float e2) {
-    return make_float4(pro1(func, x.x, y.x, e1, e2), pro1(func, x.y, y.y, e1, e2), pro1(func, x.z, y.z, e1, e2), pro1(func, x.w, y.w, e1, e2));
+    return make_float4(pro1<HEAVY>(func, x.x, y.x, e1, e2), pro1<HEAVY>(func, x.y, y.y, e1, e2), pro1<HEAVY>(func, x.z, y.z, e1, e2),
+                       pro1<HEAVY>(func, x.w, y.w, e1, e2));
 }
 
 // one thread's share of a BR x BK operand tile: NCH chunks of 4 elements along the contiguous direction
-template <int BR, bool KC, bool FAST>
+template <int BR, bool KC, bool FAST, bool HEAVY>
 struct Loader {
     static constexpr int NCH = BR * BK / 4 / NTHREADS;
     static constexpr int LDS_STRIDE = BR + (KC ? 1 : 0);
@@ -96,7 +99,7 @@ struct Loader {
         if (g1 + g2 < 0) return 0.0f;
         float x = v.p[o1 + o2];
         float y = v.p2 ? v.p2[o1 + o2] : 1.0f;
-        return pro1(v.func, x, y, v.e1, v.e2);
+        return pro1<HEAVY>(v.func, x, y, v.e1, v.e2);
     }
     __device__ __forceinline__ void load(const OpView &v, int r_tile0, int k0, long R, long Kend) {
         if (FAST) {
@@ -108,7 +111,7 @@ struct Loader {
                     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (gr[p] + gk >= 0) {
                         x = *reinterpret_cast<const float4 *>(v.p + offr[p] + ok);
-                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[p] + ok), v.e1, v.e2);
+                        if (v.func != NMFX_PRO_NONE) x = pro4<HEAVY>(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[p] + ok), v.e1, v.e2);
                     }
                     reg[p] = x;
                 }
@@ -120,7 +123,7 @@ struct Loader {
                     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (gr[0] + gk >= 0) {
                         x = *reinterpret_cast<const float4 *>(v.p + offr[0] + ok);
-                        if (v.func != NMFX_PRO_NONE) x = pro4(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[0] + ok), v.e1, v.e2);
+                        if (v.func != NMFX_PRO_NONE) x = pro4<HEAVY>(v.func, x, *reinterpret_cast<const float4 *>(v.p2 + offr[0] + ok), v.e1, v.e2);
                     }
                     reg[p] = x;
                 }
@@ -159,21 +162,24 @@ struct Loader {
     }
 };
 
+template <bool HEAVY>
 __device__ __forceinline__ double div_term(int div, float v, float s, float al, float be) {
-    switch (div) {
-    case NMFX_DIV_AB:   // nmf.m:214 (the trailing "+ beta" is the reference's)
+    if (HEAVY && div == NMFX_DIV_AB)   // nmf.m:214 (the trailing "+ beta" is the reference's)
         return (double)(powf(v, al) * powf(s, be)) - ((double)al * powf(v, al + be) + (double)be * powf(s, al + be) + (double)be) / ((double)al + (double)be);
+    switch (div) {
     case NMFX_DIV_KL: return (double)(v * logf(v / s)) - (double)v + (double)s;     // nmf.m:210
     case NMFX_DIV_IS: return (double)(logf(s / v) + v / s) - 1.0;                   // nmf.m:212
     default: { float d = v - s; return (double)d * (double)d; }                     // nmf.m:208 (0.5 applied later)
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
+// HEAVY: instantiations that carry the powf-based element maps / alpha-beta cost (kept out of the common kernels: the
+// inlined powf bodies cost registers and scratch in every variant otherwise)
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST, bool HEAVY = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using LA = Loader<BM, A_KC, FAST>;
-    using LB = Loader<BN, B_KC, FAST>;
+    using LA = Loader<BM, A_KC, FAST, HEAVY>;
+    using LB = Loader<BN, B_KC, FAST, HEAVY>;
     constexpr int LDA_S = LA::LDS_STRIDE, LDB_S = LB::LDS_STRIDE;
     constexpr int A_SZ = BK * LDA_S, B_SZ = BK * LDB_S;
     constexpr int A_SZ_AL = (A_SZ + 3) & ~3, B_SZ_AL = (B_SZ + 3) & ~3;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
                 if (FAST || (i < p.M && j < p.N)) {
                     float s = acc[a][b][e];
                     if (p.epi == EPI_COST) {
-                        part += div_term(p.cost_div, p.Vref[i + p.ldv * j], s, p.cost_alpha, p.cost_beta);
+                        part += div_term<HEAVY>(p.cost_div, p.Vref[i + p.ldv * j], s, p.cost_alpha, p.cost_beta);
                         if (p.store_c) C[i + p.ldc * j] = s;
                     } else {
                         if (p.accumulate) s += C[i + p.ldc * j];
@@ -274,13 +280,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool FAST>
+template <int BM, int BN, bool A_KC, bool B_KC, bool FAST, bool HEAVY = false>
 static nmfx_status launch_cfg(hipStream_t st, const GemmParams &p) {
-    using LA = Loader<BM, A_KC, FAST>;
-    using LB = Loader<BN, B_KC, FAST>;
+    using LA = Loader<BM, A_KC, FAST, HEAVY>;
+    using LB = Loader<BN, B_KC, FAST, HEAVY>;
     constexpr int A_SZ_AL = (BK * LA::LDS_STRIDE + 3) & ~3, B_SZ_AL = (BK * LB::LDS_STRIDE + 3) & ~3;
     const size_t lds = sizeof(float) * 2 * (A_SZ_AL + B_SZ_AL);
-    auto kern = gemm_kernel<BM, BN, A_KC, B_KC, FAST>;
+    auto kern = gemm_kernel<BM, BN, A_KC, B_KC, FAST, HEAVY>;
     static bool attr_done = false;
     if (!attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -302,13 +308,13 @@ static bool view_fast_ok(const OpView &v) {
     return true;
 }
 
-template <int BM, int BN, bool FAST>
+template <int BM, int BN, bool FAST, bool HEAVY = false>
 static nmfx_status dispatch_views(hipStream_t st, const GemmParams &p) {
     const bool akc = is_kc(p.A.mode), bkc = is_kc(p.B.mode);
-    if (akc && bkc) return launch_cfg<BM, BN, true, true, FAST>(st, p);
-    if (akc) return launch_cfg<BM, BN, true, false, FAST>(st, p);
-    if (bkc) return launch_cfg<BM, BN, false, true, FAST>(st, p);
-    return launch_cfg<BM, BN, false, false, FAST>(st, p);
+    if (akc && bkc) return launch_cfg<BM, BN, true, true, FAST, HEAVY>(st, p);
+    if (akc) return launch_cfg<BM, BN, true, false, FAST, HEAVY>(st, p);
+    if (bkc) return launch_cfg<BM, BN, false, true, FAST, HEAVY>(st, p);
+    return launch_cfg<BM, BN, false, false, FAST, HEAVY>(st, p);
 }
 
 void gemm_tile_shape(long M, long N, int &bm, int &bn) {
@@ -325,8 +331,11 @@ nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
     const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
     bool fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && view_fast_ok(p.A) &&
                 view_fast_ok(p.B);
-    if (!fast) bm = bn = 128;
+    const bool heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
+    if (!fast || heavy) bm = bn = 128;
+    if (heavy) fast = fast && (p.M % 128 == 0) && (p.N % 128 == 0);
     if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    if (heavy) return fast ? dispatch_views<128, 128, true, true>(st, p) : dispatch_views<128, 128, false, true>(st, p);
     if (bm == 64) return fast ? dispatch_views<64, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
     if (bn == 64) return fast ? dispatch_views<128, 64, true>(st, p) : dispatch_views<128, 128, false>(st, p);
     return fast ? dispatch_views<128, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);

@@ -38,8 +38,8 @@ struct OpView {
     long ld;          // leading dimension (elements)
     int mode;         // ViewMode
     int blk;          // length of the inner index of a stacked (t, inner) index
-    long tstride;     // VIEW_WSTACK_KC: m*K
-    int lim;          // VIEW_XSHIFT_KC: n
+    long tstride;     // VIEW_WSTACK_KC: m*K;  VIEW_HSTACK_KC: if > 0, rows r >= tstride read as zero
+    int lim;          // VIEW_XSHIFT_KC: n;  VIEW_HSTACK_KC: extra column shift g (element valid iff r + g >= t)
     int func;         // nmfx_prologue
     float e1, e2;     // NMFX_PRO_POWPROD exponents (MATLAB .^ semantics: x.^0 == 1, x.^1 == x)
 };

@@ -191,3 +191,18 @@ def test_nmfsc_fused_path_matches_oracle(gpu_lib, sW, sH):
     assert i2["triesH"] == i0["triesH"] and i2["triesW"] == i0["triesW"]
     _check(got, ref)
     _check(gen, ref)
+
+
+@pytest.mark.parametrize("div", ["euclidean", "frobenius"])
+@pytest.mark.parametrize("m,n,K,T", [(256, 1024, 16, 8), (96, 130, 5, 3), (128, 256, 8, 1), (200, 333, 7, 4)])
+def test_cnmf_gram_form_matches_materialised_and_oracle(gpu_lib, div, m, n, K, T):
+    """cnmf euclidean without V_hat in HBM (denominators from the KT x KT Grams) == the materialised GEMM path == oracle."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0 if T > 1 else W0[:, :, 0], H_init=H0, maxiter=20, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.cnmf(V, K, T, cfg)
+    gram = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=0))
+    mat = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1))
+    _check(gram, ref)
+    _check(mat, ref)
+    _check(gram, mat)
