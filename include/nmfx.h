@@ -100,6 +100,9 @@ nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r);
 nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = nmfsc(V, num_basis_elems, config)          -- replaces nmfsc.m:1 (hot loop nmfsc.m:141-245) */
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r);
+/* [W,H,cost] = cnmfsc(V, num_basis_elems, context_len, config) -- replaces cnmfsc.m:1 (hot loop cnmfsc.m:155-277).
+ * Uses sc_W_sparsity / sc_H_sparsity, T = context_len, W_fixed[0] / H_fixed[0]; result.tries_W needs maxiter*T entries. */
+nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r);
 /* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
                              const void *H, void *V_hat, int32_t device);

@@ -6,7 +6,7 @@
  * logic before calling in here.
  *
  *   [W, H, cost, info] = nmfx_mex(algo, V, W_init, H_init, K_s, T, opts)
- *     algo   : 'nmf' | 'cnmf' | 'nmfsc'
+ *     algo   : 'nmf' | 'cnmf' | 'nmfsc' | 'cnmfsc'
  *     V      : m x n double          W_init : m x K x T double        H_init : K x n double
  *     K_s    : 1 x S int32 (basis elements per source, sum = K)
  *     opts   : struct with fields divergence (int32 nmfx_divergence), alpha, beta, W_sparsity, H_sparsity (1 x S double),
@@ -73,6 +73,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (!strcmp(algo, "nmf")) st = nmfx_nmf(&p, &r);
     else if (!strcmp(algo, "cnmf")) st = nmfx_cnmf(&p, &r);
     else if (!strcmp(algo, "nmfsc")) st = nmfx_nmfsc(&p, &r);
+    else if (!strcmp(algo, "cnmfsc")) st = nmfx_cnmfsc(&p, &r);
     else { mexErrMsgIdAndTxt("nmfx:algo", "unknown algorithm %s", algo); return; }
     if (st != NMFX_OK) mexErrMsgIdAndTxt("nmfx:error", "%s", nmfx_last_error());   /* same text the reference's error() uses */
     mxSetM(plhs[2], (mwSize)r.cost_len);                                         /* cost = cost(1:iter) trim (nmf.m:222) */

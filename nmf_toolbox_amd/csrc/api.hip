@@ -1190,6 +1190,183 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     return NMFX_OK;
 }
 
+// cnmfsc.m:67-277 on the generic GEMM (materialised V_hat: its W branch updates V_hat incrementally, cnmfsc.m:262).
+// The reference's quirks are mirrored, see oracle/nmf_oracle.py::cnmfsc.
+nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
+    TRY(validate_problem(p, r, true));
+    const long m = p->m, n = p->n;
+    const int K = p->K_total, T = p->T, KT = K * T;
+    if (n < T) { set_error("cnmfsc: context_len exceeds the number of columns"); return NMFX_ERR_INVALID; }
+    const size_t mn = (size_t)m * n, mK = (size_t)m * K, mKT = (size_t)m * KT, Kn = (size_t)K * n;
+    double vmin = INFINITY, vmax = -INFINITY;   // cnmfsc.m:67-72
+    if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    TRY(check_device(p->device));
+    hipStream_t st = nullptr;
+    double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity, L1a = 0, L1s = 0;
+    if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // cnmfsc.m:100-104
+    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
+    const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
+
+    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, G1, G2, stage, part, costd, scratch, rrs;
+    TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
+    TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
+    TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
+    const size_t gmax = std::max(Kn, mKT);
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    TRY(part.alloc(sizeof(double) * gemm_grid_blocks(m, n))); TRY(costd.alloc(64 + sizeof(double) * K));
+    size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
+    TRY(scratch.alloc(sb));
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));
+    TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->H_init, p->dtype, Hb.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    float *W0 = W0b.as<float>(), *W = Wb.as<float>(), *Wnew = Wnb.as<float>(), *H = Hb.as<float>(), *Hnew = Hnb.as<float>(), *HT = HTb.as<float>();
+    NMFX_HIP(hipMemcpyAsync(W, W0, mKT * 4, hipMemcpyDeviceToDevice, st));                     // W = W0   cnmfsc.m:94
+    if (sW > 0) TRY(projfunc_cols(st, W, m, KT, L1a, 1.0, 1, nullptr));                          // cnmfsc.m:105-109 (W only, not W0)
+    auto project_rows = [&](float *Hx) -> nmfx_status {   // rows of H (K x n) through the transposed copy
+        TRY(transpose_f32(st, Hx, K, n, HT));
+        TRY(projfunc_cols(st, HT, n, K, L1s, 1.0, 1, nullptr));
+        return transpose_f32(st, HT, n, K, Hx);
+    };
+    if (sH > 0) TRY(project_rows(H));                                                            // cnmfsc.m:121-123
+    auto gemm = [&](GemmParams &g, double *obj) -> nmfx_status {
+        g.splitk = 1;
+        if (!obj) { g.epi = EPI_STORE; return gemm_auto(st, g, scratch.p, sb); }
+        g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = V.as<float>(); g.ldv = m; g.cost_partials = part.as<double>();
+        long blocks = 0;
+        TRY(launch_gemm(st, g, &blocks));
+        return read_obj(st, part.as<double>(), (int)blocks, costd.as<double>(), obj);
+    };
+    // V_hat = RFD(Wx (m x K x T), Hx) and 0.5*||V - V_hat||^2
+    auto rfd = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = m; g.N = n; g.Kc = KT;
+        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{Hx, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = Vh.as<float>(); g.ldc = m;
+        return gemm(g, obj);
+    };
+    // out (K x n) = sum_t Wx_t' * lshift_t(X)
+    auto hgrad = [&](const float *Wx, const float *X, float *out) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = K; g.N = n; g.Kc = (long)T * m;
+        g.A = OpView{Wx, nullptr, m, VIEW_WSTACK_KC, (int)m, m * (long)K, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{X, nullptr, m, VIEW_XSHIFT_KC, (int)m, 0, (int)n, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = out; g.ldc = K;
+        return gemm(g, nullptr);
+    };
+    // out (m x K) = X * rshift_t(H)'
+    auto xht = [&](const float *X, const float *Hx, int t, float *out) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = m; g.N = K; g.Kc = n;
+        g.A = OpView{X, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{Hx, nullptr, (long)K, VIEW_HSTACK_RC, K, 0, t * K, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = out; g.ldc = m;
+        return gemm(g, nullptr);
+    };
+
+    double stepH = 1.0;
+    std::vector<double> stepW(T, 1.0);                                                           // cnmfsc.m:147-148
+    TRY(rfd(W, H, &r->cost[0]));                                                                 // cnmfsc.m:152-153
+    int ncost = p->maxiter + 1, nH = 0, nW = 0;
+    bool early = false;
+    double *nrm2 = costd.as<double>() + 8;
+    for (int it = 1; it <= p->maxiter && !early; ++it) {
+        if (!fixH) {
+            TRY(hgrad(W0, V.as<float>(), G1.as<float>()));                                       // cnmfsc.m:160-165
+            TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));
+            if (sH > 0) {
+                TRY(axpy_f32(st, (long)Kn, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dH = pos - neg      cnmfsc.m:168
+                const double begobj = r->cost[it - 1];
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G2.as<float>(), H, Hnew));           // cnmfsc.m:174
+                    TRY(project_rows(Hnew));                                                         // cnmfsc.m:175-177
+                    double newobj;
+                    TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181
+                    if (newobj <= begobj) break;
+                    stepH /= 2;
+                    if (stepH < 1e-200) { early = true; break; }                                     // cnmfsc.m:190-194
+                }
+                if (r->tries_H) r->tries_H[nH] = tries;
+                ++nH;
+                if (early) { ncost = it; break; }
+                stepH *= 1.2;
+                std::swap(H, Hnew);
+            } else {
+                TRY(mu_plus_eps(st, H, G1.as<float>(), G2.as<float>(), (long)Kn));                   // H .* (neg ./ (pos + eps))   cnmfsc.m:202
+                TRY(row_reduce(st, H, K, K, n, 1, nrm2, rrs.p));                                     // cnmfsc.m:205
+                TRY(transpose_f32(st, H, K, n, HT));
+                TRY(scale_cols(st, HT, n, K, nrm2, 1, 1));                                           // cnmfsc.m:206
+                TRY(transpose_f32(st, HT, n, K, H));
+                for (int t = 0; t < T; ++t) TRY(scale_cols(st, W0 + (size_t)t * mK, m, K, nrm2, 1, 0));   // cnmfsc.m:207-209
+            }
+        }
+        if (!fixW) {
+            double begobj;
+            TRY(rfd(W0, H, &begobj));                                                            // cnmfsc.m:215
+            for (int t = 0; t < T && !early; ++t) {
+                float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
+                TRY(xht(V.as<float>(), H, t, G1.as<float>()));                                   // neg = V * Hs'
+                TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                                  // pos = V_hat * Hs'
+                if (sW > 0) {
+                    TRY(axpy_f32(st, (long)mK, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dW   cnmfsc.m:224
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        TRY(axpy_f32(st, (long)mK, (float)(-stepW[t]), G2.as<float>(), W0t, Wnew));  // cnmfsc.m:229
+                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));
+                        GemmParams g; memset(&g, 0, sizeof(g));                                      // RFD(Wnew, H) with a 2-D Wnew: plain Wnew*H  (cnmfsc.m:235)
+                        g.M = m; g.N = n; g.Kc = K;
+                        g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                        g.B = OpView{H, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                        g.C = Vh.as<float>(); g.ldc = m;
+                        TRY(gemm(g, &newobj));
+                        if (newobj <= begobj) break;
+                        stepW[t] /= 2;
+                        if (stepW[t] < 1e-200) { early = true; break; }                              // cnmfsc.m:245-249
+                    }
+                    if (r->tries_W) r->tries_W[nW] = tries;
+                    ++nW;
+                    if (early) { ncost = it; break; }
+                    stepW[t] *= 1.2;
+                    NMFX_HIP(hipMemcpyAsync(Wt, Wnew, mK * 4, hipMemcpyDeviceToDevice, st));         // W(:,:,t) = Wnew
+                    begobj = newobj;                                                                 // next t: 0.5*||V - V_hat||^2 of the V_hat left here
+                } else {
+                    NMFX_HIP(hipMemcpyAsync(Wt, W0t, mK * 4, hipMemcpyDeviceToDevice, st));
+                    TRY(mu_plain(st, Wt, G1.as<float>(), G2.as<float>(), (long)mK));                 // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
+                    TRY(axpy_f32(st, (long)mK, -1.0f, W0t, Wt, Wnew));                               // dW = W_t - W0_t
+                    GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
+                    g.M = m; g.N = n; g.Kc = K;
+                    g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                    g.B = OpView{H - (long)K * t, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, -t, NMFX_PRO_NONE, 0.f, 0.f};
+                    g.C = Vh.as<float>(); g.ldc = m; g.accumulate = 1; g.clamp0 = 1; g.epi = EPI_STORE; g.splitk = 1;
+                    TRY(launch_gemm(st, g));
+                }
+            }
+            if (early) break;
+        }
+        NMFX_HIP(hipMemcpyAsync(W0, W, mKT * 4, hipMemcpyDeviceToDevice, st));                   // W0 = W   cnmfsc.m:266
+        TRY(rfd(W0, H, &r->cost[it]));                                                           // cnmfsc.m:269-270
+        if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // cnmfsc.m:273-276
+            ncost = it + 1;
+            break;
+        }
+    }
+    r->cost_len = ncost;
+    r->iters_run = ncost - 1;
+    r->stepsize_H = stepH; r->stepsize_W = stepW[0];
+    r->converged_early = early ? 1 : 0;
+    if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+    if (r->tries_W) for (int i = nW; i < p->maxiter * T; ++i) r->tries_W[i] = 0;
+    TRY(download(st, W, p->dtype, r->W, mKT, stage, STAGE_ELEMS));
+    TRY(download(st, H, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    return NMFX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1197,6 +1374,7 @@ extern "C" {
 nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 0); }
 nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 1); }
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
+nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
 
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W, const void *H, void *V_hat,
                              int32_t device) {

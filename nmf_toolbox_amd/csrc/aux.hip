@@ -308,6 +308,18 @@ nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *po
     return NMFX_OK;
 }
 
+// X <- X .* (neg ./ (pos + eps))     cnmfsc.m:202 (plus, not max)
+__global__ void mu_plus_eps_kernel(float *X, const float *neg, const float *pos, long count) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) X[idx] = X[idx] * (neg[idx] / (pos[idx] + NMFX_EPS_F));
+}
+nmfx_status mu_plus_eps(hipStream_t st, float *X, const float *neg, const float *pos, long count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(mu_plus_eps_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, X, neg, pos, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // column scaling by s[c] or 1/s[c] (nmfsc.m:185-187)
 __global__ void scale_cols_kernel(float *X, long rows, long count, const double *s, int use_sqrt, int divide) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -26,7 +26,7 @@ constexpr int NTHREADS = 256;
 __device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g) {
     switch (v.mode) {
     case VIEW_RC: off = r; g = 0; break;
-    case VIEW_HSTACK_RC: { int t = r / v.blk; int k = r - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
+    case VIEW_HSTACK_RC: { int rr = r + v.lim; int t = rr / v.blk; int k = rr - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
     case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim; break;
     case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
     default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
                         if (p.store_c) C[i + p.ldc * j] = s;
                     } else {
                         if (p.accumulate) s += C[i + p.ldc * j];
+                        if (p.clamp0) s = fmaxf(s, 0.0f);   // cnmfsc.m:262  V_hat = max(V_hat + dW*Hs, 0)
                         C[i + p.ldc * j] = s;
                     }
                 }

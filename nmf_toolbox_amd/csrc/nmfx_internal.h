@@ -39,7 +39,7 @@ struct OpView {
     int mode;         // ViewMode
     int blk;          // length of the inner index of a stacked (t, inner) index
     long tstride;     // VIEW_WSTACK_KC: m*K;  VIEW_HSTACK_KC: if > 0, rows r >= tstride read as zero
-    int lim;          // VIEW_XSHIFT_KC: n;  VIEW_HSTACK_KC: extra column shift g (element valid iff r + g >= t)
+    int lim;          // VIEW_XSHIFT_KC: n;  VIEW_HSTACK_RC: row offset (select stacked block t: lim = t*blk);  VIEW_HSTACK_KC: extra column shift g (element valid iff r + g >= t)
     int func;         // nmfx_prologue
     float e1, e2;     // NMFX_PRO_POWPROD exponents (MATLAB .^ semantics: x.^0 == 1, x.^1 == x)
 };
@@ -55,6 +55,7 @@ struct GemmParams {
     float *C;
     long ldc;
     int accumulate;      // C += acc
+    int clamp0;          // EPI_STORE: C = max(C, 0) after the accumulate
     int store_c;         // EPI_COST: also store acc to C
     int epi;             // EpiMode
     int cost_div;        // nmfx_divergence for EPI_COST
@@ -134,6 +135,7 @@ nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
 nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
 nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
+nmfx_status mu_plus_eps(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ (pos + eps))
 nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out);    // out (cols x rows)
 nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec);
 nmfx_status sum_over_t(hipStream_t st, const double *colsum, int K, int T, double *out);

@@ -261,6 +261,61 @@ def nmfsc(V, num_basis_elems, config=None, device=0, info=None):
     return np.array(Wout), np.array(Hout), cost[: r.cost_len].copy()
 
 
+def cnmfsc(V, num_basis_elems, context_len, config=None, device=0, info=None):
+    """[W, H, cost] = cnmfsc(V, num_basis_elems, context_len, config)  -- cnmfsc.m:1."""
+    V = np.asarray(V, dtype=np.float64)
+    if V.ndim != 2:
+        raise ValueError("V must be a matrix")
+    if V.min() < 0:                                                # cnmfsc.m:67-69
+        raise ValueError("Negative values in data!")
+    m, n = V.shape
+    K, T = int(num_basis_elems), int(context_len)
+    cfg = dict(config) if config else {}
+    rng = _rng(cfg)
+    if _isempty(cfg.get("W_init", None)):                          # cnmfsc.m:83-85
+        cfg["W_init"] = rng.rand(m, K, T)
+    if _isempty(cfg.get("H_init", None)):                          # cnmfsc.m:88-91
+        h = rng.rand(K, n)
+        cfg["H_init"] = (1.0 / np.sqrt(np.sum(h ** 2, axis=1)))[:, None] * h
+    W0 = np.asfortranarray(np.asarray(cfg["W_init"], dtype=np.float64).reshape(m, K, -1))
+    H0 = np.asfortranarray(cfg["H_init"], dtype=np.float64)
+    if W0.shape != (m, K, T) or H0.shape != (K, n):
+        raise ValueError("W_init must be %d-by-%d-by-%d and H_init %d-by-%d" % (m, K, T, K, n))
+    sW = 0.0 if _isempty(cfg.get("W_sparsity", None)) else float(cfg["W_sparsity"])
+    sH = 0.0 if _isempty(cfg.get("H_sparsity", None)) else float(cfg["H_sparsity"])
+    fixW = False if _isempty(cfg.get("W_fixed", None)) else bool(cfg["W_fixed"])
+    fixH = False if _isempty(cfg.get("H_fixed", None)) else bool(cfg["H_fixed"])
+    maxiter = cfg.get("maxiter", None)
+    maxiter = 100 if (maxiter is None or maxiter <= 0) else int(maxiter)              # cnmfsc.m:137-139
+    tol = cfg.get("tolerance", None)
+    tol = 1e-3 if (tol is None or tol <= 0) else float(tol)                           # cnmfsc.m:142-144
+    Vf = np.asfortranarray(V)
+    Wout = np.zeros((m, K, T), order="F")
+    Hout = np.zeros((K, n), order="F")
+    cost = np.zeros(maxiter + 1)
+    tH = np.zeros(maxiter, dtype=np.int32)
+    tW = np.zeros(maxiter * T, dtype=np.int32)
+    fw = np.asarray([fixW], dtype=np.uint8)
+    fh = np.asarray([fixH], dtype=np.uint8)
+    p = _lib.Problem()
+    p.m, p.n, p.K_total, p.T, p.dtype = m, n, K, T, _lib.F64
+    p.V, p.W_init, p.H_init = _fptr(Vf), _fptr(W0), _fptr(H0)
+    p.num_sources = 1
+    p.W_fixed, p.H_fixed = _fptr(fw), _fptr(fh)
+    p.maxiter, p.tolerance, p.device = maxiter, (-1.0 if cfg.get("nmfx_disable_stop", False) else tol), int(device)
+    p.sc_W_sparsity, p.sc_H_sparsity = sW, sH
+    r = _lib.Result()
+    r.W, r.H, r.cost, r.tries_H, r.tries_W = _fptr(Wout), _fptr(Hout), _fptr(cost), _fptr(tH), _fptr(tW)
+    _lib.check(_lib.load().nmfx_cnmfsc(C.byref(p), C.byref(r)))
+    if r.converged_early:
+        print("Algorithm converged")                               # cnmfsc.m:191 display(...)
+    if info is not None:
+        info.update(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0], stepsizeH=r.stepsize_H,
+                    converged_early=bool(r.converged_early))
+    Wr = np.array(Wout)
+    return (Wr[:, :, 0] if T == 1 else Wr), np.array(Hout), cost[: r.cost_len].copy()
+
+
 def ReconstructFromDecomposition(W, H, device=0):
     """V_hat = ReconstructFromDecomposition(W, H)  -- ReconstructFromDecomposition.m:1."""
     if _is_cell(W):                                                # RFD.m:23-25

@@ -567,3 +567,143 @@ def nmfsc(V, num_basis_elems, config=None, rng=None, info=None):
             n_cost = it + 1
             break
     return _finish(n_cost)
+
+
+# --------------------------------------------------------------------------------------
+# cnmfsc.m:67-277.  Mirrors the reference's quirks:
+#   * the initial projection changes W but NOT W0 (cnmfsc.m:94-112); the H step runs on W0
+#   * the MU H-step divides by (positive_grad + eps), not max(., eps) (cnmfsc.m:206)
+#   * in the sparse W branch the line search evaluates ReconstructFromDecomposition(Wnew, H) with the 2-D slice Wnew,
+#     i.e. the plain product Wnew*H without shifts (cnmfsc.m:238), and V_hat stays that product for the next t
+# --------------------------------------------------------------------------------------
+def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
+    V = np.asarray(V, dtype=np.float64)
+    if V.min() < 0:                                       # cnmfsc.m:67-69
+        raise ValueError("Negative values in data!")
+    V = V / V.max()                                       # cnmfsc.m:72
+    m, n = V.shape
+    K, T = int(num_basis_elems), int(context_len)
+    cfg = dict(config) if config is not None else {}
+    rng = rng if rng is not None else np.random.RandomState(0)
+    if cfg.get("W_init", None) is None or np.size(cfg["W_init"]) == 0:        # cnmfsc.m:83-85
+        cfg["W_init"] = rng.rand(m, K, T)
+    if cfg.get("H_init", None) is None or np.size(cfg["H_init"]) == 0:        # cnmfsc.m:88-91
+        h = rng.rand(K, n)
+        cfg["H_init"] = (1.0 / np.sqrt(np.sum(h ** 2, axis=1)))[:, None] * h
+    W0 = np.array(cfg["W_init"], dtype=np.float64).reshape(m, K, T)           # cnmfsc.m:93
+    W = W0.copy()                                                             # cnmfsc.m:94
+    H = np.array(cfg["H_init"], dtype=np.float64)
+    rfd3 = lambda Wx, Hx: reconstruct_from_decomposition(Wx[:, :, 0] if Wx.shape[2] == 1 else Wx, Hx)
+    L1a = L1s = None
+    sW = cfg.get("W_sparsity", None)
+    if sW is None or np.size(sW) == 0:                    # cnmfsc.m:98-111
+        sW = 0.0
+    elif sW > 0:
+        sW = min(float(sW), 1.0)
+        L1a = np.sqrt(m) - (np.sqrt(m) - 1) * sW
+        for t in range(T):
+            for k in range(K):
+                W[:, k, t] = projfunc(W[:, k, t], L1a, 1.0, True)[0]
+    sH = cfg.get("H_sparsity", None)
+    if sH is None or np.size(sH) == 0:                    # cnmfsc.m:114-124
+        sH = 0.0
+    elif sH > 0:
+        sH = min(float(sH), 1.0)
+        L1s = np.sqrt(n) - (np.sqrt(n) - 1) * sH
+        for k in range(K):
+            H[k, :] = projfunc(H[k, :], L1s, 1.0, True)[0]
+    W_fixed = bool(cfg.get("W_fixed", False) or False)
+    H_fixed = bool(cfg.get("H_fixed", False) or False)
+    maxiter = cfg.get("maxiter", None)
+    maxiter = 100 if (maxiter is None or maxiter <= 0) else int(maxiter)      # cnmfsc.m:137-139
+    tol = cfg.get("tolerance", None)
+    tol = 1e-3 if (tol is None or tol <= 0) else float(tol)                   # cnmfsc.m:142-144
+    stepsizeW = np.ones(T)                                # cnmfsc.m:147
+    stepsizeH = 1.0
+    cost = np.zeros(maxiter + 1)
+    V_hat = rfd3(W, H)                                    # cnmfsc.m:152
+    cost[0] = 0.5 * np.sum((V - V_hat) ** 2)
+    triesH, triesW = [], []
+
+    def _finish(ncost):
+        if info is not None:
+            info.update(triesH=triesH, triesW=triesW, stepsizeH=stepsizeH, stepsizeW=stepsizeW.copy())
+        Wout = W[:, :, 0] if T == 1 else W
+        return Wout, H, cost[:ncost]
+
+    n_cost = maxiter + 1
+    for it in range(1, maxiter + 1):                      # cnmfsc.m:155
+        if not H_fixed:                                   # cnmfsc.m:157
+            neg = np.zeros((K, n))
+            pos = np.zeros((K, n))
+            for t in range(1, T + 1):                     # cnmfsc.m:160-165
+                neg = neg + W0[:, :, t - 1].T @ _lshift(V, t, n)
+                pos = pos + W0[:, :, t - 1].T @ _lshift(V_hat, t, n)
+            if sH > 0:
+                dH = pos - neg                            # cnmfsc.m:168
+                begobj = cost[it - 1]
+                tries = 0
+                while True:
+                    tries += 1
+                    Hnew = H - stepsizeH * dH             # cnmfsc.m:174
+                    for k in range(K):
+                        Hnew[k, :] = projfunc(Hnew[k, :], L1s, 1.0, True)[0]
+                    V_hat = rfd3(W0, Hnew)                # cnmfsc.m:180
+                    newobj = 0.5 * np.sum((V - V_hat) ** 2)
+                    if newobj <= begobj:                  # cnmfsc.m:184
+                        break
+                    stepsizeH = stepsizeH / 2
+                    if stepsizeH < 1e-200:                # cnmfsc.m:190-194
+                        triesH.append(tries)
+                        return _finish(it)
+                triesH.append(tries)
+                stepsizeH = 1.2 * stepsizeH               # cnmfsc.m:198
+                H = Hnew
+            else:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    H = H * (neg / (pos + EPS))           # cnmfsc.m:202
+                norms = np.sqrt(np.sum(H ** 2, axis=1))   # cnmfsc.m:205
+                H = (1.0 / norms)[:, None] * H
+                for t in range(T):                        # cnmfsc.m:207-209
+                    W0[:, :, t] = W0[:, :, t] * norms[None, :]
+        if not W_fixed:                                   # cnmfsc.m:214
+            V_hat = rfd3(W0, H)                           # cnmfsc.m:215
+            if sW > 0:
+                for t in range(1, T + 1):
+                    begobj = 0.5 * np.sum((V - V_hat) ** 2)               # cnmfsc.m:218
+                    Hsh = _rshift(H, t, n)                # cnmfsc.m:221
+                    neg = V @ Hsh.T
+                    pos = V_hat @ Hsh.T
+                    dW = pos - neg                        # cnmfsc.m:224
+                    tries = 0
+                    while True:
+                        tries += 1
+                        Wnew = W0[:, :, t - 1] - stepsizeW[t - 1] * dW    # cnmfsc.m:229
+                        for k in range(K):
+                            Wnew[:, k] = projfunc(Wnew[:, k], L1a, 1.0, True)[0]
+                        V_hat = reconstruct_from_decomposition(Wnew, H)   # cnmfsc.m:235: 2-D slice => plain Wnew*H
+                        newobj = 0.5 * np.sum((V - V_hat) ** 2)
+                        if newobj <= begobj:
+                            break
+                        stepsizeW[t - 1] = stepsizeW[t - 1] / 2
+                        if stepsizeW[t - 1] < 1e-200:     # cnmfsc.m:245-249
+                            triesW.append(tries)
+                            return _finish(it)
+                    triesW.append(tries)
+                    stepsizeW[t - 1] = 1.2 * stepsizeW[t - 1]             # cnmfsc.m:252
+                    W[:, :, t - 1] = Wnew
+            else:
+                for t in range(1, T + 1):                 # cnmfsc.m:257-263
+                    Hsh = _rshift(H, t, n)
+                    neg = V @ Hsh.T
+                    pos = V_hat @ Hsh.T
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        W[:, :, t - 1] = W0[:, :, t - 1] * (neg / np.fmax(pos, EPS))
+                    V_hat = np.fmax(V_hat + (W[:, :, t - 1] - W0[:, :, t - 1]) @ Hsh, 0.0)
+        W0 = W.copy()                                     # cnmfsc.m:266 (value semantics)
+        V_hat = rfd3(W0, H)                               # cnmfsc.m:269
+        cost[it] = 0.5 * np.sum((V - V_hat) ** 2)
+        if it > 1 and cost[it] < cost[it - 1] and cost[it - 1] - cost[it] < tol:   # cnmfsc.m:273-276
+            n_cost = it + 1
+            break
+    return _finish(n_cost)

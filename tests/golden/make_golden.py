@@ -65,6 +65,17 @@ def main():
         W, H, cost = O.nmfsc(3.0 * Vs, 8, cfg, info=info)
         save("nmfsc_small_" + tag, W=W, H=H, cost=cost, triesH=np.array(info["triesH"], dtype=np.int32), triesW=np.array(info["triesW"], dtype=np.int32),
              steps=np.array([info["stepsizeH"], info["stepsizeW"]]), sparsity=np.array([sW, sH]))
+    Vq, Wq0, Hq0 = synth(48, 120, 5, T=3)
+    for tag, sW, sH in (("mu", 0.0, 0.0), ("h", 0.0, 0.5), ("w", 0.3, 0.0)):
+        info = {}
+        cfg = dict(W_init=Wq0, H_init=Hq0, maxiter=10, tolerance=1e-12)
+        if sW:
+            cfg["W_sparsity"] = sW
+        if sH:
+            cfg["H_sparsity"] = sH
+        W, H, cost = O.cnmfsc(2.0 * Vq, 5, 3, cfg, info=info)
+        save("cnmfsc_small_" + tag, W=W, H=H, cost=cost, triesH=np.array(info["triesH"], dtype=np.int32), triesW=np.array(info["triesW"], dtype=np.int32),
+             sparsity=np.array([sW, sH]))
     rs = np.random.RandomState(7)
     S = np.abs(rs.randn(6, 200))
     k1 = np.sqrt(200) - (np.sqrt(200) - 1) * 0.6

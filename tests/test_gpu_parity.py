@@ -206,3 +206,21 @@ def test_cnmf_gram_form_matches_materialised_and_oracle(gpu_lib, div, m, n, K, T
     _check(gram, ref)
     _check(mat, ref)
     _check(gram, mat)
+
+
+# ---- cnmfsc: convolutive NMF with Hoyer sparseness, reference quirks included ---------------------
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.0), (0.0, 0.5), (0.3, 0.0), (0.4, 0.6)])
+@pytest.mark.parametrize("m,n,K,T", [(96, 200, 6, 4), (128, 256, 8, 1)])
+def test_cnmfsc_matches_oracle(gpu_lib, sW, sH, m, n, K, T):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=12, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1 = {}, {}
+    ref = O.cnmfsc(2.0 * V, K, T, cfg, info=i0)
+    got = gpu_lib.cnmfsc(2.0 * V, K, T, cfg, info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]      # incl. the 665-try step-size underflow of the sparse-W branch
+    _check(got, ref)

@@ -111,6 +111,27 @@ def test_nmfsc_golden(tag):
         assert np.allclose(sp, sH, atol=1e-10)
 
 
+@pytest.mark.parametrize("tag", ["mu", "h", "w"])
+def test_cnmfsc_golden(tag):
+    """cnmfsc.m restatement (numpy only: the plain-C cross-check does not cover this 'next' row yet)."""
+    g = load("cnmfsc_small_" + tag)
+    V, W0, H0 = synth(48, 120, 5, T=3)
+    sW, sH = g["sparsity"]
+    cfg = dict(W_init=W0, H_init=H0, maxiter=10, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    info = {}
+    W, H, cost = O.cnmfsc(2.0 * V, 5, 3, cfg, info=info)
+    assert rel_fro(W, g["W"]) < 1e-11 and rel_fro(H, g["H"]) < 1e-11 and rel_fro(cost, g["cost"]) < 1e-12
+    assert info["triesH"] == list(g["triesH"]) and info["triesW"] == list(g["triesW"])
+    if tag == "w":      # the reference's sparse-W line search compares against a shift-less product: it gives up by step-size underflow
+        assert max(info["triesW"]) > 600 and len(cost) <= 3
+    if tag == "mu":
+        assert np.all(np.diff(cost[1:]) <= 1e-9 * cost[1])
+
+
 def test_projfunc_golden():
     g = load("projfunc")
     for s, v0, it0 in zip(g["S"], g["V"], g["iters"]):
