@@ -98,6 +98,9 @@ typedef struct {
 nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = cnmf(V, num_basis_elems, context_len, config) -- replaces cnmf.m:1 (hot loop cnmf.m:175-258) */
 nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r);
+/* [W,H,cost] = lnmf(V, num_basis_elems, config)           -- replaces lnmf.m:1 (loop lnmf.m:66-88).
+ * divergence must be NMFX_DIV_KL, one source; cost keeps maxiter entries (the reference does not trim on break). */
+nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = nmfsc(V, num_basis_elems, config)          -- replaces nmfsc.m:1 (hot loop nmfsc.m:141-245) */
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = cnmfsc(V, num_basis_elems, context_len, config) -- replaces cnmfsc.m:1 (hot loop cnmfsc.m:155-277).
@@ -135,7 +138,8 @@ typedef struct {
     void *stream;             /* hipStream_t of the caller (NULL = default stream) */
     int64_t col_offset;       /* global index of the first local column (cnmf halo logic; 0 on 1 GPU) */
     int32_t path;             /* 0 = auto; 1 = force generic (materialised V_hat) path; 2 = force fused path */
-    int32_t algorithm;        /* 0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
+    int32_t algorithm;        /* 2 = lnmf rules (lnmf.m:59,69-70,76: L1 columns, plain ratio, sqrt H update);
+                                 0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
                                  (cnmf.m:157-166,196-199: slab Frobenius norm T, H rescaled at init only) */
 } nmfx_engine_desc;
 

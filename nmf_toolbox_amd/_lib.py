@@ -17,7 +17,7 @@ F32, F64 = 0, 1
 
 # every symbol include/nmfx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "nmfx_nmf", "nmfx_cnmf", "nmfx_nmfsc", "nmfx_cnmfsc", "nmfx_reconstruct", "nmfx_projfunc", "nmfx_last_error",
+    "nmfx_nmf", "nmfx_cnmf", "nmfx_lnmf", "nmfx_nmfsc", "nmfx_cnmfsc", "nmfx_reconstruct", "nmfx_projfunc", "nmfx_last_error",
     "nmfx_device_count", "nmfx_version", "nmfx_engine_workspace_bytes", "nmfx_engine_packed_count",
     "nmfx_engine_create", "nmfx_engine_destroy", "nmfx_engine_init", "nmfx_engine_wstep_partial",
     "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
@@ -83,7 +83,7 @@ def load():
     lib.nmfx_engine_profile_tag_name.argtypes = [C.c_int32]
     lib.nmfx_engine_destroy.restype = None
     lib.nmfx_engine_destroy.argtypes = [C.c_void_p]
-    for name in ("nmfx_nmf", "nmfx_cnmf", "nmfx_nmfsc", "nmfx_cnmfsc"):
+    for name in ("nmfx_nmf", "nmfx_cnmf", "nmfx_lnmf", "nmfx_nmfsc", "nmfx_cnmfsc"):
         getattr(lib, name).argtypes = [C.POINTER(Problem), C.POINTER(Result)]
     lib.nmfx_reconstruct.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_projfunc.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]

@@ -235,12 +235,16 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->algo = d->algorithm;
     e->alpha = d->divergence == NMFX_DIV_AB ? d->alpha : 1.0;
     e->beta = d->divergence == NMFX_DIV_AB ? d->beta : 1.0;
-    if (e->algo == 0 && e->T != 1) {
-        set_error("nmfx_engine: algorithm nmf requires T == 1");
+    if (e->algo != 1 && e->T != 1) {
+        set_error("nmfx_engine: algorithms nmf / lnmf require T == 1");
+        return NMFX_ERR_INVALID;
+    }
+    if (e->algo == 2 && e->div != NMFX_DIV_KL) {
+        set_error("nmfx_engine: lnmf is defined for the KL divergence only (lnmf.m:69,76,81)");
         return NMFX_ERR_INVALID;
     }
     // fused path eligibility: nmf rules, KL or euclidean, K in {64,128,256}, tileable shard
-    const bool eligible = e->algo == 0 && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
+    const bool eligible = (e->algo == 0 || e->algo == 2) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
                           e->m % 128 == 0 && e->n % 128 == 0;
     if (d->path == 2 && !eligible) {
         set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K in {64,128,256}, m %% 128 == 0, n %% 128 == 0)");
@@ -475,8 +479,8 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     {
         Scope s(e, TAG_SMALL);
-        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 1, e->sumsq));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo == 1, e->f_out));
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo, e->f_out));
         if (e->algo == 1) TRY(scale_rows(e->st, e->H, e->K, e->n, e->f_out));
         if (e->fused) {
             e->cost_valid = false;
@@ -548,8 +552,9 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             p.P = e->Pbuf;
         }
         Scope s(e, TAG_SMALL);
+        p.rule = e->algo == 2 ? 1 : 0;
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, 0, nullptr));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, e->algo, nullptr));
         e->cost_valid = false;
         return refresh_w_derived(e);
     }
@@ -568,8 +573,9 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
             p.Pvec = e->Pvec;
         }
+        p.rule = e->algo == 2 ? 1 : 0;
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, e->algo == 1, nullptr));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, e->algo, nullptr));
     }
     if (e->gram) return NMFX_OK;
     return recon(e, false);
@@ -596,6 +602,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         const bool kl = e->div == NMFX_DIV_KL;
         if (e->isplit_h == 1) {
             f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
+            f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
             TRY(launch_fused(e->st, f, 1, false, func, true, 1));
         } else {
@@ -606,7 +613,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             }
             Scope s(e, TAG_SMALL);
             TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
-            TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+            TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
         }
         e->cost_valid = false;
         return NMFX_OK;
@@ -638,7 +645,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
             TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
         }
-        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
+        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
     }
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
@@ -813,7 +820,7 @@ nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool n
 
 nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     TRY(validate_problem(p, r, false));
-    if (algorithm == 0 && p->T != 1) { set_error("nmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm != 1 && p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     TRY(check_device(p->device));
     const int K = p->K_total, S = p->num_sources;
@@ -856,7 +863,11 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         return NMFX_OK;
     };
     // nmf.m:221-224 / cnmf.m:254-257
-    auto stop = [&](int idx) { return p->tolerance >= 0 && idx > 0 && r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance; };
+    auto stop = [&](int idx) {
+        if (p->tolerance < 0 || idx == 0) return false;
+        if (algorithm == 2) return r->cost[idx] <= r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] <= p->tolerance;   // lnmf.m:84
+        return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;
+    };
     bool stopped = false;
     for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
         if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
@@ -878,6 +889,10 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         if (s == NMFX_OK) s = read_cost(p->maxiter - 1);
     }
     r->cost_len = r->iters_run;
+    if (algorithm == 2) {   // lnmf.m:84-86 breaks WITHOUT trimming: the cost vector keeps its maxiter length, zero after the stop
+        for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
+        r->cost_len = p->maxiter;
+    }
     if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKT, stage, STAGE_ELEMS);
     if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
     nmfx_engine_destroy(e);
@@ -1373,6 +1388,7 @@ extern "C" {
 
 nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 0); }
 nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 1); }
+nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 2); }
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
 nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
 

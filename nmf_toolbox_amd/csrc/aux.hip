@@ -133,9 +133,10 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     double dn = 0.0, dp = 0.0;
     const float lam = p.lamW ? p.lamW[k] : 0.0f;
     const bool vec = (p.m & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(nn) | reinterpret_cast<uintptr_t>(pp)) & 15) == 0;
+    const bool plain = p.rule == 1;   // lnmf.m:69: W .* (N ./ max(P, eps)), no diagonal terms; the column statistic is the L1 sum
     auto upd = [&](float wi, float ni, float pi, float fdn, float fdp) {
-        float neg = fmaf(wi, fdn, ni);
-        float pos = fmaf(wi, fdp, pi);
+        float neg = plain ? ni : fmaf(wi, fdn, ni);
+        float pos = plain ? pi : fmaf(wi, fdp, pi);
         if (p.inv_exp != 1.0f) { neg = powf(neg, p.inv_exp); pos = powf(pos, p.inv_exp); }
         return wi * (neg / fmaxf(pos + lam, NMFX_EPS_F));
     };
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
             o.x = upd(a.x, b.x, c4.x, fdn, fdp); o.y = upd(a.y, b.y, c4.y, fdn, fdp);
             o.z = upd(a.z, b.z, c4.z, fdn, fdp); o.w = upd(a.w, b.w, c4.w, fdn, fdp);
             w4[i] = o;
-            ss += ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+            ss += plain ? ((double)o.x + o.y) + ((double)o.z + o.w) : ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
         }
     } else {
         for (long i = threadIdx.x; i < p.m; i += 256) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         for (long i = threadIdx.x; i < p.m; i += 256) {
             const float wn = upd(w[i], nn[i], pp ? pp[i] : pv, fdn, fdp);
             w[i] = wn;
-            ss += (double)wn * (double)wn;
+            ss += plain ? (double)wn : (double)wn * (double)wn;
         }
     }
     ss = block_sum<4>(ss, red);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
     const int c = blockIdx.x, k = c % K, t = c / K;
     if (fix && fix[k]) return;
     float *w = W + m * c;
-    if (cnmf_rule) {
+    if (cnmf_rule == 1) {
         double s = 0.0;
         for (int tt = 0; tt < T; ++tt) s += sumsq[k + K * tt];
         const double nrm = sqrt(s) / (double)T;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
         for (long i = threadIdx.x; i < m; i += 256) w[i] = w[i] / f;
         if (f_out && t == 0 && threadIdx.x == 0) f_out[k] = nrm;
     } else {
-        const float f = (float)(1.0 / sqrt(sumsq[c]));
+        const float f = (float)(cnmf_rule == 2 ? 1.0 / sumsq[c] : 1.0 / sqrt(sumsq[c]));   // rule 2: lnmf.m:70  W * diag(1 ./ sum(W,1))
         if ((m & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
             float4 *w4 = reinterpret_cast<float4 *>(w);
             for (long i = threadIdx.x; i < m / 4; i += 256) { float4 v = w4[i]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; w4[i] = v; }
@@ -239,6 +240,7 @@ __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, cons
     float pos = Gp ? Gp[idx] : (float)Gpvec[k];
     if (inv_exp != 1.0f) { neg = powf(neg, inv_exp); pos = powf(pos, inv_exp); }
     const float lam = lamH ? lamH[k] : 0.0f;
+    if (inv_exp == -2.0f) { H[idx] = sqrtf(H[idx] * Gn[idx]); return; }   // lnmf.m:76  H = sqrt(H .* (W'*(V./V_hat)))
     H[idx] = H[idx] * (neg / fmaxf(pos + lam, NMFX_EPS_F));
 }
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(const FusedParams p) {
                     const int k = 32 * kb + rowmap(reg, h);
                     if (p.fix && p.fix[k]) continue;
                     const long idx = (long)k + (long)K * r;
+                    if (p.sqrt_rule) { p.Hio[idx] = sqrtf(p.Hio[idx] * acc[kb][reg]); continue; }   // lnmf.m:76
                     const float den = p.den ? p.den[idx] : (float)p.denvec[k];
                     const float lam = p.lam ? p.lam[k] : 0.0f;
                     p.Hio[idx] = p.Hio[idx] * (acc[kb][reg] / fmaxf(den + lam, NMFX_EPS_F));

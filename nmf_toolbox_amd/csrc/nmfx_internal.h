@@ -95,6 +95,7 @@ struct FusedParams {
     const double *denvec; // EPI 1: [K]
     const float *lam;     // [K] or nullptr
     const uint8_t *fix;   // [K] or nullptr
+    int sqrt_rule;        // EPI 1: H <- sqrt(H .* G)   (lnmf.m:76) instead of the ratio update
 };
 bool fused_supported(int K);
 // func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost;  do_g2=false: cost-only pass
@@ -120,6 +121,7 @@ struct WUpdateParams {
     int K, T;
     double *sumsq;       // out [K*T]: sum of squares of the updated (un-normalised) columns
     float inv_exp;       // outer exponent 1/alpha (1 = none)
+    int rule;            // 0: nmf/cnmf (diag terms, sum of squares out); 1: lnmf (plain ratio, column sum out)
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,

@@ -103,7 +103,7 @@ class Engine:
                 setattr(d, name, arr.ctypes.data_as(C.c_void_p))
         d.device = self.V.device.index or 0
         d.stream = C.c_void_p(torch.cuda.current_stream(self.V.device).cuda_stream)
-        d.algorithm = {"nmf": 0, "cnmf": 1}[algorithm]
+        d.algorithm = {"nmf": 0, "cnmf": 1, "lnmf": 2}[algorithm]
         d.path = int(path)
         self.desc = d
         nbytes, count = C.c_size_t(0), C.c_size_t(0)

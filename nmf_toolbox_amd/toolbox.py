@@ -203,6 +203,35 @@ def cnmf(V, num_basis_elems, context_len, config=None, device=0):
     return (Wl if is_W_cell else Wl[0]), (Hl if is_H_cell else Hl[0]), cost                        # cnmf.m:261-267
 
 
+def lnmf(V, num_basis_elems, config=None, device=0):
+    """[W, H, cost] = lnmf(V, num_basis_elems, config)  -- lnmf.m:1.  `cost` has maxiter entries, zero
+    after an early stop (the reference breaks without trimming, lnmf.m:84-86)."""
+    V = np.asarray(V, dtype=np.float64)
+    if V.ndim != 2:
+        raise ValueError("V must be a matrix")
+    m, n = V.shape
+    K = int(num_basis_elems)
+    cfg = dict(config) if config else {}
+    rng = _rng(cfg)
+    if _isempty(cfg.get("H_init", None)):                          # lnmf.m:104-106
+        cfg["H_init"] = np.fmax(rng.rand(K, n), EPS)
+    if _isempty(cfg.get("W_init", None)):                          # lnmf.m:108-111
+        w = np.fmax(rng.rand(m, K), EPS)
+        cfg["W_init"] = w * (1.0 / np.sum(w, axis=0))[None, :]
+    cfg["W_fixed"] = [False if _isempty(cfg.get("W_fixed", None)) else bool(cfg["W_fixed"])]
+    cfg["H_fixed"] = [False if _isempty(cfg.get("H_fixed", None)) else bool(cfg["H_fixed"])]
+    cfg["W_sparsity"], cfg["H_sparsity"] = [0.0], [0.0]
+    if cfg.get("maxiter", None) is None or cfg["maxiter"] <= 0:      # lnmf.m:121-123
+        cfg["maxiter"] = 100
+    if cfg.get("tolerance", None) is None or cfg["tolerance"] <= 0:  # lnmf.m:125-127
+        cfg["tolerance"] = 1e-3
+    cfg["alpha"] = cfg["beta"] = 1.0
+    W0 = np.asarray(cfg["W_init"], dtype=np.float64)
+    H0 = np.asarray(cfg["H_init"], dtype=np.float64)
+    Wl, Hl, cost = _run_mu(_lib.load().nmfx_lnmf, V, [K], 1, cfg, [W0], [H0], _lib.DIV_KL, device)
+    return Wl[0][:, :, 0], Hl[0], cost
+
+
 def nmfsc(V, num_basis_elems, config=None, device=0, info=None):
     """[W, H, cost] = nmfsc(V, num_basis_elems, config)  -- nmfsc.m:1.
 

@@ -707,3 +707,45 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
             n_cost = it + 1
             break
     return _finish(n_cost)
+
+
+# --------------------------------------------------------------------------------------
+# lnmf.m:49-92.  Note the reference's details: L1 column normalisation, no diagonal
+# terms, H <- sqrt(H .* (W'*(V./V_hat))), stop rule with <= (lnmf.m:87) and a cost vector that is NOT trimmed on break.
+# --------------------------------------------------------------------------------------
+def lnmf(V, num_basis_elems, config=None, rng=None):
+    V = np.asarray(V, dtype=np.float64)
+    m, n = V.shape
+    K = int(num_basis_elems)
+    cfg = dict(config) if config is not None else {}
+    rng = rng if rng is not None else np.random.RandomState(0)
+    if cfg.get("H_init", None) is None or np.size(cfg["H_init"]) == 0:       # lnmf.m:104-106
+        cfg["H_init"] = np.fmax(rng.rand(K, n), EPS)
+    if cfg.get("W_init", None) is None or np.size(cfg["W_init"]) == 0:       # lnmf.m:108-111
+        w = np.fmax(rng.rand(m, K), EPS)
+        cfg["W_init"] = w * (1.0 / np.sum(w, axis=0))[None, :]
+    W_fixed = bool(cfg.get("W_fixed", False) or False)
+    H_fixed = bool(cfg.get("H_fixed", False) or False)
+    maxiter = cfg.get("maxiter", None)
+    maxiter = 100 if (maxiter is None or maxiter <= 0) else int(maxiter)     # lnmf.m:121-123
+    tol = cfg.get("tolerance", None)
+    tol = 1e-3 if (tol is None or tol <= 0) else float(tol)                  # lnmf.m:125-127
+    W = np.array(cfg["W_init"], dtype=np.float64)
+    W = W * (1.0 / np.sum(W, axis=0))[None, :]            # lnmf.m:59
+    H = np.array(cfg["H_init"], dtype=np.float64)
+    V_hat = W @ H                                         # lnmf.m:62
+    cost = np.zeros(maxiter)
+    ones_mn = np.ones((m, n))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for it in range(1, maxiter + 1):
+            if not W_fixed:                               # lnmf.m:68-72
+                W = W * (((V / V_hat) @ H.T) / np.fmax(ones_mn @ H.T, EPS))
+                W = W * (1.0 / np.sum(W, axis=0))[None, :]
+                V_hat = W @ H
+            if not H_fixed:                               # lnmf.m:75-78
+                H = np.sqrt(H * (W.T @ (V / V_hat)))
+                V_hat = W @ H
+            cost[it - 1] = np.sum(V * np.log(V / V_hat) - V + V_hat)          # lnmf.m:81
+            if it > 1 and cost[it - 1] <= cost[it - 2] and cost[it - 2] - cost[it - 1] <= tol:   # lnmf.m:84-86
+                break
+    return W, H, cost                                     # cost is NOT trimmed (lnmf.m:85-86 only breaks)

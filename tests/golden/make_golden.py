@@ -65,6 +65,9 @@ def main():
         W, H, cost = O.nmfsc(3.0 * Vs, 8, cfg, info=info)
         save("nmfsc_small_" + tag, W=W, H=H, cost=cost, triesH=np.array(info["triesH"], dtype=np.int32), triesW=np.array(info["triesW"], dtype=np.int32),
              steps=np.array([info["stepsizeH"], info["stepsizeW"]]), sparsity=np.array([sW, sH]))
+    Vl, Wl0, Hl0 = synth(96, 160, 8)
+    W, H, cost = O.lnmf(Vl, 8, dict(W_init=Wl0, H_init=Hl0, maxiter=30, tolerance=1e-12))
+    save("lnmf_small", W=W, H=H, cost=cost)
     Vq, Wq0, Hq0 = synth(48, 120, 5, T=3)
     for tag, sW, sH in (("mu", 0.0, 0.0), ("h", 0.0, 0.5), ("w", 0.3, 0.0)):
         info = {}

@@ -224,3 +224,25 @@ def test_cnmfsc_matches_oracle(gpu_lib, sW, sH, m, n, K, T):
     got = gpu_lib.cnmfsc(2.0 * V, K, T, cfg, info=i1)
     assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]      # incl. the 665-try step-size underflow of the sparse-W branch
     _check(got, ref)
+
+
+# ---- lnmf on the generic and the fused KL kernels ------------------------------------------------
+@pytest.mark.parametrize("m,n,K,path", [(96, 160, 8, 0), (256, 1024, 64, 2), (256, 1024, 64, 1), (128, 32768, 64, 2)])
+def test_lnmf_matches_oracle(gpu_lib, m, n, K, path):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    iters = 25 if n < 10000 else 4
+    cfg = dict(W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-12)
+    W, H, c = gpu_lib.lnmf(V, K, dict(cfg, nmfx_path=path))
+    Wr, Hr, cr = O.lnmf(V, K, cfg)
+    assert len(c) == len(cr) and rel_fro(W, Wr) < 1e-5 and rel_fro(H, Hr) < 1e-5 and rel_fro(c, cr) < 1e-6
+    assert np.allclose(W.sum(0), 1.0, atol=1e-5)                       # L1-normalised columns (lnmf.m:70)
+
+
+def test_lnmf_untrimmed_cost_and_stop(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(96, 160, 8)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=60, tolerance=1.0)
+    c = gpu_lib.lnmf(V, 8, cfg)[2]
+    cr = O.lnmf(V, 8, cfg)[2]
+    assert len(c) == 60 and abs(np.count_nonzero(c) - np.count_nonzero(cr)) <= 1 and np.count_nonzero(cr) < 60   # zeros after the stop (lnmf.m:84-86)

@@ -132,6 +132,16 @@ def test_cnmfsc_golden(tag):
         assert np.all(np.diff(cost[1:]) <= 1e-9 * cost[1])
 
 
+def test_lnmf_golden():
+    g = load("lnmf_small")
+    V, W0, H0 = synth(96, 160, 8)
+    W, H, cost = O.lnmf(V, 8, dict(W_init=W0, H_init=H0, maxiter=30, tolerance=1e-12))
+    assert rel_fro(W, g["W"]) < 1e-12 and rel_fro(H, g["H"]) < 1e-12 and rel_fro(cost, g["cost"]) < 1e-12
+    assert np.allclose(W.sum(0), 1.0, atol=1e-13) and np.all(np.diff(cost) <= 0)
+    c = O.lnmf(V, 8, dict(W_init=W0, H_init=H0, maxiter=60, tolerance=1.0))[2]
+    assert len(c) == 60 and 1 < np.count_nonzero(c) < 60 and np.all(c[np.count_nonzero(c):] == 0)   # not trimmed on break (lnmf.m:84-86)
+
+
 def test_projfunc_golden():
     g = load("projfunc")
     for s, v0, it0 in zip(g["S"], g["V"], g["iters"]):
