@@ -354,7 +354,7 @@ int gemm_pick_split(long M, long N, long Kc) {
     int split = 1;
     if (tiles < 256 && ktiles >= 8) {
         split = (int)((512 + tiles - 1) / tiles);
-        if (split > 16) split = 16;
+        if (split > 128) split = 128;   // K x K Grams over n: one output tile, all parallelism must come from the contraction
         if (split > ktiles / 4) split = (int)(ktiles / 4);
     }
     return split < 1 ? 1 : split;
