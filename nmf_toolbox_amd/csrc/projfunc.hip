@@ -115,6 +115,67 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
 }
 
+
+// Any length: the working vector lives in a global fp64 scratch row (L2-resident for realistic sizes) instead of registers.
+__global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(float *X, long len, double k1, double k2, int nn, int *usediters, double *scratch,
+                                                                  unsigned char *flags) {
+    __shared__ double red[PF_WAVES * 4];
+    float *x = X + len * blockIdx.x;
+    double *v = scratch + len * blockIdx.x;
+    unsigned char *fl = flags + len * blockIdx.x;   // bit0: in Z, bit1: was negative
+    const int tid = threadIdx.x;
+    const double N = (double)len;
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+    for (long i = tid; i < len; i += PF_THREADS) {
+        double s = (double)x[i];
+        unsigned char f = 0;
+        if (!nn) { if (s < 0) f = 2; s = fabs(s); }
+        v[i] = s; fl[i] = f; r.a += s;
+    }
+    r = block_red4(r, red);
+    const double shift0 = (k1 - r.a) / N;
+    for (long i = tid; i < len; i += PF_THREADS) v[i] += shift0;
+    double nz = 0.0;
+    int j = 0;
+    for (;;) {
+        const double mid = k1 / (N - nz);
+        r.a = r.b = r.c = r.d = 0.0;
+        for (long i = tid; i < len; i += PF_THREADS) {
+            const double vi = v[i], w = vi - ((fl[i] & 1) ? 0.0 : mid);
+            r.a += w * w; r.b += w * vi; r.c += vi * vi;
+        }
+        r = block_red4(r, red);
+        const double a = r.a, b = 2.0 * r.b, c = r.c - k2;
+        const double disc = b * b - 4.0 * a * c;
+        const double alphap = (-b + (disc > 0.0 ? sqrt(disc) : 0.0)) / (2.0 * a);
+        r.a = r.b = r.c = r.d = 0.0;
+        for (long i = tid; i < len; i += PF_THREADS) {
+            const double vi = v[i], w = vi - ((fl[i] & 1) ? 0.0 : mid);
+            const double vn = alphap * w + vi;
+            v[i] = vn;
+            if (!(vn >= 0.0)) r.a += 1.0;
+        }
+        r = block_red4(r, red);
+        if (r.a == 0.0 || j >= PF_MAX_ITERS) break;
+        ++j;
+        r.a = r.b = r.c = r.d = 0.0;
+        for (long i = tid; i < len; i += PF_THREADS) {
+            double vi = v[i];
+            unsigned char f = fl[i] & 2;
+            if (vi <= 0.0) { f |= 1; vi = 0.0; v[i] = 0.0; r.b += 1.0; }
+            fl[i] = f;
+            r.a += vi;
+        }
+        r = block_red4(r, red);
+        nz = r.b;
+        const double shift = (k1 - r.a) / (N - nz);
+        for (long i = tid; i < len; i += PF_THREADS)
+            if (!(fl[i] & 1)) v[i] += shift;
+    }
+    for (long i = tid; i < len; i += PF_THREADS) x[i] = (float)((fl[i] & 2) ? -v[i] : v[i]);
+    if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
+}
+
 nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
     if (count <= 0 || len <= 0) return NMFX_OK;
     dim3 g(count), b(PF_THREADS);
@@ -122,9 +183,16 @@ nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double 
     else if (len <= 16L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<16>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
     else if (len <= 32L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<32>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
     else if (len <= 64L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<64>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
-    else {
-        set_error("projfunc: vector length %ld exceeds the register-resident limit %d", len, 64 * PF_THREADS);
-        return NMFX_ERR_UNSUPPORTED;
+    else {   // longer than the register-resident limit: global fp64 working rows (allocated per call; this is the rare path)
+        double *scratch = nullptr;
+        unsigned char *flags = nullptr;
+        NMFX_HIP(hipMalloc(&scratch, sizeof(double) * (size_t)len * count));
+        hipError_t e2 = hipMalloc(&flags, (size_t)len * count);
+        if (e2 != hipSuccess) { (void)hipFree(scratch); set_error("projfunc: hipMalloc failed: %s", hipGetErrorString(e2)); return NMFX_ERR_NOMEM; }
+        hipLaunchKernelGGL(projfunc_long_kernel, g, b, 0, st, X, len, k1, k2, nn, usediters_dev, scratch, flags);
+        hipError_t e3 = hipStreamSynchronize(st);
+        (void)hipFree(scratch); (void)hipFree(flags);
+        if (e3 != hipSuccess) { set_error("projfunc_long: %s", hipGetErrorString(e3)); return NMFX_ERR_HIP; }
     }
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

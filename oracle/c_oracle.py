@@ -108,3 +108,31 @@ def nmfsc(V, W_init, H_init, sW=0.0, sH=0.0, fixW=False, fixH=False, maxiter=100
     info = dict(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0],
                 stepsizeH=steps[0], stepsizeW=steps[1])
     return W, H, cost[: ncost.value], info
+
+
+def lnmf(V, W_init, H_init, fixW=False, fixH=False, maxiter=100, tol=1e-3):
+    V, W, H = _f(V), _f(W_init), _f(H_init)
+    m, n = V.shape
+    K = H.shape[0]
+    cost = np.zeros(maxiter)
+    it = C.c_int(0)
+    lib().oracle_lnmf(m, n, K, _p(V), _p(W), _p(H), int(fixW), int(fixH), int(maxiter), C.c_double(tol), _p(cost), C.byref(it))
+    return W, H, cost
+
+
+def cnmfsc(V, W_init, H_init, sW=0.0, sH=0.0, fixW=False, fixH=False, maxiter=100, tol=1e-3):
+    V, H = _f(V), _f(H_init)
+    W = _f(W_init)
+    if W.ndim == 2:
+        W = W.reshape(W.shape[0], W.shape[1], 1, order="F")
+    m, n = V.shape
+    K, T = W.shape[1], W.shape[2]
+    cost = np.zeros(maxiter + 1)
+    ncost = C.c_int(0)
+    tH = np.zeros(maxiter, dtype=np.int32)
+    tW = np.zeros(maxiter * T, dtype=np.int32)
+    rc = lib().oracle_cnmfsc(m, n, K, T, _p(V), _p(W), _p(H), C.c_double(sW), C.c_double(sH), int(fixW), int(fixH), int(maxiter), C.c_double(tol),
+                             _p(cost), C.byref(ncost), _p(tH), _p(tW))
+    if rc == 1:
+        raise ValueError("Negative values in data!")
+    return W, H, cost[: ncost.value], dict(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0])

@@ -9,9 +9,9 @@
  *
  * All matrices are column-major (MATLAB order): V[i+m*j], W[i+m*k+m*K*t], H[k+K*j].
  * Reference lines followed: nmf.m:130-225, cnmf.m:137-258, nmfsc.m:57-245,
- * projfunc.m:13-65, ReconstructFromDecomposition.m:30-38.
+ * projfunc.m:13-65, ReconstructFromDecomposition.m:30-38, lnmf.m:49-92, cnmfsc.m:67-277.
  *
- * Build: make -C oracle   (-> oracle/_build/liboracle.so, loaded with ctypes by tests)
+ * Build: make -C oracle   (-> oracle/liboracle.so, loaded with ctypes by tests)
  */
 #include <math.h>
 #include <stdlib.h>
@@ -406,5 +406,152 @@ int oracle_nmfsc(int m, int n, int K, const double *Vin, double *W, double *H, d
     }
     if (steps) { steps[0] = stepH; steps[1] = stepW; }
     free(V); free(Vh); free(neg); free(pos); free(Xn);
+    return 0;
+}
+
+/* lnmf.m:49-92 (independent restatement; KL only, one source).  cost has maxiter entries and is NOT trimmed on break. */
+int oracle_lnmf(int m, int n, int K, const double *V, double *W, double *H, int fixW, int fixH, int maxiter, double tol,
+                double *cost, int *iters_run) {
+    size_t mn = (size_t)m * n;
+    double *Vh = dalloc(mn), *A = dalloc(mn), *N = dalloc((size_t)m * K), *G = dalloc((size_t)K * n);
+    for (int k = 0; k < K; ++k) { /* lnmf.m:59 */
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += W[i + (size_t)m * k];
+        for (int i = 0; i < m; ++i) W[i + (size_t)m * k] *= 1.0 / s;
+    }
+    oracle_reconstruct(m, n, K, 1, W, H, Vh);
+    for (int it = 0; it < maxiter; ++it) cost[it] = 0.0;
+    *iters_run = maxiter;
+    for (int it = 0; it < maxiter; ++it) {
+        if (!fixW) { /* lnmf.m:68-72 */
+            for (size_t e = 0; e < mn; ++e) A[e] = V[e] / Vh[e];
+            x_times_ht(m, n, K, 0, A, H, N);
+            for (int k = 0; k < K; ++k) {
+                double rs = 0.0, s = 0.0;
+                for (int j = 0; j < n; ++j) rs += H[k + (size_t)K * j]; /* ones(m,n)*H' */
+                for (int i = 0; i < m; ++i) { double *w = &W[i + (size_t)m * k]; *w = *w * (N[i + (size_t)m * k] / fmax_nan(rs, EPS)); s += *w; }
+                for (int i = 0; i < m; ++i) W[i + (size_t)m * k] *= 1.0 / s;
+            }
+            oracle_reconstruct(m, n, K, 1, W, H, Vh);
+        }
+        if (!fixH) { /* lnmf.m:75-78 */
+            for (size_t e = 0; e < mn; ++e) A[e] = V[e] / Vh[e];
+            memset(G, 0, sizeof(double) * (size_t)K * n);
+            wt_times_x_acc(m, n, K, 0, W, A, G);
+            for (size_t e = 0; e < (size_t)K * n; ++e) H[e] = sqrt(H[e] * G[e]);
+            oracle_reconstruct(m, n, K, 1, W, H, Vh);
+        }
+        cost[it] = div_cost(DIV_KL, mn, V, Vh); /* lnmf.m:81 */
+        if (it > 0 && cost[it] <= cost[it - 1] && cost[it - 1] - cost[it] <= tol) { *iters_run = it + 1; break; } /* lnmf.m:84-86 */
+    }
+    free(Vh); free(A); free(N); free(G);
+    return 0;
+}
+
+/* cnmfsc.m:67-277 (independent restatement, quirks included: see oracle/nmf_oracle.py::cnmfsc).
+ * W in/out is m x K x T; tries arrays may be NULL; triesW needs maxiter*T entries.  returns 0 ok, 1 negative data */
+int oracle_cnmfsc(int m, int n, int K, int T, const double *Vin, double *W, double *H, double sW, double sH, int fixW, int fixH,
+                  int maxiter, double tol, double *cost, int *ncost, int *triesH, int *triesW) {
+    size_t mn = (size_t)m * n, mK = (size_t)m * K, mKT = mK * T, Kn = (size_t)K * n;
+    double vmax = -INFINITY, vmin = INFINITY;
+    for (size_t e = 0; e < mn; ++e) { if (Vin[e] > vmax) vmax = Vin[e]; if (Vin[e] < vmin) vmin = Vin[e]; }
+    if (vmin < 0) return 1;
+    double *V = dalloc(mn), *Vh = dalloc(mn), *W0 = dalloc(mKT), *neg = dalloc(Kn > mK ? Kn : mK), *pos = dalloc(Kn > mK ? Kn : mK);
+    double *Xn = dalloc(Kn > mK ? Kn : mK), *stepW = dalloc(T);
+    for (size_t e = 0; e < mn; ++e) V[e] = Vin[e] / vmax;
+    memcpy(W0, W, sizeof(double) * mKT); /* W0 = W_init; W = W0 (cnmfsc.m:93-94) */
+    double L1a = 0, L1s = 0, stepH = 1.0;
+    int dummy, nH = 0, nW = 0, early = 0;
+    for (int t = 0; t < T; ++t) stepW[t] = 1.0;
+    if (sW > 0) { /* only W is projected, W0 is not (cnmfsc.m:105-109) */
+        if (sW > 1) sW = 1;
+        L1a = sqrt((double)m) - (sqrt((double)m) - 1) * sW;
+        for (int c = 0; c < K * T; ++c) oracle_projfunc(m, W + (size_t)m * c, 1, L1a, 1.0, 1, W + (size_t)m * c, 1, &dummy);
+    }
+    if (sH > 0) {
+        if (sH > 1) sH = 1;
+        L1s = sqrt((double)n) - (sqrt((double)n) - 1) * sH;
+        for (int k = 0; k < K; ++k) oracle_projfunc(n, H + k, K, L1s, 1.0, 1, H + k, K, &dummy);
+    }
+    oracle_reconstruct(m, n, K, T, W, H, Vh);
+    cost[0] = half_sq_resid(mn, V, Vh);
+    *ncost = maxiter + 1;
+    for (int it = 1; it <= maxiter && !early; ++it) {
+        if (!fixH) {
+            memset(neg, 0, sizeof(double) * Kn); memset(pos, 0, sizeof(double) * Kn);
+            for (int t = 0; t < T; ++t) { /* cnmfsc.m:160-165 */
+                wt_times_x_acc(m, n, K, t, W0 + mK * t, V, neg);
+                wt_times_x_acc(m, n, K, t, W0 + mK * t, Vh, pos);
+            }
+            if (sH > 0) {
+                double begobj = cost[it - 1];
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    for (size_t e = 0; e < Kn; ++e) Xn[e] = H[e] - stepH * (pos[e] - neg[e]);
+                    for (int k = 0; k < K; ++k) oracle_projfunc(n, Xn + k, K, L1s, 1.0, 1, Xn + k, K, &dummy);
+                    oracle_reconstruct(m, n, K, T, W0, Xn, Vh);
+                    if (half_sq_resid(mn, V, Vh) <= begobj) break;
+                    stepH /= 2;
+                    if (stepH < 1e-200) { early = 1; break; }
+                }
+                if (triesH) triesH[nH] = tries;
+                ++nH;
+                if (early) { *ncost = it; break; }
+                stepH *= 1.2;
+                memcpy(H, Xn, sizeof(double) * Kn);
+            } else {
+                for (size_t e = 0; e < Kn; ++e) H[e] = H[e] * (neg[e] / (pos[e] + EPS)); /* cnmfsc.m:202 */
+                for (int k = 0; k < K; ++k) {
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s += H[k + (size_t)K * j] * H[k + (size_t)K * j];
+                    s = sqrt(s);
+                    for (int j = 0; j < n; ++j) H[k + (size_t)K * j] *= 1.0 / s;
+                    for (int t = 0; t < T; ++t)
+                        for (int i = 0; i < m; ++i) W0[i + (size_t)m * k + mK * t] *= s; /* cnmfsc.m:207-209 */
+                }
+            }
+        }
+        if (!fixW) {
+            oracle_reconstruct(m, n, K, T, W0, H, Vh); /* cnmfsc.m:215 */
+            for (int t = 0; t < T && !early; ++t) {
+                double *W0t = W0 + mK * t, *Wt = W + mK * t;
+                x_times_ht(m, n, K, t, V, H, neg);
+                x_times_ht(m, n, K, t, Vh, H, pos);
+                if (sW > 0) {
+                    double begobj = half_sq_resid(mn, V, Vh);
+                    int tries = 0;
+                    for (;;) {
+                        ++tries;
+                        for (size_t e = 0; e < mK; ++e) Xn[e] = W0t[e] - stepW[t] * (pos[e] - neg[e]);
+                        for (int k = 0; k < K; ++k) oracle_projfunc(m, Xn + (size_t)m * k, 1, L1a, 1.0, 1, Xn + (size_t)m * k, 1, &dummy);
+                        oracle_reconstruct(m, n, K, 1, Xn, H, Vh); /* 2-D slice: plain Wnew*H (cnmfsc.m:235) */
+                        if (half_sq_resid(mn, V, Vh) <= begobj) break;
+                        stepW[t] /= 2;
+                        if (stepW[t] < 1e-200) { early = 1; break; }
+                    }
+                    if (triesW) triesW[nW] = tries;
+                    ++nW;
+                    if (early) { *ncost = it; break; }
+                    stepW[t] *= 1.2;
+                    memcpy(Wt, Xn, sizeof(double) * mK);
+                } else {
+                    for (size_t e = 0; e < mK; ++e) { Wt[e] = W0t[e] * (neg[e] / fmax_nan(pos[e], EPS)); Xn[e] = Wt[e] - W0t[e]; }
+                    for (int j = t; j < n; ++j) /* V_hat = max(V_hat + dW*rshift_t(H), 0)  (cnmfsc.m:262) */
+                        for (int k = 0; k < K; ++k) {
+                            double h = H[k + (size_t)K * (j - t)];
+                            for (int i = 0; i < m; ++i) Vh[i + (size_t)m * j] += Xn[i + (size_t)m * k] * h;
+                        }
+                    for (size_t e = 0; e < mn; ++e) if (!(Vh[e] > 0.0)) Vh[e] = 0.0;
+                }
+            }
+            if (early) break;
+        }
+        memcpy(W0, W, sizeof(double) * mKT); /* cnmfsc.m:266 */
+        oracle_reconstruct(m, n, K, T, W0, H, Vh);
+        cost[it] = half_sq_resid(mn, V, Vh);
+        if (it > 1 && cost[it] < cost[it - 1] && cost[it - 1] - cost[it] < tol) { *ncost = it + 1; break; }
+    }
+    free(V); free(Vh); free(W0); free(neg); free(pos); free(Xn); free(stepW);
     return 0;
 }

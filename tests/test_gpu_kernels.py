@@ -75,7 +75,7 @@ def test_gemm_prologue_and_accumulate(gpu_lib, pro):
     assert rel_fro(got, A @ g) < 2e-6
 
 
-@pytest.mark.parametrize("N,count,sparse", [(200, 3, 0.6), (1024, 8, 0.5), (4096, 4, 0.8), (5000, 2, 0.3), (32768, 2, 0.5), (40000, 1, 0.5)])
+@pytest.mark.parametrize("N,count,sparse", [(200, 3, 0.6), (1024, 8, 0.5), (4096, 4, 0.8), (5000, 2, 0.3), (32768, 2, 0.5), (40000, 1, 0.5), (70000, 2, 0.7), (200001, 1, 0.4)])
 def test_projfunc(gpu_lib, N, count, sparse):
     from oracle import nmf_oracle as O
     import ctypes as C

@@ -113,7 +113,7 @@ def test_nmfsc_golden(tag):
 
 @pytest.mark.parametrize("tag", ["mu", "h", "w"])
 def test_cnmfsc_golden(tag):
-    """cnmfsc.m restatement (numpy only: the plain-C cross-check does not cover this 'next' row yet)."""
+    """cnmfsc.m restatement: literal NumPy vs golden vs the independent plain-C one."""
     g = load("cnmfsc_small_" + tag)
     V, W0, H0 = synth(48, 120, 5, T=3)
     sW, sH = g["sparsity"]
@@ -126,6 +126,9 @@ def test_cnmfsc_golden(tag):
     W, H, cost = O.cnmfsc(2.0 * V, 5, 3, cfg, info=info)
     assert rel_fro(W, g["W"]) < 1e-11 and rel_fro(H, g["H"]) < 1e-11 and rel_fro(cost, g["cost"]) < 1e-12
     assert info["triesH"] == list(g["triesH"]) and info["triesW"] == list(g["triesW"])
+    Wc, Hc, cc, ic = CO.cnmfsc(2.0 * V, W0, H0, sW=sW, sH=sH, maxiter=10, tol=1e-12)
+    assert ic["triesH"] == info["triesH"] and ic["triesW"] == info["triesW"]
+    assert rel_fro(Wc, W) < 1e-10 and rel_fro(Hc, H) < 1e-10 and rel_fro(cc, cost) < 1e-11
     if tag == "w":      # the reference's sparse-W line search compares against a shift-less product: it gives up by step-size underflow
         assert max(info["triesW"]) > 600 and len(cost) <= 3
     if tag == "mu":
@@ -138,6 +141,8 @@ def test_lnmf_golden():
     W, H, cost = O.lnmf(V, 8, dict(W_init=W0, H_init=H0, maxiter=30, tolerance=1e-12))
     assert rel_fro(W, g["W"]) < 1e-12 and rel_fro(H, g["H"]) < 1e-12 and rel_fro(cost, g["cost"]) < 1e-12
     assert np.allclose(W.sum(0), 1.0, atol=1e-13) and np.all(np.diff(cost) <= 0)
+    Wc, Hc, cc = CO.lnmf(V, W0, H0, maxiter=30, tol=1e-12)
+    assert rel_fro(Wc, W) < 1e-12 and rel_fro(Hc, H) < 1e-12 and rel_fro(cc, cost) < 1e-12
     c = O.lnmf(V, 8, dict(W_init=W0, H_init=H0, maxiter=60, tolerance=1.0))[2]
     assert len(c) == 60 and 1 < np.count_nonzero(c) < 60 and np.all(c[np.count_nonzero(c):] == 0)   # not trimmed on break (lnmf.m:84-86)
 
