@@ -98,11 +98,19 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # dev aid for 1-GPU boxes: NMFX_BENCH_BACKEND=gloo NMFX_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 over gloo (RCCL refuses
+    # two ranks on one device); the driver's multi-GPU runs use the defaults (one GPU per rank, nccl = RCCL)
+    backend = os.environ.get("NMFX_BENCH_BACKEND", "nccl")
+    if os.environ.get("NMFX_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     alg, div, m, n, K, T, fmul = WORKLOADS[args.workload]
     lo, hi = shard_columns(n, world, rank)
