@@ -227,18 +227,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
             lb.load(p.B, j_tile0, (int)kbeg + (t + 1) * BK, p.N, kend);
         }
         const float *Ac = smem + cur * BUF_SZ, *Bc = Ac + A_SZ_AL;
+        // operands of step kk+1 are read from LDS before the MFMAs of step kk issue (in-order wave: a read placed after
+        // them would only start when the last MFMA has issued); sched_barrier keeps hipcc from re-clustering the reads
+        float fa[NR], fb[MR], ga[NR], gb[MR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) fa[a] = Bc[h * LDB_S + wj0 + 32 * a + l31];
+#pragma unroll
+        for (int b = 0; b < MR; ++b) fb[b] = Ac[h * LDA_S + wi0 + 32 * b + l31];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float fa[NR], fb[MR];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int a = 0; a < NR; ++a) fa[a] = Bc[(2 * kk + h) * LDB_S + wj0 + 32 * a + l31];
+                for (int a = 0; a < NR; ++a) ga[a] = Bc[(2 * kk + 2 + h) * LDB_S + wj0 + 32 * a + l31];
 #pragma unroll
-            for (int b = 0; b < MR; ++b) fb[b] = Ac[(2 * kk + h) * LDA_S + wi0 + 32 * b + l31];
+                for (int b = 0; b < MR; ++b) gb[b] = Ac[(2 * kk + 2 + h) * LDA_S + wi0 + 32 * b + l31];
+            }
 #pragma unroll
             for (int a = 0; a < NR; ++a)
 #pragma unroll
                 for (int b = 0; b < MR; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < NR; ++a) fa[a] = ga[a];
+#pragma unroll
+            for (int b = 0; b < MR; ++b) fb[b] = gb[b];
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < ntiles) {
             la.store(smem + (cur ^ 1) * BUF_SZ);
