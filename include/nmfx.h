@@ -138,6 +138,11 @@ typedef struct {
     void *stream;             /* hipStream_t of the caller (NULL = default stream) */
     int64_t col_offset;       /* global index of the first local column (cnmf halo logic; 0 on 1 GPU) */
     int32_t path;             /* 0 = auto; 1 = force generic (materialised V_hat) path; 2 = force fused path */
+    /* cnmf on a column shard: H carries halo_left + n_local + halo_right columns and V n_local + halo_right
+     * (the convolution reaches T-1 columns into the neighbours); n_valid = how many of V's columns exist globally
+     * (= n_local + halo_right except on the last rank).  The caller refreshes H's halos after every hstep.  All 0 on one GPU. */
+    int32_t halo_left, halo_right;
+    int64_t n_valid;
     int32_t algorithm;        /* 2 = lnmf rules (lnmf.m:59,69-70,76: L1 columns, plain ratio, sqrt H update);
                                  0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
                                  (cnmf.m:157-166,196-199: slab Frobenius norm T, H rescaled at init only) */
@@ -161,6 +166,10 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e);
  * shard's cost of the iteration in the engine; on the fused path V_hat is never formed and the cost of iteration i is a
  * by-product of the W-step pass of iteration i+1 (same W, H), or of nmfx_engine_cost_pass(). */
 nmfx_status nmfx_engine_hstep(nmfx_engine *e);
+/* Column-sharded cnmf: with defer = 1, nmfx_engine_hstep stops after the H update so that the caller can refresh H's halo
+ * columns from the neighbouring ranks; nmfx_engine_hstep_finish then refreshes V_hat / the cost with the new H. */
+nmfx_status nmfx_engine_defer_hstep_finish(nmfx_engine *e, int32_t defer);
+nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e);
 /* make the engine's cost refer to the CURRENT (W, H): no-op when it already does, else one fused S = W*H pass */
 nmfx_status nmfx_engine_cost_pass(nmfx_engine *e);
 int32_t nmfx_engine_is_fused(nmfx_engine *e);

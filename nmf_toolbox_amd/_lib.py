@@ -20,7 +20,7 @@ EXPORTS = [
     "nmfx_nmf", "nmfx_cnmf", "nmfx_lnmf", "nmfx_nmfsc", "nmfx_cnmfsc", "nmfx_reconstruct", "nmfx_projfunc", "nmfx_last_error",
     "nmfx_device_count", "nmfx_version", "nmfx_engine_workspace_bytes", "nmfx_engine_packed_count",
     "nmfx_engine_create", "nmfx_engine_destroy", "nmfx_engine_init", "nmfx_engine_wstep_partial",
-    "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
+    "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_defer_hstep_finish", "nmfx_engine_hstep_finish", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32",
 ]
@@ -57,7 +57,8 @@ class EngineDesc(C.Structure):
         ("m", C.c_int64), ("n_local", C.c_int64), ("K_total", C.c_int32), ("T", C.c_int32), ("divergence", C.c_int32),
         ("alpha", C.c_double), ("beta", C.c_double),
         ("lamW_col", C.c_void_p), ("lamH_row", C.c_void_p), ("fixW_col", C.c_void_p), ("fixH_row", C.c_void_p),
-        ("device", C.c_int32), ("stream", C.c_void_p), ("col_offset", C.c_int64), ("path", C.c_int32), ("algorithm", C.c_int32),
+        ("device", C.c_int32), ("stream", C.c_void_p), ("col_offset", C.c_int64), ("path", C.c_int32),
+        ("halo_left", C.c_int32), ("halo_right", C.c_int32), ("n_valid", C.c_int64), ("algorithm", C.c_int32),
     ]
 
 
@@ -91,6 +92,8 @@ def load():
     lib.nmfx_engine_packed_count.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_create.argtypes = [C.POINTER(EngineDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.nmfx_engine_is_fused.argtypes = [C.c_void_p]
+    lib.nmfx_engine_defer_hstep_finish.argtypes = [C.c_void_p, C.c_int32]
+    lib.nmfx_engine_hstep_finish.argtypes = [C.c_void_p]
     for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

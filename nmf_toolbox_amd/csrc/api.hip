@@ -63,7 +63,10 @@ struct ProfEvent {
 };
 
 struct nmfx_engine {
-    long m, n;
+    long m, n;                // n = local columns owned by this shard
+    int hL, hR;               // halo columns of H on each side; V / V_hat carry hR extra columns on the right
+    long nvalid;              // columns of V that exist globally (<= n + hR)
+    float *Hext;              // base of the K x (hL + n + hR) buffer; H points at its centre
     int K, T, KT, div, algo;
     double alpha, beta;       // NMFX_DIV_AB only; alpha == 0 selects the dual update equations (nmf.m:124-128)
     int device;
@@ -82,7 +85,7 @@ struct nmfx_engine {
     void *rr_scratch;
     int n_cost_partials, n_cost_used;
     // fused path (fused.hip): V_hat is never materialised
-    bool fused, cost_valid;
+    bool fused, cost_valid, defer_hfinish;
     bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
     float *CC;                // KT x KT Gram of the stacked W (gram path)
     int nsplit_w, isplit_h;
@@ -138,13 +141,13 @@ bool div_has_matrix_den(int div) { return div != NMFX_DIV_KL; }
 // carve (or just size, when ws == nullptr) the workspace
 Layout layout(nmfx_engine *e, void *ws) {
     Carver c(ws);
-    const size_t mn = (size_t)e->m * e->n, Kn = (size_t)e->K * e->n, mKT = (size_t)e->m * e->KT;
+    const size_t mn = (size_t)e->m * (e->n + e->hR), Kn = (size_t)e->K * e->n, mKT = (size_t)e->m * e->KT;
     e->Vhat = c.take<float>(mn);
     e->Gn = c.take<float>(Kn);
     e->Gp = div_has_matrix_den(e->div) ? c.take<float>(Kn) : nullptr;
     size_t gs = gemm_scratch_bytes(e->m, e->KT, e->n);
     size_t gs2 = gemm_scratch_bytes(e->K, e->n, (long)e->T * e->m);
-    size_t gs3 = gemm_scratch_bytes(e->m, e->n, e->KT);
+    size_t gs3 = gemm_scratch_bytes(e->m, e->n + e->hR, e->KT);
     if (gs2 > gs) gs = gs2;
     if (gs3 > gs) gs = gs3;
     e->gemm_scratch_bytes = gs;
@@ -162,7 +165,7 @@ Layout layout(nmfx_engine *e, void *ws) {
     e->l1W = c.take<double>(e->KT);
     e->l1H = c.take<double>(e->K);
     e->cost = c.take<double>(4);
-    e->n_cost_partials = (int)gemm_grid_blocks(e->m, e->n);
+    e->n_cost_partials = (int)gemm_grid_blocks(e->m, e->n + e->hR);
     e->cost_partials = c.take<double>(e->n_cost_partials);
     e->rr_scratch = c.take<char>(row_reduce_scratch_bytes(e->K));
     Layout L;
@@ -225,6 +228,16 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     e->m = d->m;
     e->n = d->n_local;
+    e->hL = d->halo_left; e->hR = d->halo_right;
+    e->nvalid = (d->halo_left || d->halo_right) ? d->n_valid : d->n_local;
+    if (e->hL < 0 || e->hR < 0 || e->nvalid < d->n_local || e->nvalid > d->n_local + d->halo_right) {
+        set_error("nmfx_engine: inconsistent halo description");
+        return NMFX_ERR_INVALID;
+    }
+    if ((e->hL || e->hR) && d->algorithm != 1) {
+        set_error("nmfx_engine: halos are only meaningful for cnmf");
+        return NMFX_ERR_INVALID;
+    }
     e->K = d->K_total;
     e->T = d->T;
     e->KT = d->K_total * d->T;
@@ -245,7 +258,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     // fused path eligibility: nmf rules, KL or euclidean, K in {64,128,256}, tileable shard
     const bool eligible = (e->algo == 0 || e->algo == 2) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
-                          e->m % 128 == 0 && e->n % 128 == 0;
+                          e->m % 128 == 0 && e->n % 128 == 0 && e->hL == 0 && e->hR == 0;
     if (d->path == 2 && !eligible) {
         set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K in {64,128,256}, m %% 128 == 0, n %% 128 == 0)");
         return NMFX_ERR_UNSUPPORTED;
@@ -300,11 +313,12 @@ nmfx_status recon(nmfx_engine *e, bool with_cost, bool store = true) {
     Scope s(e, with_cost ? TAG_RECON_COST : TAG_RECON);
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.M = e->m; g.N = e->n; g.Kc = e->KT;
+    g.M = e->m; g.N = e->n + e->hR; g.Kc = e->KT;   // V_hat also on the right-halo columns: the H step of the last T-1 local columns needs it
     g.A = OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
     if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
     g.C = e->Vhat; g.ldc = e->m;
+    g.cost_ncols = e->hR ? e->n : 0;
     g.splitk = 1;
     if (with_cost) {
         g.epi = EPI_COST; g.store_c = store ? 1 : 0; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
@@ -327,7 +341,7 @@ nmfx_status x_times_ht(nmfx_engine *e, OpView x, float *out, int tag) {
     x.ld = e->m; x.mode = VIEW_RC; x.blk = 0; x.tstride = 0; x.lim = 0;
     g.A = x;
     if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
     g.C = out; g.ldc = e->m; g.epi = EPI_STORE; g.splitk = 1;
     return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
 }
@@ -343,7 +357,7 @@ nmfx_status wt_times_x(nmfx_engine *e, OpView x, float *out, int tag) {
         x.ld = e->m; x.mode = VIEW_KC; x.blk = 0; x.tstride = 0; x.lim = 0;
     } else {
         g.A = OpView{e->W, nullptr, e->m, VIEW_WSTACK_KC, (int)e->m, e->m * e->K, 0, NMFX_PRO_NONE, 0.f, 0.f};
-        x.ld = e->m; x.mode = VIEW_XSHIFT_KC; x.blk = (int)e->m; x.tstride = 0; x.lim = (int)e->n;
+        x.ld = e->m; x.mode = VIEW_XSHIFT_KC; x.blk = (int)e->m; x.tstride = 0; x.lim = (int)e->nvalid;
     }
     g.B = x;
     g.C = out; g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
@@ -436,7 +450,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     nmfx_engine *e = new nmfx_engine{};
     nmfx_status s = fill_from_desc(e, d);
     if (s != NMFX_OK) { delete e; return s; }
-    e->V = V; e->W = W; e->H = H; e->packed = packed;
+    e->V = V; e->W = W; e->Hext = H; e->H = H + (size_t)e->K * e->hL; e->packed = packed;
     Layout L = layout(e, workspace);
     if (L.total > workspace_bytes) {
         set_error("nmfx_engine_create: workspace too small (%zu < %zu)", workspace_bytes, L.total);
@@ -481,7 +495,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         Scope s(e, TAG_SMALL);
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo, e->f_out));
-        if (e->algo == 1) TRY(scale_rows(e->st, e->H, e->K, e->n, e->f_out));
+        if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
         if (e->fused) {
             e->cost_valid = false;
             if (e->div == NMFX_DIV_KL) {   // sum(V_local), once
@@ -518,7 +532,7 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
     TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
     if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
         Scope s(e, TAG_GRAM);
-        OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
         TRY(small_gemm(e, e->KT, e->KT, e->n, hs, hs, e->packed + mKT, e->KT));
     } else if (div_has_matrix_den(e->div)) {
         den_view(e, b);
@@ -526,7 +540,7 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
     } else {
         Scope s(e, TAG_SMALL);
         TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
-        TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec));
+        TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, e->hL));
         TRY(d2f(e->st, e->Pvec, e->packed + mKT, e->KT));
     }
     return NMFX_OK;
@@ -581,6 +595,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
     return recon(e, false);
 }
 
+nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e);
 // H step + V_hat refresh + local cost partial: nmf.m:176-218 / cnmf.m:207-251
 nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
@@ -632,7 +647,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 memset(&g, 0, sizeof(g));
                 g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
                 g.A = OpView{e->CC + (long)t * e->K, nullptr, (long)e->KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-                g.B = OpView{e->H + (long)e->K * t, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->n - t, t, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{e->H + (long)e->K * t, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->nvalid - t, t, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
                 g.C = e->Gp; g.ldc = e->K; g.accumulate = t > 0; g.epi = EPI_STORE; g.splitk = 1;
                 TRY(launch_gemm(e->st, g));
             }
@@ -647,6 +662,15 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         }
         TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
     }
+    if (e->defer_hfinish) return NMFX_OK;   // the caller refreshes H's halos first, then calls nmfx_engine_hstep_finish
+    return nmfx_engine_hstep_finish(e);
+}
+
+// second half of the H step on the generic paths: V_hat refresh (+ cost) with the NEW H -- on a column shard the halo
+// columns of H must have been refreshed from the neighbours before this runs (V_hat near the shard edges depends on them)
+nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
     else TRY(recon(e, !nocost));
@@ -654,6 +678,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     e->cost_valid = true;
     return cost_from_partials(e, nocost ? 0 : e->n_cost_used);
 }
+nmfx_status nmfx_engine_defer_hstep_finish(nmfx_engine *e, int32_t defer) { e->defer_hfinish = defer != 0; return NMFX_OK; }
 
 // make e->cost hold the cost of the CURRENT (W, H): free on the generic path (hstep already did it), one S = W*H pass on the
 // fused path unless the last wstep_partial just produced it

@@ -358,16 +358,17 @@ nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols,
 
 // broadcast vector helper for KL: Pvec[c = k + K*t] = sum_{j < n - t} H[k,j]  given full row sums and the tail columns
 //   (cnmf.m:191-192 with V_pos = ones: ones(m,n) * H_shifted' = rowsum of the first n-t columns)
-__global__ void kl_pvec_kernel(const double *rowsum, const float *H, int K, long n, int T, double *Pvec) {
+__global__ void kl_pvec_kernel(const double *rowsum, const float *H, int K, long n, int T, double *Pvec, int hL) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= K * T) return;
     const int k = c % K, t = c / K;
     double s = rowsum[k];
     for (int d = 0; d < t; ++d) s -= (double)H[k + K * (n - 1 - d)];
+    for (int d = 1; d <= t && d <= hL; ++d) s += (double)H[(long)k - (long)K * d];   // columns -d of a shard's left halo
     Pvec[c] = s;
 }
-nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec) {
-    hipLaunchKernelGGL(kl_pvec_kernel, dim3((K * T + 63) / 64), dim3(64), 0, st, rowsum, H, K, n, T, Pvec);
+nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec, int halo_left) {
+    hipLaunchKernelGGL(kl_pvec_kernel, dim3((K * T + 63) / 64), dim3(64), 0, st, rowsum, H, K, n, T, Pvec, halo_left);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

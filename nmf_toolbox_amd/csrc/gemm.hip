@@ -27,7 +27,7 @@ __device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g)
     switch (v.mode) {
     case VIEW_RC: off = r; g = 0; break;
     case VIEW_HSTACK_RC: { int rr = r + v.lim; int t = rr / v.blk; int k = rr - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
-    case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim; break;
+    case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim + v.goff; break;
     case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
     default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
     }
@@ -35,7 +35,7 @@ __device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g)
 __device__ __forceinline__ void dec_k(const OpView &v, int kc, long &off, int &g) {
     switch (v.mode) {
     case VIEW_RC: off = v.ld * kc; g = 0; break;
-    case VIEW_HSTACK_RC: off = v.ld * kc; g = kc; break;
+    case VIEW_HSTACK_RC: off = v.ld * kc; g = kc + v.goff; break;
     case VIEW_HSTACK_KC: { int t = kc / v.blk; int k = kc - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
     case VIEW_WSTACK_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.tstride * t; g = 0; } break;
     case VIEW_XSHIFT_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.ld * t; g = -t; } break;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
                 if (FAST || (i < p.M && j < p.N)) {
                     float s = acc[a][b][e];
                     if (p.epi == EPI_COST) {
-                        part += div_term<HEAVY>(p.cost_div, p.Vref[i + p.ldv * j], s, p.cost_alpha, p.cost_beta);
+                        if (p.cost_ncols == 0 || j < p.cost_ncols) part += div_term<HEAVY>(p.cost_div, p.Vref[i + p.ldv * j], s, p.cost_alpha, p.cost_beta);
                         if (p.store_c) C[i + p.ldc * j] = s;
                     } else {
                         if (p.accumulate) s += C[i + p.ldc * j];

@@ -42,6 +42,7 @@ struct OpView {
     int lim;          // VIEW_XSHIFT_KC: n;  VIEW_HSTACK_RC: row offset (select stacked block t: lim = t*blk);  VIEW_HSTACK_KC: extra column shift g (element valid iff r + g >= t)
     int func;         // nmfx_prologue
     float e1, e2;     // NMFX_PRO_POWPROD exponents (MATLAB .^ semantics: x.^0 == 1, x.^1 == x)
+    int goff;         // HSTACK views: columns j >= -goff exist (left halo of a column shard); element valid iff j - t >= -goff
 };
 
 enum EpiMode {
@@ -63,6 +64,7 @@ struct GemmParams {
     const float *Vref;   // EPI_COST: reference matrix (M x N, ld = ldv)
     long ldv;
     double *cost_partials;  // EPI_COST: one fp64 partial per block [gridDim.x*gridDim.y]
+    long cost_ncols;     // EPI_COST: only columns j < cost_ncols enter the cost (0 = all): halo columns of a shard are not this rank's
     int splitk;          // >1: partial sums written to slabs C + z*slab_stride, reduced by reduce_slabs
     long slab_stride;
     long kc_per_split;   // multiple of BK
@@ -139,7 +141,7 @@ nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const 
 nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
 nmfx_status mu_plus_eps(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ (pos + eps))
 nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out);    // out (cols x rows)
-nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec);
+nmfx_status kl_pvec(hipStream_t st, const double *rowsum, const float *H, int K, long n, int T, double *Pvec, int halo_left = 0);
 nmfx_status sum_over_t(hipStream_t st, const double *colsum, int K, int T, double *out);
 nmfx_status d2f(hipStream_t st, const double *in, float *out, int count);
 nmfx_status f2d(hipStream_t st, const float *in, double *out, int count);

@@ -65,6 +65,9 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
         dist.all_reduce(backend.packed, group=group)          # the ONE exchange step of an iteration
         backend.wstep_finish()
         backend.hstep()
+        if getattr(backend, "has_halos", False):
+            backend.exchange_halos()                          # cnmf only: T-1 columns of H to each neighbour ...
+            backend.hstep_finish()                            # ... then V_hat / cost with the new H
         if not lag and cost_out is not None:
             emit(it)
     if lag and iters > 0 and cost_out is not None:
@@ -76,17 +79,20 @@ class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
     def __init__(self, V, W, H, divergence="euclidean", T=1, algorithm="nmf", lamW=None, lamH=None, fixW=None, fixH=None,
-                 group=None, use_dist=None, path=0):
+                 group=None, use_dist=None, path=0, halo=(0, 0), n_valid=None):
         import torch
         self.torch = torch
         if not (V.is_cuda and W.is_cuda and H.is_cuda):
             raise _lib.NmfxError(_lib.NMFX_ERR_NO_DEVICE, "Engine needs CUDA/HIP tensors: there is no CPU fallback")
         self.lib = _lib.load()
         self.V, self.W, self.H = V.contiguous(), W.contiguous(), H.contiguous()
-        self.n, self.m = self.V.shape
+        self.hL, self.hR = int(halo[0]), int(halo[1])          # cnmf shards: H = [left halo | local | right halo], V = [local | right halo]
+        self.m = self.V.shape[1]
+        self.n = self.H.shape[0] - self.hL - self.hR
         self.K = self.H.shape[1]
         self.T = int(T)
-        assert self.H.shape[0] == self.n and self.W.numel() == self.m * self.K * self.T
+        assert self.V.shape[0] == self.n + self.hR and self.W.numel() == self.m * self.K * self.T
+        self.H_local = self.H[self.hL:self.hL + self.n]        # this rank's own columns (a view)
         dist = torch.distributed
         self.dist = dist if (use_dist if use_dist is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)) else None
         self.group = group
@@ -105,6 +111,8 @@ class Engine:
         d.stream = C.c_void_p(torch.cuda.current_stream(self.V.device).cuda_stream)
         d.algorithm = {"nmf": 0, "cnmf": 1, "lnmf": 2}[algorithm]
         d.path = int(path)
+        d.halo_left, d.halo_right = self.hL, self.hR
+        d.n_valid = int(n_valid) if n_valid is not None else self.n + self.hR
         self.desc = d
         nbytes, count = C.c_size_t(0), C.c_size_t(0)
         _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
@@ -119,6 +127,9 @@ class Engine:
         _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
         self.cost_lags = bool(self.lib.nmfx_engine_is_fused(self.h))
+        self.has_halos = bool(self.hL or self.hR)
+        if self.has_halos:   # V_hat / cost are refreshed only after the neighbours' new H columns have arrived
+            _lib.check(self.lib.nmfx_engine_defer_hstep_finish(self.h, 1))
 
     def close(self):
         if getattr(self, "h", None):
@@ -140,8 +151,39 @@ class Engine:
     def hstep(self):
         _lib.check(self.lib.nmfx_engine_hstep(self.h))
 
+    def hstep_finish(self):
+        _lib.check(self.lib.nmfx_engine_hstep_finish(self.h))
+
     def cost_pass(self):
         _lib.check(self.lib.nmfx_engine_cost_pass(self.h))
+
+    def exchange_halos(self):
+        """cnmf on column shards: refresh H's halo columns from the neighbouring ranks (T-1 columns each way, point-to-point).
+        Rank r sends its first hR' columns to r-1 (their right halo) and its last hL' columns to r+1 (their left halo)."""
+        if self.dist is None or (self.hL == 0 and self.hR == 0):
+            return
+        dist, torch = self.dist, self.torch
+        world, rank = dist.get_world_size(self.group), self.rank
+        ops, keep = [], []
+        h = self.T - 1
+        if h == 0:
+            return
+        if rank > 0:                       # left neighbour exists: receive my left halo, send my first h columns
+            ops.append(dist.P2POp(dist.irecv, self.H[0:self.hL], rank - 1, self.group))
+            buf = self.H_local[0:h].contiguous(); keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, rank - 1, self.group))
+        if rank < world - 1:               # right neighbour exists
+            ops.append(dist.P2POp(dist.irecv, self.H[self.hL + self.n:self.hL + self.n + self.hR], rank + 1, self.group))
+            buf = self.H_local[self.n - h:self.n].contiguous(); keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, rank + 1, self.group))
+        if ops:
+            stream_ordered = dist.get_backend(self.group) == "nccl"   # RCCL point-to-point is ordered on the current stream
+            if not stream_ordered:
+                torch.cuda.current_stream(self.V.device).synchronize()   # gloo copies through the host: the H update must have finished
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if not stream_ordered:
+                torch.cuda.synchronize(self.V.device)
 
     def iterate(self, iters, cost_out=None):
         """`iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration."""
