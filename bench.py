@@ -123,7 +123,29 @@ def main():
     W = torch.rand((T * K, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)      # identical on every rank
     g.manual_seed(2 + rank)
     H = torch.rand((nl, K), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
-    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path)
+    halo = (0, 0)
+    if alg == "cnmf" and world > 1 and T > 1:
+        # column-sharded cnmf: H gets T-1 halo columns on each inner side, V on the right; the initial halo contents are the
+        # neighbours' edge columns, moved once point-to-point (Engine.exchange_halos keeps H's halos fresh afterwards)
+        h = T - 1
+        hL, hR = (h if rank > 0 else 0), (h if rank < world - 1 else 0)
+        Hx = torch.zeros((hL + nl + hR, K), device=dev, dtype=torch.float32)
+        Hx[hL:hL + nl] = H
+        Vx = torch.zeros((nl + hR, m), device=dev, dtype=torch.float32)
+        Vx[:nl] = V
+        torch.cuda.synchronize()
+        ops = []
+        if rank > 0:
+            ops += [dist.P2POp(dist.isend, V[:h].contiguous(), rank - 1), dist.P2POp(dist.isend, H[:h].contiguous(), rank - 1),
+                    dist.P2POp(dist.irecv, Hx[:hL], rank - 1)]
+        if rank < world - 1:
+            ops += [dist.P2POp(dist.irecv, Vx[nl:], rank + 1), dist.P2POp(dist.irecv, Hx[hL + nl:], rank + 1),
+                    dist.P2POp(dist.isend, H[nl - h:].contiguous(), rank + 1)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        torch.cuda.synchronize()
+        V, H, halo = Vx, Hx, (hL, hR)
+    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo)
     eng.init()
     costs = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
 
@@ -176,7 +198,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.m %s MU, V=%dx%d K=%d%s fp32, V column-sharded over %d GPU(s)" % (alg, div, m, n, K, (" T=%d" % T) if T > 1 else "", world),
                        "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
-                       "path": "fused (V_hat never materialised)" if eng.cost_lags else "generic (materialised V_hat)"},
+                       "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
+                                0: "generic GEMM (materialised V_hat)"}[eng.path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,

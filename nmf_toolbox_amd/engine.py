@@ -126,7 +126,8 @@ class Engine:
         self.h = h
         _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
-        self.cost_lags = bool(self.lib.nmfx_engine_is_fused(self.h))
+        self.path_kind = int(self.lib.nmfx_engine_is_fused(self.h))
+        self.cost_lags = self.path_kind == 1
         self.has_halos = bool(self.hL or self.hR)
         if self.has_halos:   # V_hat / cost are refreshed only after the neighbours' new H columns have arrived
             _lib.check(self.lib.nmfx_engine_defer_hstep_finish(self.h, 1))
