@@ -101,6 +101,16 @@ nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = lnmf(V, num_basis_elems, config)           -- replaces lnmf.m:1 (loop lnmf.m:66-88).
  * divergence must be NMFX_DIV_KL, one source; cost keeps maxiter entries (the reference does not trim on break). */
 nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r);
+/* [W,H,Z,A,cost] = constrainednmf(V, labels, num_basis_elems, config) -- replaces constrainednmf.m:1 (loop constrainednmf.m:183-258;
+ * SURVEY 8(f) row f4).  The caller has done the label bookkeeping of constrainednmf.m:147-170 (host control logic): V's columns
+ * are already sorted by processed label (unlabelled samples first), and segments[0..nz] gives, for every column c of the cluster
+ * matrix Z (K x nz), the range [segments[c], segments[c+1]) of sorted samples it owns (length-1 ranges for unlabelled samples, one
+ * range per class after them), i.e. the non-zeros of row c of A.  H_init is ignored (H = Z*A); H_sparsity[0] / H_fixed[0] carry
+ * config.Z_sparsity / config.Z_fixed; result.H = Z*A in SORTED sample order; Z_out receives Z (same dtype as the problem).
+ * Divergences: euclidean, kl, is, and ab with alpha == 0 only -- the alpha ~= 0 expression at constrainednmf.m:229 is ill-formed
+ * in the reference (element-wise product of a K x n and an m x n matrix) and is refused with NMFX_ERR_UNSUPPORTED. */
+nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, int64_t nz, const void *Z_init,
+                                nmfx_result *r, void *Z_out);
 /* [W,H,cost] = nmfsc(V, num_basis_elems, config)          -- replaces nmfsc.m:1 (hot loop nmfsc.m:141-245) */
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = cnmfsc(V, num_basis_elems, context_len, config) -- replaces cnmfsc.m:1 (hot loop cnmfsc.m:155-277).
@@ -109,6 +119,10 @@ nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r);
 /* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
                              const void *H, void *V_hat, int32_t device);
+/* [W_sorted,H_sorted] = SortDictionary(W, H)               -- replaces SortDictionary.m:1.  H and H_sorted may
+ * be NULL; order_out (optional, [K]) receives the 0-based column permutation. */
+nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype, const void *W, const void *H,
+                                 void *W_sorted, void *H_sorted, int32_t *order_out, int32_t device);
 /* [v,usediters] = projfunc(s, k1, k2, nn) applied to `count` vectors of length N (stride N) -- replaces projfunc.m:1 */
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2,
                           int32_t nn, void *v, int32_t *usediters, int32_t device);
@@ -143,7 +157,9 @@ typedef struct {
      * (= n_local + halo_right except on the last rank).  The caller refreshes H's halos after every hstep.  All 0 on one GPU. */
     int32_t halo_left, halo_right;
     int64_t n_valid;
-    int32_t algorithm;        /* 2 = lnmf rules (lnmf.m:59,69-70,76: L1 columns, plain ratio, sqrt H update);
+    int32_t algorithm;        /* 3 = constrainednmf rules (nmf's W step; the H step updates Z and sets H = Z*A,
+                                 constrainednmf.m:213-237; needs nmfx_engine_set_constraint; one GPU only);
+                                 2 = lnmf rules (lnmf.m:59,69-70,76: L1 columns, plain ratio, sqrt H update);
                                  0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
                                  (cnmf.m:157-166,196-199: slab Frobenius norm T, H rescaled at init only) */
 } nmfx_engine_desc;
@@ -179,6 +195,8 @@ nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost);
 /* enqueue an 8-byte device-to-device copy of that cost into dst_dev on the engine's stream */
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev);
 nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0);
+/* algorithm 3 only, before nmfx_engine_init: host segments[0..nz] (see nmfx_constrainednmf) and the DEVICE cluster matrix Z (K x nz) */
+nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *segments_host, int64_t nz, float *Z_dev);
 /* convenience for one GPU: `iters` full iterations, costs written to the DEVICE array dev_cost_out[iters] (may be NULL) */
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out);
 

@@ -22,7 +22,8 @@ EXPORTS = [
     "nmfx_engine_create", "nmfx_engine_destroy", "nmfx_engine_init", "nmfx_engine_wstep_partial",
     "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_defer_hstep_finish", "nmfx_engine_hstep_finish", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
-    "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32",
+    "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
+    "nmfx_engine_set_constraint",
 ]
 
 
@@ -86,6 +87,9 @@ def load():
     lib.nmfx_engine_destroy.argtypes = [C.c_void_p]
     for name in ("nmfx_nmf", "nmfx_cnmf", "nmfx_lnmf", "nmfx_nmfsc", "nmfx_cnmfsc"):
         getattr(lib, name).argtypes = [C.POINTER(Problem), C.POINTER(Result)]
+    lib.nmfx_constrainednmf.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Result), C.c_void_p]
+    lib.nmfx_sort_dictionary.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nmfx_engine_set_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.nmfx_reconstruct.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_projfunc.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_engine_workspace_bytes.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]

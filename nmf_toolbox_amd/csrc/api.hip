@@ -91,6 +91,10 @@ struct nmfx_engine {
     int nsplit_w, isplit_h;
     float *WT, *slabs, *Pbuf, *GW;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
+    // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
+    float *Z;
+    long nz;
+    long *seg_dev;            // owned (hipMalloc) -- the only allocation the engine makes itself
     // profiling
     bool prof;
     std::vector<ProfEvent> events;
@@ -248,8 +252,15 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->algo = d->algorithm;
     e->alpha = d->divergence == NMFX_DIV_AB ? d->alpha : 1.0;
     e->beta = d->divergence == NMFX_DIV_AB ? d->beta : 1.0;
+    if (e->algo < 0 || e->algo > 3) { set_error("nmfx_engine: unknown algorithm %d", e->algo); return NMFX_ERR_INVALID; }
+    if (e->algo == 3 && e->div == NMFX_DIV_AB && e->alpha != 0) {
+        // constrainednmf.m:229 `W' * V.^alpha .* V_hat.^(beta-1) * A'` multiplies a K x n by an m x n matrix element-wise: MATLAB
+        // raises a dimension error there (unless K == m), so there is no reference behaviour to reproduce
+        set_error("constrainednmf: the alpha-beta update with alpha ~= 0 is ill-formed in the reference (constrainednmf.m:229); use alpha = 0 (dual form), euclidean, kl or is");
+        return NMFX_ERR_UNSUPPORTED;
+    }
     if (e->algo != 1 && e->T != 1) {
-        set_error("nmfx_engine: algorithms nmf / lnmf require T == 1");
+        set_error("nmfx_engine: algorithms nmf / lnmf / constrainednmf require T == 1");
         return NMFX_ERR_INVALID;
     }
     if (e->algo == 2 && e->div != NMFX_DIV_KL) {
@@ -257,7 +268,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_INVALID;
     }
     // fused path eligibility: nmf rules, KL or euclidean, K in {64,128,256}, tileable shard
-    const bool eligible = (e->algo == 0 || e->algo == 2) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
+    const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
                           e->m % 128 == 0 && e->n % 128 == 0 && e->hL == 0 && e->hR == 0;
     if (d->path == 2 && !eligible) {
         set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K in {64,128,256}, m %% 128 == 0, n %% 128 == 0)");
@@ -278,6 +289,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     return NMFX_OK;
 }
 
+inline int norm_mode(const nmfx_engine *e) { return e->algo == 3 ? 0 : e->algo; }   // w_normalize: 0 L2 columns, 1 cnmf slabs, 2 L1 (lnmf)
 inline int mdiv(const nmfx_engine *e) { return e->div == NMFX_DIV_EUCLIDEAN_NOCOST ? NMFX_DIV_EUCLIDEAN : e->div; }
 
 // element maps (V, V_hat) -> numerator operand A, denominator operand B   (nmf.m:149-156, cnmf.m:191-192)
@@ -377,7 +389,10 @@ nmfx_status small_gemm(nmfx_engine *e, long M, long N, long Kc, OpView A, OpView
 nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form = false) {
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
-    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    if (useH) {   // constrainednmf.m:251 charges Z_sparsity on |Z|, not on H = Z*A
+        if (e->algo == 3) TRY(row_reduce(e->st, e->Z, e->K, e->K, e->nz, 2, e->l1H, e->rr_scratch));
+        else TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    }
     double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
     if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
     // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
@@ -482,8 +497,27 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
 
 void nmfx_engine_destroy(nmfx_engine *e) {
     if (!e) return;
+    if (e->seg_dev) (void)hipFree(e->seg_dev);
     for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
     delete e;
+}
+
+// constrainednmf (algorithm 3): segments of label-sorted columns and the device cluster matrix Z (K x nz, column-major).
+// seg_host[0] = 0 < seg_host[1] < ... < seg_host[nz] = n_local; call before nmfx_engine_init.
+nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *seg_host, int64_t nz, float *Z_dev) {
+    if (!e || e->algo != 3) { set_error("nmfx_engine_set_constraint: engine was not created with algorithm 3"); return NMFX_ERR_INVALID; }
+    if (!seg_host || !Z_dev || nz <= 0 || nz > e->n) { set_error("nmfx_engine_set_constraint: bad arguments"); return NMFX_ERR_INVALID; }
+    if (seg_host[0] != 0 || seg_host[nz] != e->n) { set_error("nmfx_engine_set_constraint: segments must cover [0, n)"); return NMFX_ERR_INVALID; }
+    for (int64_t c = 0; c < nz; ++c)
+        if (seg_host[c + 1] <= seg_host[c]) { set_error("nmfx_engine_set_constraint: empty segment %ld", (long)c); return NMFX_ERR_INVALID; }
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->seg_dev) { (void)hipFree(e->seg_dev); e->seg_dev = nullptr; }
+    std::vector<long> sg(seg_host, seg_host + nz + 1);
+    NMFX_HIP(hipMalloc(&e->seg_dev, sizeof(long) * (nz + 1)));
+    NMFX_HIP(hipMemcpyAsync(e->seg_dev, sg.data(), sizeof(long) * (nz + 1), hipMemcpyHostToDevice, e->st));
+    NMFX_HIP(hipStreamSynchronize(e->st));
+    e->Z = Z_dev; e->nz = nz;
+    return NMFX_OK;
 }
 
 nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 = is_rank0; return NMFX_OK; }
@@ -491,10 +525,14 @@ nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 =
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
 nmfx_status nmfx_engine_init(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
+    if (e->algo == 3) {
+        if (!e->Z) { set_error("nmfx_engine_init: constrainednmf needs nmfx_engine_set_constraint first"); return NMFX_ERR_INVALID; }
+        TRY(z_update(e->st, e->Z, e->H, nullptr, nullptr, nullptr, e->K, e->nz, e->seg_dev, nullptr, nullptr, 1.0f, 1));   // H = Z*A, constrainednmf.m:177
+    }
     {
         Scope s(e, TAG_SMALL);
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, e->algo, e->f_out));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out));
         if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
         if (e->fused) {
             e->cost_valid = false;
@@ -568,7 +606,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         Scope s(e, TAG_SMALL);
         p.rule = e->algo == 2 ? 1 : 0;
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, e->algo, nullptr));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, norm_mode(e), nullptr));
         e->cost_valid = false;
         return refresh_w_derived(e);
     }
@@ -589,7 +627,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         }
         p.rule = e->algo == 2 ? 1 : 0;
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, e->algo, nullptr));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
     }
     if (e->gram) return NMFX_OK;
     return recon(e, false);
@@ -615,20 +653,21 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         f.c_per_split = e->m / e->isplit_h;
         const int func = e->div == NMFX_DIV_KL ? 2 : 0;
         const bool kl = e->div == NMFX_DIV_KL;
-        if (e->isplit_h == 1) {
+        if (e->isplit_h == 1 && e->algo != 3) {
             f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
             TRY(launch_fused(e->st, f, 1, false, func, true, 1));
         } else {
-            f.out = e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
+            f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
             {
                 Scope s(e, TAG_FUSED_H);
                 TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
             }
             Scope s(e, TAG_SMALL);
-            TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
-            TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
+            if (e->isplit_h > 1) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
         }
         e->cost_valid = false;
         return NMFX_OK;
@@ -660,7 +699,8 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
             TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
         }
-        TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
+        if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
+        else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
     }
     if (e->defer_hfinish) return NMFX_OK;   // the caller refreshes H's halos first, then calls nmfx_engine_hstep_finish
     return nmfx_engine_hstep_finish(e);
@@ -821,10 +861,10 @@ nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, si
 
 constexpr size_t STAGE_ELEMS = (size_t)8 << 20;  // 64 MiB of doubles
 
-nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc) {
+nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true) {
     if (!p || !r) { set_error("null problem/result"); return NMFX_ERR_INVALID; }
     if (p->m <= 0 || p->n <= 0 || p->K_total <= 0 || p->T <= 0) { set_error("m, n, K_total, T must be positive"); return NMFX_ERR_INVALID; }
-    if (!p->V || !p->W_init || !p->H_init || !r->W || !r->H || !r->cost) { set_error("V, W_init, H_init, result.W, result.H, result.cost are required"); return NMFX_ERR_INVALID; }
+    if (!p->V || !p->W_init || (need_H_init && !p->H_init) || !r->W || !r->H || !r->cost) { set_error("V, W_init, H_init, result.W, result.H, result.cost are required"); return NMFX_ERR_INVALID; }
     if (p->dtype != NMFX_F32 && p->dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
     if (p->maxiter <= 0) { set_error("maxiter must be positive (the wrapper applies the reference default)"); return NMFX_ERR_INVALID; }
     if (!nmfsc) {
@@ -843,9 +883,15 @@ nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool n
     return NMFX_OK;
 }
 
-nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
-    TRY(validate_problem(p, r, false));
-    if (algorithm != 1 && p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
+nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const int64_t *seg = nullptr, int64_t nz = 0, const void *Z_init = nullptr,
+                   void *Z_out = nullptr) {
+    TRY(validate_problem(p, r, false, algorithm != 3));
+    if (algorithm != 1 && p->T != 1) { set_error("nmf / lnmf / constrainednmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm == 3) {
+        if (!seg || !Z_init || !Z_out || nz <= 0) { set_error("constrainednmf: segments, Z_init and Z_out are required"); return NMFX_ERR_INVALID; }
+        if (p->num_sources != 1) { set_error("constrainednmf: single source only (constrainednmf.m has no multi-source form)"); return NMFX_ERR_INVALID; }
+        if (p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("constrainednmf: unknown divergence (constrainednmf.m:204-205)"); return NMFX_ERR_INVALID; }
+    }
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     TRY(check_device(p->device));
     const int K = p->K_total, S = p->num_sources;
@@ -869,16 +915,21 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
     TRY(nmfx_engine_packed_count(&d, &packed_count));
     const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
-    DevBuf V, W, H, ws, packed, stage;
+    DevBuf V, W, H, Z, ws, packed, stage;
     TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(ws.alloc(ws_bytes)); TRY(packed.alloc(packed_count * 4));
     TRY(stage.alloc(STAGE_ELEMS * 8));
     hipStream_t st = nullptr;
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0, stage, STAGE_ELEMS));
     TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
-    TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    if (algorithm != 3) TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
+        TRY(Z.alloc((size_t)K * nz * 4));
+        TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0, stage, STAGE_ELEMS));
+    }
     nmfx_engine *e = nullptr;
     TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
-    nmfx_status s = nmfx_engine_init(e);
+    nmfx_status s = algorithm == 3 ? nmfx_engine_set_constraint(e, seg, nz, Z.as<float>()) : NMFX_OK;
+    if (s == NMFX_OK) s = nmfx_engine_init(e);
     int it = 0;
     r->iters_run = 0;
     auto read_cost = [&](int idx) -> nmfx_status {
@@ -920,6 +971,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     }
     if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKT, stage, STAGE_ELEMS);
     if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
+    if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz, stage, STAGE_ELEMS);
     nmfx_engine_destroy(e);
     return s;
 }
@@ -1414,6 +1466,9 @@ extern "C" {
 nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 0); }
 nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 1); }
 nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 2); }
+nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, int64_t nz, const void *Z_init, nmfx_result *r, void *Z_out) {
+    return run_mu(p, r, 3, segments, nz, Z_init, Z_out);
+}
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
 nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
 
@@ -1436,6 +1491,38 @@ nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t
     g.C = Vd.as<float>(); g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
     TRY(launch_gemm(st, g));
     return download(st, Vd.as<float>(), dtype, V_hat, mn, stage, STAGE_ELEMS);
+}
+
+// [W_sorted, H_sorted] = SortDictionary(W, H): basis columns by increasing centre of mass (SortDictionary.m:33-47), computed in the
+// buffers' own dtype; H / H_sorted may be NULL (nargin < 2).  order_out[K] receives the 0-based permutation (`sorted` - 1).
+nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype, const void *W, const void *H, void *W_sorted, void *H_sorted,
+                                 int32_t *order_out, int32_t device) {
+    if (m <= 0 || K <= 0 || !W || !W_sorted || (H && (!H_sorted || n <= 0))) { set_error("nmfx_sort_dictionary: bad arguments"); return NMFX_ERR_INVALID; }
+    if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
+    TRY(check_device(device));
+    const size_t es = dsize(dtype), wb = (size_t)m * K * es, hb = H ? (size_t)K * n * es : 0;
+    DevBuf Wd, Ws, Hd, Hs, cog, ord;
+    TRY(Wd.alloc(wb)); TRY(Ws.alloc(wb)); TRY(cog.alloc(sizeof(int) * K)); TRY(ord.alloc(sizeof(int) * K));
+    hipStream_t st = nullptr;
+    NMFX_HIP(hipMemcpyAsync(Wd.p, W, wb, hipMemcpyHostToDevice, st));
+    TRY(center_of_gravity(st, Wd.p, dtype == NMFX_F64, m, K, cog.as<int>()));
+    std::vector<int> cg(K), order(K);
+    NMFX_HIP(hipMemcpyAsync(cg.data(), cog.p, sizeof(int) * K, hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < K; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cg[a] < cg[b]; });   // MATLAB sort is stable (SortDictionary.m:43)
+    NMFX_HIP(hipMemcpyAsync(ord.p, order.data(), sizeof(int) * K, hipMemcpyHostToDevice, st));
+    TRY(permute(st, Wd.p, Ws.p, dtype == NMFX_F64, m, K, ord.as<int>(), 0));
+    NMFX_HIP(hipMemcpyAsync(W_sorted, Ws.p, wb, hipMemcpyDeviceToHost, st));
+    if (H) {
+        TRY(Hd.alloc(hb)); TRY(Hs.alloc(hb));
+        NMFX_HIP(hipMemcpyAsync(Hd.p, H, hb, hipMemcpyHostToDevice, st));
+        TRY(permute(st, Hd.p, Hs.p, dtype == NMFX_F64, K, n, ord.as<int>(), 1));
+        NMFX_HIP(hipMemcpyAsync(H_sorted, Hs.p, hb, hipMemcpyDeviceToHost, st));
+    }
+    NMFX_HIP(hipStreamSynchronize(st));
+    if (order_out) for (int k = 0; k < K; ++k) order_out[k] = order[k];
+    return NMFX_OK;
 }
 
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,

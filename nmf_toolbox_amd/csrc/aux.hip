@@ -252,6 +252,118 @@ nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp,
     return NMFX_OK;
 }
 
+// constrainednmf.m:213-237: Z <- Z .* ((Gn*A').^e ./ max((Gp*A').^e + lambda, eps)), then H = Z*A.
+// A is the 0/1 label matrix of samples sorted by label (constrainednmf.m:163-170): right-multiplying by A' is a segmented
+// column sum (segment c = the columns that share Z column c), and Z*A copies Z column c to every column of its segment.
+// One block per segment; threadIdx.x walks K (coalesced), threadIdx.y strides the segment's columns.
+__global__ __launch_bounds__(256) void z_update_kernel(float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K,
+                                                       const long *seg, const float *lamZ, const uint8_t *fixZ, float inv_exp, int gather_only) {
+    __shared__ float red[2][4][64];
+    const long c = blockIdx.x, j0 = seg[c], j1 = seg[c + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + tx;
+        float z = 0.f;
+        if (gather_only) {
+            if (k < K) z = Z[k + (long)K * c];
+        } else {
+            float sn = 0.f, sp = 0.f;
+            const float zold = k < K ? Z[k + (long)K * c] : 0.f;                  // read by every wave BEFORE the barrier, written after it
+            if (k < K)
+                for (long j = j0 + ty; j < j1; j += 4) {
+                    sn += Gn[k + (long)K * j];
+                    if (Gp) sp += Gp[k + (long)K * j];
+                }
+            __syncthreads();
+            red[0][ty][tx] = sn; red[1][ty][tx] = sp;
+            __syncthreads();
+            if (k < K) {
+                float neg = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+                float pos = Gp ? red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]
+                               : (float)(Gpvec[k] * (double)(j1 - j0));          // W'*ones(m,n)*A' (constrainednmf.m:220)
+                z = zold;
+                if (!(fixZ && fixZ[k])) {
+                    if (inv_exp != 1.0f) { neg = powf(neg, inv_exp); pos = powf(pos, inv_exp); }
+                    z = z * (neg / fmaxf(pos + (lamZ ? lamZ[k] : 0.f), NMFX_EPS_F));
+                    if (ty == 0) Z[k + (long)K * c] = z;
+                }
+            }
+        }
+        if (k < K)
+            for (long j = j0 + ty; j < j1; j += 4) H[k + (long)K * j] = z;        // H = Z*A (constrainednmf.m:237)
+    }
+}
+nmfx_status z_update(hipStream_t st, float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long nz, const long *seg,
+                     const float *lamZ, const uint8_t *fixZ, float inv_exp, int gather_only) {
+    if (nz <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(z_update_kernel, dim3((unsigned)nz), dim3(64, 4), 0, st, Z, H, Gn, Gp, Gpvec, K, seg, lamZ, fixZ, inv_exp, gather_only);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// SortDictionary.m:33-42: per basis column, the last row index (1-based) whose cumulative sum is <= half the column total
+// (1 when there is none).  One 256-thread block per column; every thread owns a contiguous chunk of rows, the chunk sums are
+// scanned through LDS and each thread then walks its chunk, all in fp64 and in the input's own dtype.
+template <class T>
+__global__ __launch_bounds__(256) void center_of_gravity_kernel(const T *W, long m, long ld, int *cog) {
+    __shared__ double part[256];
+    __shared__ long best[256];
+    __shared__ double total_s;
+    const T *w = W + ld * blockIdx.x;
+    const int tid = threadIdx.x;
+    const long chunk = (m + 255) / 256, i0 = tid * chunk, i1 = i0 + chunk < m ? i0 + chunk : m;
+    double loc = 0.0;
+    for (long i = i0; i < i1; ++i) loc += (double)w[i];
+    part[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {   // 256-entry sequential exclusive scan: keeps the left-to-right order of cumsum (SortDictionary.m:35)
+        double run = 0.0;
+        for (int t = 0; t < 256; ++t) { const double v = part[t]; part[t] = run; run += v; }
+        total_s = run;
+    }
+    __syncthreads();
+    const double half = total_s / 2;
+    double cs = part[tid];
+    long last = 0;
+    for (long i = i0; i < i1; ++i) {
+        cs += (double)w[i];
+        if (cs <= half) last = i + 1;
+    }
+    __syncthreads();
+    best[tid] = last;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && best[tid + o] > best[tid]) best[tid] = best[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) cog[blockIdx.x] = best[0] > 0 ? (int)best[0] : 1;     // SortDictionary.m:38-42
+}
+nmfx_status center_of_gravity(hipStream_t st, const void *W, int is_f64, long m, int K, int *cog) {
+    if (K <= 0) return NMFX_OK;
+    if (is_f64) hipLaunchKernelGGL(center_of_gravity_kernel<double>, dim3(K), dim3(256), 0, st, (const double *)W, m, m, cog);
+    else hipLaunchKernelGGL(center_of_gravity_kernel<float>, dim3(K), dim3(256), 0, st, (const float *)W, m, m, cog);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// out(:, j) = in(:, order[j])  (by_rows == 0, SortDictionary.m:44)   |   out(k, :) = in(order[k], :)  (by_rows == 1, SortDictionary.m:46)
+template <class T>
+__global__ void permute_kernel(const T *in, T *out, long rows, long cols, const int *order, int by_rows) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const long r = idx % rows, c = idx / rows;
+    out[idx] = by_rows ? in[order[r] + rows * c] : in[r + rows * order[c]];
+}
+nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long rows, long cols, const int *order, int by_rows) {
+    const long count = rows * cols;
+    if (count <= 0) return NMFX_OK;
+    const dim3 g((unsigned)((count + 255) / 256)), b(256);
+    if (is_f64) hipLaunchKernelGGL(permute_kernel<double>, g, b, 0, st, (const double *)in, (double *)out, rows, cols, order, by_rows);
+    else hipLaunchKernelGGL(permute_kernel<float>, g, b, 0, st, (const float *)in, (float *)out, rows, cols, order, by_rows);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // cost = scale * sum(partials) + sum_c lamW[c%K]*l1W[c] + sum_k lamH[k]*l1H[k]      nmf.m:206-218
 __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials, int count, double scale, const double *l1W, int nW,
                                                           const float *lamW, const double *l1H, int K, const float *lamH, double *out,

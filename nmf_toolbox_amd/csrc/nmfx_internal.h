@@ -132,6 +132,10 @@ nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s)
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
                      const float *lamH, const uint8_t *fixH, float inv_exp);
+nmfx_status z_update(hipStream_t st, float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long nz, const long *seg,
+                     const float *lamZ, const uint8_t *fixZ, float inv_exp, int gather_only);
+nmfx_status center_of_gravity(hipStream_t st, const void *W, int is_f64, long m, int K, int *cog);
+nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long rows, long cols, const int *order, int by_rows);
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA = nullptr, const double *dotB = nullptr,
                         int ndot = 0, const double *minus = nullptr);   // + sum_k dotA[k]*dotB[k] - *minus

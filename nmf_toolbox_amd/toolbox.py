@@ -5,6 +5,10 @@
     W, H, cost = nmfsc(V, num_basis_elems, config)                nmfsc.m:1
     V_hat      = ReconstructFromDecomposition(W, H)               ReconstructFromDecomposition.m:1
     v, iters   = projfunc(s, k1, k2, nn)                          projfunc.m:1
+    W, H, cost = lnmf(V, num_basis_elems, config)                 lnmf.m:1            
+    W, H, cost = cnmfsc(V, num_basis_elems, context_len, config)  cnmfsc.m:1          (f1)
+    W, H, Z, A, cost = constrainednmf(V, labels, num_basis_elems, config)  constrainednmf.m:1   (f4)
+    W_sorted, H_sorted = SortDictionary(W, H)                     SortDictionary.m:1  (f4)
 
 Same argument meaning, defaults and error behaviour as the MATLAB functions (a MATLAB cell array is
 a Python list, a struct a dict; errors are ValueError carrying the reference's message).  This file
@@ -230,6 +234,127 @@ def lnmf(V, num_basis_elems, config=None, device=0):
     H0 = np.asarray(cfg["H_init"], dtype=np.float64)
     Wl, Hl, cost = _run_mu(_lib.load().nmfx_lnmf, V, [K], 1, cfg, [W0], [H0], _lib.DIV_KL, device)
     return Wl[0][:, :, 0], Hl[0], cost
+
+
+def _label_segments(labels, n):
+    """constrainednmf.m:147-170 -- host bookkeeping only: processed labels, the stable sort that makes equal labels contiguous
+    (unlabelled samples, label -1, first) and, instead of the dense 0/1 matrix A, the column ranges of its non-zeros."""
+    labels = np.asarray(labels).reshape(-1)
+    if labels.size != n:                                            # constrainednmf.m:98
+        raise ValueError("Length of the label vector not equal to number of samples. Length of label vector = %d; number of samples = %d"
+                         % (labels.size, n))
+    num_labeled = int(np.count_nonzero(labels > -1))               # constrainednmf.m:149
+    uniq, processed = np.unique(labels, return_inverse=True)      # constrainednmf.m:151/156 (1-based in MATLAB)
+    processed = processed.reshape(-1).astype(np.int64) + 1
+    if num_labeled < n:
+        processed -= 1                                              # constrainednmf.m:152-154
+        processed[processed == 0] = -1
+        num_classes = len(uniq) - 1
+    else:
+        num_classes = len(uniq)
+    sorted_idx = np.argsort(processed, kind="stable")              # constrainednmf.m:163
+    sorted_labels = processed[sorted_idx]
+    n_u = n - num_labeled
+    seg = list(range(n_u + 1))
+    for c in range(1, num_classes + 1):                            # rows of C, constrainednmf.m:166-169
+        seg.append(seg[-1] + int(np.count_nonzero(sorted_labels[n_u:] == c)))
+    return sorted_idx, np.asarray(seg, dtype=np.int64), n_u, num_classes
+
+
+def constrainednmf(V, labels, num_basis_elems, config=None, device=0):
+    """[W, H, Z, A, cost] = constrainednmf(V, labels, num_basis_elems, config)  -- constrainednmf.m:1.
+
+    The reference draws Z with rand() inside the function (constrainednmf.m:174); `config['Z_init']` (extension) supplies it
+    for reproducible runs.  A is returned dense like the reference's; config['nmfx_sparse_A'] = True returns scipy CSR instead."""
+    V = np.asarray(V, dtype=np.float64)
+    if V.ndim != 2:
+        raise ValueError("V must be a matrix")
+    m, n = V.shape
+    K = int(num_basis_elems)
+    cfg = dict(config) if config else {}
+    sorted_idx, seg, n_u, num_classes = _label_segments(labels, n)
+    rng = _rng(cfg)
+    if _isempty(cfg.get("W_init", None)):                          # constrainednmf.m:100-102
+        cfg["W_init"] = rng.rand(m, K)
+    for key in ("W_sparsity", "Z_sparsity"):                      # constrainednmf.m:103-108
+        cfg[key] = 0.0 if _isempty(cfg.get(key, None)) else float(cfg[key])
+    for key in ("W_fixed", "Z_fixed"):                            # constrainednmf.m:109-114
+        cfg[key] = False if _isempty(cfg.get(key, None)) else bool(cfg[key])
+    if "divergence" not in cfg:                                    # constrainednmf.m:115-117
+        cfg["divergence"] = "euclidean"
+    div = cfg["divergence"]
+    is_ab = div in ("ab_divergence", "ab")
+    cfg["alpha"] = float(cfg["alpha"]) if ("alpha" in cfg and is_ab) else 1.0    # constrainednmf.m:118-127
+    cfg["beta"] = float(cfg["beta"]) if ("beta" in cfg and is_ab) else 1.0
+    if cfg.get("maxiter", None) is None or cfg["maxiter"] <= 0:     # constrainednmf.m:133-135
+        cfg["maxiter"] = 100
+    if cfg.get("tolerance", None) is None or cfg["tolerance"] <= 0:  # constrainednmf.m:136-138
+        cfg["tolerance"] = 1e-3
+    if is_ab and cfg["alpha"] == 0 and cfg["beta"] == 0:             # constrainednmf.m:140-142
+        raise ValueError("alpha = 0 and beta = 0 is not supported at this time.")
+    if div not in _DIV_NMF:                                        # constrainednmf.m:204-205
+        raise ValueError("No update equations defined for cost function with divergence type " + str(div))
+    nz = n_u + num_classes
+    Z0 = cfg.get("Z_init", None)
+    Z0 = rng.rand(K, nz) if _isempty(Z0) else np.asarray(Z0, dtype=np.float64)   # constrainednmf.m:174
+    if Z0.shape != (K, nz):
+        raise ValueError("Z_init must be %d-by-%d" % (K, nz))
+    W0 = np.asarray(cfg["W_init"], dtype=np.float64)
+    if W0.shape != (m, K):
+        raise ValueError("W_init must be %d-by-%d" % (m, K))
+    Vs = np.asfortranarray(V[:, sorted_idx])                       # constrainednmf.m:164
+    W0 = np.asfortranarray(W0)
+    Z0 = np.asfortranarray(Z0)
+    maxiter = int(cfg["maxiter"])
+    Wout, Hout, Zout, cost = np.zeros((m, K), order="F"), np.zeros((K, n), order="F"), np.zeros((K, nz), order="F"), np.zeros(maxiter)
+    one = np.asarray([K], dtype=np.int32)
+    lw, lz = np.asarray([cfg["W_sparsity"]]), np.asarray([cfg["Z_sparsity"]])
+    fw, fz = np.asarray([cfg["W_fixed"]], dtype=np.uint8), np.asarray([cfg["Z_fixed"]], dtype=np.uint8)
+    p = _lib.Problem()
+    p.m, p.n, p.K_total, p.T, p.dtype = m, n, K, 1, _lib.F64
+    p.V, p.W_init, p.H_init = _fptr(Vs), _fptr(W0), None
+    p.divergence, p.alpha, p.beta = _DIV_NMF[div], cfg["alpha"], cfg["beta"]
+    p.num_sources, p.K_s = 1, _fptr(one)
+    p.W_sparsity, p.H_sparsity, p.W_fixed, p.H_fixed = _fptr(lw), _fptr(lz), _fptr(fw), _fptr(fz)
+    p.maxiter = maxiter
+    p.tolerance = -1.0 if cfg.get("nmfx_disable_stop", False) else float(cfg["tolerance"])
+    p.device, p.path = int(device), int(cfg.get("nmfx_path", 0))
+    r = _lib.Result()
+    r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
+    _lib.check(_lib.load().nmfx_constrainednmf(C.byref(p), _fptr(seg), nz, _fptr(Z0), C.byref(r), _fptr(Zout)))
+    # constrainednmf.m:259-267: A (and with it H = Z*A) goes back to the original sample order
+    H = np.empty((K, n))
+    H[:, sorted_idx] = Hout
+    zcol = np.repeat(np.arange(nz), np.diff(seg))                  # Z column of every SORTED sample
+    rows, cols = zcol, sorted_idx
+    if cfg.get("nmfx_sparse_A", False):
+        import scipy.sparse as sp
+        A = sp.csr_matrix((np.ones(n), (rows, cols)), shape=(nz, n))
+    else:
+        A = np.zeros((nz, n))
+        A[rows, cols] = 1.0
+    return np.array(Wout), H, np.array(Zout), A, cost[: r.cost_len].copy()
+
+
+def SortDictionary(W, H=None, device=0):
+    """[W_sorted, H_sorted] = SortDictionary(W, H)  -- SortDictionary.m:1.  H_sorted is None when H is not given."""
+    W = np.asfortranarray(W, dtype=np.float64)
+    if W.ndim != 2:
+        raise ValueError("SortDictionary does not work for CNMF bases")   # SortDictionary.m:3
+    m, K = W.shape
+    Ws = np.zeros((m, K), order="F")
+    Hf = Hs = None
+    n = 0
+    if H is not None:
+        Hf = np.asfortranarray(H, dtype=np.float64)
+        if Hf.ndim != 2 or Hf.shape[0] != K:
+            raise ValueError("H must have %d rows" % K)
+        n = Hf.shape[1]
+        Hs = np.zeros((K, n), order="F")
+    order = np.zeros(K, dtype=np.int32)
+    _lib.check(_lib.load().nmfx_sort_dictionary(m, K, n, _lib.F64, _fptr(W), _fptr(Hf) if Hf is not None else None, _fptr(Ws),
+                                                _fptr(Hs) if Hs is not None else None, _fptr(order), int(device)))
+    return Ws, Hs
 
 
 def nmfsc(V, num_basis_elems, config=None, device=0, info=None):

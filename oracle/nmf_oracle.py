@@ -749,3 +749,144 @@ def lnmf(V, num_basis_elems, config=None, rng=None):
             if it > 1 and cost[it - 1] <= cost[it - 2] and cost[it - 2] - cost[it - 1] <= tol:   # lnmf.m:84-86
                 break
     return W, H, cost                                     # cost is NOT trimmed (lnmf.m:85-86 only breaks)
+
+
+# --------------------------------------------------------------------------------------
+# constrainednmf.m:92-267   
+# --------------------------------------------------------------------------------------
+def constrainednmf(V, labels, num_basis_elems, config=None, rng=None):
+    """constrainednmf.m:1.  Returns (W, H, Z, A, cost).  The reference draws Z with rand() inside the function
+    (constrainednmf.m:174); config['Z_init'] overrides that draw so seeded comparisons are possible (test aid)."""
+    V = np.asarray(V, dtype=np.float64)
+    m, n = V.shape                                        # constrainednmf.m:96
+    labels = np.asarray(labels).reshape(-1)
+    if labels.size != n:                                  # constrainednmf.m:98
+        raise ValueError("Length of the label vector not equal to number of samples. Length of label vector = %d; number of samples = %d"
+                         % (labels.size, n))
+    K = int(num_basis_elems)
+    cfg = dict(config) if config is not None else {}
+    rng = rng if rng is not None else np.random.RandomState(0)
+
+    def empty(key):
+        return cfg.get(key, None) is None or np.size(cfg[key]) == 0
+
+    if empty("W_init"):                                   # constrainednmf.m:100-102
+        cfg["W_init"] = rng.rand(m, K)
+    lamW = 0.0 if empty("W_sparsity") else float(cfg["W_sparsity"])        # 103-105
+    lamZ = 0.0 if empty("Z_sparsity") else float(cfg["Z_sparsity"])        # 106-108
+    W_fixed = False if empty("W_fixed") else bool(cfg["W_fixed"])          # 109-111
+    Z_fixed = False if empty("Z_fixed") else bool(cfg["Z_fixed"])          # 112-114
+    div = cfg.get("divergence", "euclidean")              # 115-117
+    is_ab = div in ("ab_divergence", "ab")
+    alpha = float(cfg["alpha"]) if ("alpha" in cfg and is_ab) else 1.0     # 118-122
+    beta = float(cfg["beta"]) if ("beta" in cfg and is_ab) else 1.0        # 123-127
+    use_dual = alpha == 0                                 # 128-132
+    maxiter = cfg.get("maxiter", None)
+    maxiter = 100 if (maxiter is None or maxiter <= 0) else int(maxiter)   # 133-135
+    tol = cfg.get("tolerance", None)
+    tol = 1e-3 if (tol is None or tol <= 0) else float(tol)                # 136-138
+    if is_ab and alpha == 0 and beta == 0:                # 140-142
+        raise ValueError("alpha = 0 and beta = 0 is not supported at this time.")
+
+    W = _col_normalize(np.array(cfg["W_init"], dtype=np.float64))          # 144-145
+
+    num_labeled = int(np.count_nonzero(labels > -1))      # 149
+    uniq, inv = np.unique(labels, return_inverse=True)    # 151 / 156 (MATLAB's third output is 1-based)
+    processed = inv.reshape(-1).astype(np.int64) + 1
+    if num_labeled < n:                                   # 150-154
+        processed = processed - 1
+        processed[processed == 0] = -1
+        num_classes = len(uniq) - 1
+    else:                                                 # 155-158
+        num_classes = len(uniq)
+    sorted_idx = np.argsort(processed, kind="stable")     # 163 (MATLAB sort is stable)
+    sorted_labels = processed[sorted_idx]
+    V = V[:, sorted_idx]                                  # 164
+    n_u = n - num_labeled
+    Cm = np.zeros((num_classes, num_labeled))             # 166-169
+    for samp in range(n_u, n):
+        Cm[sorted_labels[samp] - 1, samp - n_u] = 1.0
+    A = np.block([[np.eye(n_u), np.zeros((n_u, num_labeled))],
+                  [np.zeros((num_classes, n_u)), Cm]])    # 170
+    nz = n + num_classes - num_labeled
+    Z = rng.rand(K, nz) if empty("Z_init") else np.array(cfg["Z_init"], dtype=np.float64)   # 174
+    H = Z @ A                                             # 177
+    V_hat = reconstruct_from_decomposition(W, H)          # 179
+    cost = np.zeros(maxiter)                              # 181
+    ones_mn, ones_nm = np.ones((m, n)), np.ones((n, m))
+    n_run = maxiter
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for it in range(1, maxiter + 1):                  # 183
+            if not W_fixed:                               # 185-209: the W step of nmf.m
+                if div == "euclidean":
+                    neg = V @ H.T + W * _ddiag(H @ V_hat.T @ W)[None, :]
+                    pos = V_hat @ H.T + W * _ddiag(H @ V.T @ W)[None, :]
+                elif div in ("kl_divergence", "kl"):
+                    neg = (V / V_hat) @ H.T + W * _ddiag(H @ ones_nm @ W)[None, :]
+                    pos = ones_mn @ H.T + W * _ddiag(H @ (V.T / V_hat.T) @ W)[None, :]
+                elif div in ("is_divergence", "is"):
+                    neg = (V / V_hat ** 2) @ H.T + W * _ddiag(H @ (ones_nm / V_hat.T) @ W)[None, :]
+                    pos = (ones_mn / V_hat) @ H.T + W * _ddiag(H @ (V.T / V_hat.T ** 2) @ W)[None, :]
+                elif is_ab:
+                    if use_dual:
+                        neg = ((V ** (alpha - 1) * V_hat ** beta) @ H.T + W * _ddiag(H @ V.T ** (alpha + beta - 1) @ W)[None, :]) ** (1 / beta)
+                        pos = (V ** (alpha + beta - 1) @ H.T + W * _ddiag(H @ (V ** (alpha - 1) * V_hat ** beta).T @ W)[None, :]) ** (1 / beta)
+                    else:
+                        neg = ((V ** alpha * V_hat ** (beta - 1)) @ H.T + W * _ddiag(H @ V_hat.T ** (alpha + beta - 1) @ W)[None, :]) ** (1 / alpha)
+                        pos = (V_hat ** (alpha + beta - 1) @ H.T + W * _ddiag(H @ (V ** alpha * V_hat ** (beta - 1)).T @ W)[None, :]) ** (1 / alpha)
+                else:                                     # 204-205
+                    raise ValueError("No update equations defined for cost function with divergence type " + str(div))
+                W = W * (neg / np.fmax(pos + lamW, EPS))  # 207
+                W = _col_normalize(W)                     # 208
+            V_hat = reconstruct_from_decomposition(W, H)  # 210
+            if not Z_fixed:                               # 213-236
+                if div == "euclidean":
+                    neg = W.T @ V @ A.T
+                    pos = W.T @ V_hat @ A.T
+                elif div in ("kl_divergence", "kl"):
+                    neg = W.T @ (V / V_hat) @ A.T
+                    pos = W.T @ ones_mn @ A.T
+                elif div in ("is_divergence", "is"):
+                    neg = W.T @ (V / V_hat ** 2) @ A.T
+                    pos = W.T @ (ones_mn / (W @ H)) @ A.T
+                elif is_ab:
+                    if use_dual:
+                        neg = (W.T @ (V ** (alpha - 1) * V_hat ** beta) @ A.T) ** (1 / beta)
+                        pos = (W.T @ V ** (alpha + beta - 1) @ A.T) ** (1 / beta)
+                    else:
+                        # constrainednmf.m:229 reads  W' * V.^alpha .* V_hat.^(beta-1) * A'  -- by MATLAB precedence that is
+                        # ((W'*V.^alpha) .* V_hat.^(beta-1)) * A', a K x n times m x n element-wise product: a dimension error
+                        raise ValueError("Matrix dimensions must agree.")
+                else:
+                    raise ValueError("No update equations defined for cost function with divergence type " + str(div))
+                Z = Z * (neg / np.fmax(pos + lamZ, EPS))  # 235
+            H = Z @ A                                     # 237
+            V_hat = reconstruct_from_decomposition(W, H)  # 238
+            c = _cost(div, V, V_hat, alpha, beta)         # 241-250
+            cost[it - 1] = c + lamW * np.sum(np.abs(W)) + lamZ * np.sum(np.abs(Z))   # 251
+            if it > 1 and cost[it - 1] < cost[it - 2] and cost[it - 2] - cost[it - 1] < tol:   # 254-257
+                n_run = it
+                break
+    cost = cost[:n_run]
+    A_temp = A.copy()                                     # 263-266
+    for samp in range(n):
+        A[:, sorted_idx[samp]] = A_temp[:, samp]
+    H = Z @ A                                             # 267
+    return W, H, Z, A, cost
+
+
+# --------------------------------------------------------------------------------------
+# SortDictionary.m:25-49
+# --------------------------------------------------------------------------------------
+def sort_dictionary(W, H=None):
+    W = np.asarray(W, dtype=np.float64)
+    K = W.shape[1]                                        # SortDictionary.m:31
+    W_sum = np.cumsum(W, axis=0)                          # 33
+    cog = np.zeros(K, dtype=np.int64)
+    for j in range(K):                                    # 35-42
+        hit = np.nonzero(W_sum[:, j] <= W_sum[-1, j] / 2)[0]
+        cog[j] = 1 if hit.size == 0 else hit[-1] + 1
+    order = np.argsort(cog, kind="stable")                # 43
+    W_sorted = W[:, order]                                # 44
+    H_sorted = None if H is None else np.asarray(H, dtype=np.float64)[order, :]   # 45-47
+    return W_sorted, H_sorted

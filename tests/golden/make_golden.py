@@ -88,6 +88,20 @@ def main():
     save("projfunc", S=S, k1=np.array([k1]), V=np.array(outs), iters=np.array(its, dtype=np.int32), s_signed=sg, v_signed=vs, it_signed=np.array([it_s]))
     Wr, Hr = synth(40, 60, 5, T=3)[1:]
     save("reconstruct", W=Wr, H=Hr, V_hat=O.reconstruct_from_decomposition(Wr, Hr), V_hat_2d=O.reconstruct_from_decomposition(Wr[:, :, 0], Hr))
+    # --- constrainednmf (labels -1 = unlabelled) and SortDictionary ----------------------------------
+    Vk, Wk0, _ = synth(64, 120, 6)
+    labels = np.random.RandomState(11).randint(-1, 4, size=120)
+    labels[labels >= 0] = labels[labels >= 0] * 3 + 2          # non-consecutive class ids 2, 5, 8, 11
+    nz = int(np.count_nonzero(labels == -1)) + 4
+    Z0 = np.fmax(np.random.RandomState(12).rand(6, nz), 2.0 ** -52)
+    for div in ("euclidean", "kl"):
+        W, H, Z, A, cost = O.constrainednmf(Vk, labels, 6, dict(divergence=div, W_init=Wk0, Z_init=Z0, maxiter=20, tolerance=1e-12, Z_sparsity=0.05))
+        save("constrainednmf_" + div, labels=labels, Z0=Z0, W=W, H=H, Z=Z, cost=cost, A_nnz_cols=np.argmax(A, axis=0))
+    Wd = np.abs(np.random.RandomState(13).randn(50, 9)) * np.exp(-0.5 * ((np.arange(50)[:, None] - np.array([40, 5, 22, 22, 47, 1, 30, 12, 22])[None, :]) / 4.0) ** 2)
+    Wd[:, 3] = Wd[:, 2]                                          # a tie: stable sort keeps 2 before 3
+    Hd = np.random.RandomState(14).rand(9, 20)
+    Ws, Hs = O.sort_dictionary(Wd, Hd)
+    save("sort_dictionary", W=Wd, H=Hd, W_sorted=Ws, H_sorted=Hs)
 
 
 if __name__ == "__main__":

@@ -246,3 +246,74 @@ def test_lnmf_untrimmed_cost_and_stop(gpu_lib):
     c = gpu_lib.lnmf(V, 8, cfg)[2]
     cr = O.lnmf(V, 8, cfg)[2]
     assert len(c) == 60 and abs(np.count_nonzero(c) - np.count_nonzero(cr)) <= 1 and np.count_nonzero(cr) < 60   # zeros after the stop (lnmf.m:84-86)
+
+
+# ---- constrainednmf + SortDictionary ---------------------------------------------------------------
+def _labels(n, n_classes, frac_unlabelled, seed):
+    rs = np.random.RandomState(seed)
+    lab = rs.randint(0, n_classes, size=n) * 2 + 3          # non-consecutive ids
+    lab[rs.rand(n) < frac_unlabelled] = -1
+    return lab
+
+
+@pytest.mark.parametrize("div,cfgx", [("euclidean", {}), ("kl", {}), ("is", {}), ("kl", dict(Z_sparsity=0.1, W_sparsity=0.05)),
+                                       ("euclidean", dict(Z_fixed=True)), ("kl", dict(W_fixed=True))])
+@pytest.mark.parametrize("m,n,K,path", [(96, 200, 7, 0), (256, 384, 64, 2), (256, 384, 64, 1)])
+def test_constrainednmf_matches_oracle(gpu_lib, div, cfgx, m, n, K, path):
+    from oracle import nmf_oracle as O
+    if path == 2 and div == "is":
+        pytest.skip("the fused kernels cover kl / euclidean")
+    V, W0, _ = synth(m, n, K)
+    lab = _labels(n, 5, 0.3, 5)
+    nz = int(np.count_nonzero(lab == -1)) + len(np.unique(lab[lab >= 0]))
+    Z0 = np.fmax(np.random.RandomState(9).rand(K, nz), 2.0 ** -52)
+    cfg = dict(divergence=div, W_init=W0, Z_init=Z0, maxiter=15, tolerance=1e-12, **cfgx)
+    W, H, Z, A, cost = gpu_lib.constrainednmf(V, lab, K, dict(cfg, nmfx_path=path))
+    W0_, H0_, Z0_, A0_, cost0 = O.constrainednmf(V, lab, K, cfg)
+    assert np.array_equal(A, A0_)
+    assert rel_fro(W, W0_) <= TOL and rel_fro(H, H0_) <= TOL and rel_fro(Z, Z0_) <= TOL, (rel_fro(W, W0_), rel_fro(H, H0_), rel_fro(Z, Z0_))
+    assert len(cost) == len(cost0) and rel_fro(cost, cost0) <= (1e-5 if div == "is" else 1e-6)
+    assert rel_fro(H, Z @ A) <= 1e-6
+
+
+def test_constrainednmf_edge_cases(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(64, 90, 6)
+    # nothing labelled: constrainednmf == nmf (A = I)
+    W, H, Z, A, cost = gpu_lib.constrainednmf(V, -np.ones(90, dtype=int), 6, dict(W_init=W0, Z_init=H0, maxiter=10, tolerance=1e-12))
+    Wn, Hn, costn = gpu_lib.nmf(V, 6, dict(W_init=W0, H_init=H0, maxiter=10, tolerance=1e-12))
+    assert np.array_equal(A, np.eye(90)) and rel_fro(W, Wn) < 1e-6 and rel_fro(H, Hn) < 1e-6 and rel_fro(cost, costn) < 1e-6
+    # everything labelled, one class: Z is K x 1
+    W, H, Z, A, cost = gpu_lib.constrainednmf(V, np.full(90, 4), 6, dict(divergence="kl", W_init=W0, Z_init=H0[:, :1], maxiter=8, tolerance=1e-12))
+    Wo, Ho, Zo, Ao, costo = O.constrainednmf(V, np.full(90, 4), 6, dict(divergence="kl", W_init=W0, Z_init=H0[:, :1], maxiter=8, tolerance=1e-12))
+    assert Z.shape == (6, 1) and rel_fro(W, Wo) <= TOL and rel_fro(Z, Zo) <= TOL and rel_fro(cost, costo) <= 1e-6
+    # alpha-beta: dual form runs (2 iterations: it degenerates like nmf's), alpha ~= 0 is refused with the reference line
+    lab = _labels(90, 3, 0.5, 1)
+    nz = int(np.count_nonzero(lab == -1)) + len(np.unique(lab[lab >= 0]))
+    cfg = dict(divergence="ab", alpha=0.0, beta=1.0, W_init=W0, Z_init=H0[:, :nz], maxiter=2, tolerance=1e-12)
+    got, ref = gpu_lib.constrainednmf(V, lab, 6, cfg), O.constrainednmf(V, lab, 6, cfg)
+    assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[2], ref[2]) <= TOL
+    with pytest.raises(Exception, match="constrainednmf.m:229"):
+        gpu_lib.constrainednmf(V, lab, 6, dict(divergence="ab", alpha=0.5, beta=0.5, maxiter=2))
+    with pytest.raises(ValueError, match="Length of the label vector"):
+        gpu_lib.constrainednmf(V, np.zeros(5), 6)
+    with pytest.raises(ValueError, match="alpha = 0 and beta = 0"):
+        gpu_lib.constrainednmf(V, lab, 6, dict(divergence="ab", alpha=0, beta=0))
+    W, H, Z, A, cost = gpu_lib.constrainednmf(V, lab, 6, dict(seed=4, maxiter=0))      # defaults: rand inits, 100 iterations, 1e-3
+    assert len(cost) <= 100 and Z.shape == (6, nz) and np.all(np.diff(cost) <= 1e-6 * cost[0])
+
+
+def test_sort_dictionary_matches_oracle(gpu_lib):
+    from oracle import nmf_oracle as O
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "sort_dictionary.npz"))
+    Ws, Hs = gpu_lib.SortDictionary(g["W"], g["H"])
+    assert np.array_equal(Ws, g["W_sorted"]) and np.array_equal(Hs, g["H_sorted"])
+    for m, K, seed in [(513, 40, 0), (4096, 300, 1), (7, 3, 2), (1, 5, 3)]:
+        rs = np.random.RandomState(seed)
+        W = np.abs(rs.randn(m, K)) * (rs.rand(m, K) < 0.4)
+        W[:, K // 2] = 0.0                                  # an all-zero atom: every cumsum <= 0, centre = m
+        H = rs.rand(K, 33)
+        Ws, Hs = gpu_lib.SortDictionary(W, H)
+        Wo, Ho = O.sort_dictionary(W, H)
+        assert np.array_equal(Ws, Wo) and np.array_equal(Hs, Ho)
+    assert gpu_lib.SortDictionary(g["W"])[1] is None

@@ -175,6 +175,47 @@ def test_reconstruct_golden():
     assert rel_fro(W.transpose(0, 2, 1).reshape(m, T * K) @ Hst, g["V_hat"]) < 1e-14
 
 
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+def test_constrainednmf_golden(div):
+    g = load("constrainednmf_" + div)
+    V, W0, _ = synth(64, 120, 6)
+    W, H, Z, A, cost = O.constrainednmf(V, g["labels"], 6, dict(divergence=div, W_init=W0, Z_init=g["Z0"], maxiter=20, tolerance=1e-12, Z_sparsity=0.05))
+    assert rel_fro(W, g["W"]) < 1e-12 and rel_fro(H, g["H"]) < 1e-12 and rel_fro(Z, g["Z"]) < 1e-12 and rel_fro(cost, g["cost"]) < 1e-12
+    assert np.array_equal(np.argmax(A, axis=0), g["A_nnz_cols"]) and np.all(A.sum(0) == 1) and np.allclose(H, Z @ A)
+    # samples of one class share their encoding (the point of the constraint), unlabelled ones do not
+    lab = g["labels"]
+    for c in np.unique(lab[lab >= 0]):
+        cols = np.nonzero(lab == c)[0]
+        assert np.all(H[:, cols] == H[:, cols[:1]])
+    assert np.all(np.diff(cost) <= 1e-9 * cost[0])
+
+
+def test_constrainednmf_reduces_to_nmf_when_nothing_is_labelled():
+    """All labels -1: A = I, Z = H, and constrainednmf.m:183-258 is nmf.m:143-225 -- which pins this restatement to the nmf oracle."""
+    V, W0, H0 = synth(48, 70, 5)
+    for div in ("euclidean", "kl", "is"):
+        cfg = dict(divergence=div, W_init=W0, maxiter=15, tolerance=1e-12, W_sparsity=0.02)
+        W, H, Z, A, cost = O.constrainednmf(V, -np.ones(70, dtype=int), 5, dict(cfg, Z_init=H0, Z_sparsity=0.03))
+        Wn, Hn, costn = O.nmf(V, 5, dict(cfg, H_init=H0, H_sparsity=0.03))
+        assert np.array_equal(A, np.eye(70)) and np.array_equal(H, Z)
+        assert rel_fro(W, Wn) < 1e-12 and rel_fro(H, Hn) < 1e-12 and rel_fro(cost, costn) < 1e-12
+    with pytest.raises(ValueError, match="Length of the label vector"):
+        O.constrainednmf(V, np.zeros(3), 5)
+    with pytest.raises(ValueError, match="Matrix dimensions must agree"):      # constrainednmf.m:229 is ill-formed for alpha ~= 0
+        O.constrainednmf(V, np.zeros(70, dtype=int), 5, dict(divergence="ab", alpha=0.5, beta=0.5, maxiter=1))
+
+
+def test_sort_dictionary_golden():
+    g = load("sort_dictionary")
+    Ws, Hs = O.sort_dictionary(g["W"], g["H"])
+    assert np.array_equal(Ws, g["W_sorted"]) and np.array_equal(Hs, g["H_sorted"])
+    # hand-checkable: cumsum <= half-total, last index (SortDictionary.m:36-41)
+    W = np.array([[1.0, 0.0, 5.0], [1.0, 0.0, 1.0], [1.0, 4.0, 1.0], [1.0, 0.0, 1.0]])      # cog = 2, 2, 1 (none <= 4 -> 1)
+    Ws, Hs = O.sort_dictionary(W, np.array([[1.0], [2.0], [3.0]]))
+    assert np.array_equal(Ws, W[:, [2, 0, 1]]) and np.array_equal(Hs.ravel(), [3.0, 1.0, 2.0])
+    assert O.sort_dictionary(W)[1] is None
+
+
 def test_matlab_semantics():
     V, W0, H0 = synth(24, 30, 3)
     with pytest.raises(ValueError, match="No update equations"):
