@@ -116,6 +116,21 @@ nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r);
 /* [W,H,cost] = cnmfsc(V, num_basis_elems, context_len, config) -- replaces cnmfsc.m:1 (hot loop cnmfsc.m:155-277).
  * Uses sc_W_sparsity / sc_H_sparsity, T = context_len, W_fixed[0] / H_fixed[0]; result.tries_W needs maxiter*T entries. */
 nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r);
+/* nmfsc on DEVICE buffers, optionally on a column shard per rank ("multi-GPU nmfsc, distributed projfunc
+ * reductions").  libnmfx does not link RCCL: every cross-rank sum goes through the caller's all-reduce callback, which must
+ * reduce `count` elements of `dtype` (NMFX_F32 / NMFX_F64) at dev_ptr IN PLACE over all ranks, ordered after the work already
+ * queued on `stream`, and return 0.  The same sequence of calls is made on every rank.  allreduce == NULL means one GPU.
+ *   V  m x n_local fp32, already divided by the GLOBAL max(V(:)) (nmfsc.m:62 -- one MAX all-reduce the caller does itself)
+ *   W  m x K (replicated, identical on every rank), H  K x n_local: updated in place
+ *   p->n = n_local; n_total = global column count (the H sparseness target of nmfsc.m:102-106 is defined on whole rows);
+ *   p->V / W_init / H_init / dtype are ignored; result.W / result.H are ignored, cost / tries_* / stepsize_* are filled.
+ * Per outer iteration: ONE large all-reduce of [V*H' | H*H'] (m*K + K*K floats), an 8-byte sum per objective evaluation
+ * (nmfsc.m:161,212,238) and, when H is projected, 4*K doubles per reduction of projfunc.m:22-53.  Column shards need the
+ * fused kernels: K in {64,128,256}, m % 128 == 0, n_local % 128 == 0 (NMFX_ERR_UNSUPPORTED otherwise). */
+typedef enum { NMFX_REDUCE_SUM = 0, NMFX_REDUCE_MAX = 1 } nmfx_reduce_op;
+typedef int32_t (*nmfx_allreduce_fn)(void *ctx, void *dev_ptr, int64_t count, int32_t dtype, int32_t op, void *stream);
+nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,
+                           nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r);
 /* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
                              const void *H, void *V_hat, int32_t device);

@@ -23,7 +23,7 @@ EXPORTS = [
     "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_defer_hstep_finish", "nmfx_engine_hstep_finish", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
-    "nmfx_engine_set_constraint",
+    "nmfx_engine_set_constraint", "nmfx_nmfsc_dev",
 ]
 
 
@@ -63,6 +63,9 @@ class EngineDesc(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)   # nmfx_allreduce_fn
+REDUCE_SUM, REDUCE_MAX = 0, 1
+
 _lib = None
 
 
@@ -90,6 +93,7 @@ def load():
     lib.nmfx_constrainednmf.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(Result), C.c_void_p]
     lib.nmfx_sort_dictionary.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_engine_set_constraint.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.nmfx_nmfsc_dev.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.POINTER(Result)]
     lib.nmfx_reconstruct.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_projfunc.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_engine_workspace_bytes.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]

@@ -977,36 +977,59 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
 }
 
 // 0.5*||V - V_hat||^2 from the per-block partials of an EPI_COST GEMM (host double)
-nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out) {
+nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out, Comm *comm = nullptr) {
     TRY(finish_cost(st, partials, count, 0.5, nullptr, 0, nullptr, nullptr, 0, nullptr, cost_dev));
+    if (comm && comm->active()) TRY(comm->allreduce(cost_dev, 1, NMFX_F64, NMFX_REDUCE_SUM));   // column shards: the objective is a sum over ranks
     NMFX_HIP(hipMemcpyAsync(out, cost_dev, sizeof(double), hipMemcpyDeviceToHost, st));
     NMFX_HIP(hipStreamSynchronize(st));
     return NMFX_OK;
 }
 
+// device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
+struct ScDev {
+    const float *V;      // m x n_local, already divided by the GLOBAL max (nmfsc.m:62)
+    float *W, *H;        // in/out
+    long n_total;        // global column count (L1s, nmfsc.m:102-106, is defined on whole rows of H)
+    Comm comm;
+    hipStream_t st;
+};
+
 // nmfsc.m:57-245
-nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
-    TRY(validate_problem(p, r, true));
+nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullptr) {
+    if (!dev) TRY(validate_problem(p, r, true));
     if (p->T != 1) { set_error("nmfsc: T must be 1"); return NMFX_ERR_INVALID; }
     const long m = p->m, n = p->n;
     const int K = p->K_total;
     const size_t mn = (size_t)m * n, mK = (size_t)m * K, Kn = (size_t)K * n;
+    Comm nocomm{};
+    Comm &comm = dev ? dev->comm : nocomm;
     double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62
-    if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    if (dev) { vmin = 0; vmax = 1; }
+    else if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
     TRY(check_device(p->device));
-    hipStream_t st = nullptr;
+    hipStream_t st = dev ? dev->st : nullptr;
+    const long n_total = dev ? dev->n_total : n;
     double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity;
     double L1a = 0, L1s = 0;
     if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // nmfsc.m:89-93
-    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // nmfsc.m:102-106
+    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n_total) - (std::sqrt((double)n_total) - 1) * sH; }   // nmfsc.m:102-106
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
-    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch;
-    TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W.alloc(mK * 4)); TRY(Wn.alloc(mK * 4)); TRY(Hk.alloc(Kn * 4)); TRY(HT.alloc(Kn * 4));
+    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch, pfv, pff, pfr;
+    const bool fast = p->path != 1 && fused_supported(K) && m % 128 == 0 && n % 128 == 0;
+    if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
+    if (comm.active() && !fast) {
+        set_error("nmfsc on column shards runs on the fused kernels only: K in {64,128,256}, m %% 128 == 0, n_local %% 128 == 0");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (!dev) TRY(V.alloc(mn * 4));
+    if (!fast) TRY(Vh.alloc(mn * 4));
+    if (comm.active() && sH > 0) { TRY(pfv.alloc(Kn * 8)); TRY(pff.alloc(Kn)); TRY(pfr.alloc(sizeof(double) * 6 * K + 64)); }
+    TRY(W.alloc(mK * 4)); TRY(Wn.alloc(mK * 4)); TRY(Hk.alloc(Kn * 4)); TRY(HT.alloc(Kn * 4));
     TRY(HnT.alloc(Kn * 4));
-    const size_t gmax = Kn > mK ? Kn : mK;
+    const size_t gmax = (Kn > mK ? Kn : mK) + (size_t)K * K;   // + K*K: [V*H' | H*H'] travel as ONE all-reduce on column shards
     TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));
     TRY(stage.alloc(STAGE_ELEMS * 8));
     const int nparts = (int)gemm_grid_blocks(m, n);
@@ -1014,13 +1037,25 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n);
     if (sb2 > sb) sb = sb2;
     TRY(scratch.alloc(sb));
-    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
-    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mK, 1.0, stage, STAGE_ELEMS));
-    TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    if (!dev) {
+        TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
+        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mK, 1.0, stage, STAGE_ELEMS));
+        TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    } else {
+        NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mK * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipMemcpyAsync(Hk.p, dev->H, Kn * 4, hipMemcpyDeviceToDevice, st));
+    }
+    const float *Vp = dev ? dev->V : Vp;
     float *Wd = W.as<float>(), *Wnew = Wn.as<float>(), *HTd = HT.as<float>(), *HnewT = HnT.as<float>();
+    // rows of H (stored as the columns of an n_local x K transposed copy) through projfunc; on column shards every reduction of
+    // projfunc.m:22-53 is a sum over ranks
+    auto project_H = [&](float *HxT) -> nmfx_status {
+        if (comm.active()) return projfunc_cols_dist(st, HxT, n, K, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>());
+        return projfunc_cols(st, HxT, n, K, L1s, 1.0, 1, nullptr);
+    };
     TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
-    if (sW > 0) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96
-    if (sH > 0) TRY(projfunc_cols(st, HTd, n, K, L1s, 1.0, 1, nullptr));    // nmfsc.m:107-109
+    if (sW > 0) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
+    if (sH > 0) TRY(project_H(HTd));                                        // nmfsc.m:107-109
 
     // V_hat = Wx * Hx (Hx given transposed, n x K) with the residual objective; returns 0.5*||V - V_hat||^2
     auto recon_obj = [&](const float *Wx, const float *HxT, double *obj) -> nmfx_status {
@@ -1029,7 +1064,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         g.M = m; g.N = n; g.Kc = K;
         g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         g.B = OpView{HxT, nullptr, n, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-        g.C = Vh.as<float>(); g.ldc = m; g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = V.as<float>(); g.ldv = m;
+        g.C = Vh.as<float>(); g.ldc = m; g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = Vp; g.ldv = m;
         g.cost_partials = part.as<double>(); g.splitk = 1;
         long blocks = 0;
         TRY(launch_gemm(st, g, &blocks));
@@ -1060,8 +1095,6 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     //   objective         0.5*||V - W*H||^2          fused cost-only pass (S = W*H in registers)
     //   W'*V, V*H'        fused H-step / W-step passes with R = V
     //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
-    const bool fast = p->path != 1 && fused_supported(K) && m % 128 == 0 && n % 128 == 0;
-    if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
     DevBuf WTb, slabs, Gb, Denb, KKb, fparts;
     int nsplit_w = 1, isplit_h = 1;
     if (fast) {
@@ -1075,10 +1108,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
         f.cost_partials = fparts.as<double>();
         TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
-        return read_obj(st, fparts.as<double>(), (int)((m / 128) * nsplit_w), costd.as<double>(), obj);
+        return read_obj(st, fparts.as<double>(), (int)((m / 128) * nsplit_w), costd.as<double>(), obj, &comm);
     };
     auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
         GemmParams g;
@@ -1091,7 +1124,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = V.as<float>(); f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = m / isplit_h;
+        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = m / isplit_h;
         f.out = isplit_h == 1 ? Gb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
         TRY(launch_fused(st, f, isplit_h, false, 0, true, 0));
         if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Gb.as<float>(), 0));
@@ -1099,17 +1132,19 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         return kk_gemm(K, n, K, OpView{KKb.as<float>(), nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                        OpView{Hx, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, Denb.as<float>(), K);
     };
-    // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx')
+    // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx'); N_ has room for K*K more floats: [N | Hx*Hx'] is what column shards sum
     auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
+        float *KK = N_ + mK;
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
         f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
         TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
         if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));
-        TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+        TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KK, K));
+        if (comm.active()) TRY(comm.allreduce(N_, (long)(mK + (size_t)K * K), NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
         return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                       OpView{KKb.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
+                       OpView{KK, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
     };
     double stepH = 1.0, stepW = 1.0;   // nmfsc.m:133-134
     if (fast) {
@@ -1134,7 +1169,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
                     for (;;) {
                         ++tries;
                         TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
-                        TRY(projfunc_cols(st, HnewT, n, K, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
+                        TRY(project_H(HnewT));                                                      // nmfsc.m:155-157
                         TRY(transpose_f32(st, HnewT, n, K, Hcand));
                         TRY(fast_obj(Wd, Hcand, &newobj));                                          // nmfsc.m:160-161
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
@@ -1151,6 +1186,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
                     TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
                     TRY(transpose_f32(st, Hcur, K, n, HTd));
                     TRY(col_reduce(st, HTd, n, n, K, 1, nrm2));                                     // nmfsc.m:185
+                    if (comm.active()) TRY(comm.allreduce(nrm2, K, NMFX_F64, NMFX_REDUCE_SUM));     // row norms of H span the shards
                     TRY(scale_cols(st, HTd, n, K, nrm2, 1, 1));                                     // nmfsc.m:186
                     TRY(scale_cols(st, Wd, m, K, nrm2, 1, 0));                                      // nmfsc.m:187
                     TRY(transpose_f32(st, HTd, n, K, Hcur));
@@ -1198,6 +1234,12 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
         r->converged_early = early ? 1 : 0;
         if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
         if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+        if (dev) {
+            NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mK * 4, hipMemcpyDeviceToDevice, st));
+            NMFX_HIP(hipMemcpyAsync(dev->H, Hcur, Kn * 4, hipMemcpyDeviceToDevice, st));
+            NMFX_HIP(hipStreamSynchronize(st));
+            return NMFX_OK;
+        }
         TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
         TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
         return NMFX_OK;
@@ -1209,7 +1251,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     for (int it = 1; it <= p->maxiter && !early; ++it) {
         if (!fixH) {
             if (sH > 0) {
-                TRY(xt_w(V.as<float>(), Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));   // dH' = (V_hat - V)' * W   nmfsc.m:144-148
+                TRY(xt_w(Vp, Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));   // dH' = (V_hat - V)' * W   nmfsc.m:144-148
                 const double begobj = r->cost[it - 1];                                      // nmfsc.m:149
                 int tries = 0;
                 for (;;) {
@@ -1228,7 +1270,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
                 stepH *= 1.2;                                                                   // nmfsc.m:178
                 std::swap(HTd, HnewT);                                                          // nmfsc.m:179
             } else {
-                TRY(xt_w(V.as<float>(), nullptr, NMFX_PRO_NONE, G1.as<float>()));               // (W'*V)'       nmfsc.m:144
+                TRY(xt_w(Vp, nullptr, NMFX_PRO_NONE, G1.as<float>()));               // (W'*V)'       nmfsc.m:144
                 TRY(xt_w(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // (W'*V_hat)'   nmfsc.m:145
                 TRY(mu_plain(st, HTd, G1.as<float>(), G2.as<float>(), (long)Kn));               // nmfsc.m:182
                 double *nrm2 = costd.as<double>() + 8;
@@ -1241,7 +1283,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
             double begobj;
             TRY(recon_obj(Wd, HTd, &begobj));                                                   // nmfsc.m:193,197
             if (sW > 0) {
-                TRY(x_ht(V.as<float>(), Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));        // dW = (V_hat - V) * H'   nmfsc.m:194-200
+                TRY(x_ht(Vp, Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));        // dW = (V_hat - V) * H'   nmfsc.m:194-200
                 int tries = 0;
                 for (;;) {
                     ++tries;
@@ -1259,7 +1301,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
                 stepW *= 1.2;                                                                   // nmfsc.m:228
                 std::swap(Wd, Wnew);                                                            // nmfsc.m:229
             } else {
-                TRY(x_ht(V.as<float>(), nullptr, NMFX_PRO_NONE, G1.as<float>()));               // nmfsc.m:194
+                TRY(x_ht(Vp, nullptr, NMFX_PRO_NONE, G1.as<float>()));               // nmfsc.m:194
                 TRY(x_ht(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // nmfsc.m:195
                 TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
             }
@@ -1277,6 +1319,12 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
     if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
     TRY(transpose_f32(st, HTd, n, K, Hk.as<float>()));
+    if (dev) {
+        NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mK * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipMemcpyAsync(dev->H, Hk.p, Kn * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipStreamSynchronize(st));
+        return NMFX_OK;
+    }
     TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
     TRY(download(st, Hk.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS));
     return NMFX_OK;
@@ -1470,6 +1518,15 @@ nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, 
     return run_mu(p, r, 3, segments, nz, Z_init, Z_out);
 }
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
+nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,
+                           nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r) {
+    if (!p || !r || !V_dev || !W_dev || !H_dev || !r->cost) { set_error("nmfx_nmfsc_dev: null argument"); return NMFX_ERR_INVALID; }
+    if (p->m <= 0 || p->n <= 0 || p->K_total <= 0 || p->maxiter <= 0 || n_total < p->n) { set_error("nmfx_nmfsc_dev: bad sizes"); return NMFX_ERR_INVALID; }
+    ScDev d{};
+    d.V = V_dev; d.W = W_dev; d.H = H_dev; d.n_total = n_total; d.st = static_cast<hipStream_t>(stream);
+    d.comm.fn = allreduce; d.comm.ctx = allreduce_ctx; d.comm.st = d.st;
+    return run_nmfsc(p, r, &d);
+}
 nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
 
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W, const void *H, void *V_hat,

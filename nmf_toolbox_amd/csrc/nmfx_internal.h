@@ -20,6 +20,20 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Collectives are the CALLER's: libnmfx never links RCCL.  A Comm wraps the all-reduce callback handed to nmfx_nmfsc_dev
+// (torch.distributed in the Python driver, ncclAllReduce in a MEX shim); inactive on one GPU.
+struct Comm {
+    nmfx_allreduce_fn fn = nullptr;
+    void *ctx = nullptr;
+    hipStream_t st = nullptr;
+    bool active() const { return fn != nullptr; }
+    nmfx_status allreduce(void *dev_ptr, long count, int dtype, int op) const {
+        if (!fn) return NMFX_OK;
+        if (fn(ctx, dev_ptr, (int64_t)count, dtype, op, (void *)st) != 0) { set_error("all-reduce callback failed"); return NMFX_ERR_INVALID; }
+        return NMFX_OK;
+    }
+};
+
 // ---- operand views of the general MFMA GEMM (gemm.hip) ------------------------------------
 // An operand element is addressed by (r, kc): r = its non-contracted index (row of op(A) /
 // column of op(B)), kc = the contraction index.  RC = memory-contiguous along r, KC = along kc.
@@ -155,5 +169,9 @@ nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count)
 
 // ---- Hoyer projection (projfunc.hip): vectors are the COLUMNS of X (len x count), in place ----
 nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev);
+// the same projection when every vector is split over the ranks of `comm` (len = local part, N_total = whole length);
+// v_scratch: len*count doubles, flags: len*count bytes, red: 6*count doubles
+nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, long N_total, double k1, double k2, int nn, const Comm &comm,
+                               double *v_scratch, unsigned char *flags, double *red);
 
 }  // namespace nmfx

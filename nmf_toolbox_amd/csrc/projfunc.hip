@@ -4,6 +4,8 @@
 // |Z|, all(v>=0)) is a wave-shuffle + LDS tree in fp64 so the discrete branches (v<=0 sets,
 // nmfsc.m:164 objective test downstream) follow the float64 reference.  Bandwidth-class: the only
 // HBM traffic is one read and one write of the vector.
+#include <vector>
+
 #include "nmfx_internal.h"
 
 namespace nmfx {
@@ -174,6 +176,130 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(float *X, lon
     }
     for (long i = tid; i < len; i += PF_THREADS) x[i] = (float)((fl[i] & 2) ? -v[i] : v[i]);
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
+}
+
+// ---- the same projection with every vector split over ranks (column-sharded H of nmfsc) --------------
+// projfunc.m:22-53 as four phases; between phases the caller all-reduces red[4*count] (sum over ranks), so every rank sees the
+// same sums and takes the same branches.  state[2k] = |Z| of vector k (global), state[2k+1] = 1 once all(v >= 0) held.
+__global__ __launch_bounds__(PF_THREADS) void pfd_init_kernel(const float *X, long len, int nn, double *V, unsigned char *F, double *red, double *state) {
+    __shared__ double sred[PF_WAVES * 4];
+    const long k = blockIdx.x;
+    const float *x = X + len * k;
+    double *v = V + len * k;
+    unsigned char *fl = F + len * k;
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+    for (long i = threadIdx.x; i < len; i += PF_THREADS) {
+        double s = (double)x[i];
+        unsigned char f = 0;
+        if (!nn) { if (s < 0) f = 2; s = fabs(s); }                               // projfunc.m:16-19
+        v[i] = s; fl[i] = f; r.a += s;
+    }
+    r = block_red4(r, sred);
+    if (threadIdx.x == 0) { red[4 * k] = r.a; red[4 * k + 1] = 0.0; red[4 * k + 2] = 0.0; red[4 * k + 3] = 0.0; state[2 * k] = 0.0; state[2 * k + 1] = 0.0; }
+}
+// in: red = {sum(v), |Z|} (global).  v += (k1 - sum)/(N - |Z|) off Z (projfunc.m:22 / 52-53); out: red = {w'w, w'v, v'v} (31-36)
+__global__ __launch_bounds__(PF_THREADS) void pfd_shift_sums_kernel(double *V, const unsigned char *F, long len, double N, double k1, double *red, double *state) {
+    __shared__ double sred[PF_WAVES * 4];
+    const long k = blockIdx.x;
+    const bool done = state[2 * k + 1] != 0.0;
+    const double sum = red[4 * k], nz = red[4 * k + 1];
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+    if (!done) {
+        double *v = V + len * k;
+        const unsigned char *fl = F + len * k;
+        const double shift = (k1 - sum) / (N - nz), mid = k1 / (N - nz);
+        for (long i = threadIdx.x; i < len; i += PF_THREADS) {
+            const bool z = fl[i] & 1;
+            const double vi = z ? v[i] : v[i] + shift;
+            if (!z) v[i] = vi;
+            const double w = vi - (z ? 0.0 : mid);
+            r.a += w * w; r.b += w * vi; r.c += vi * vi;
+        }
+    }
+    r = block_red4(r, sred);                                                      // also orders the reads of red above before the writes below
+    if (threadIdx.x == 0) {
+        if (!done) state[2 * k] = nz;
+        red[4 * k] = r.a; red[4 * k + 1] = r.b; red[4 * k + 2] = r.c; red[4 * k + 3] = 0.0;
+    }
+}
+// in: red = {w'w, w'v, v'v} (global).  v += alphap*w (projfunc.m:37-38); out: red = {#(v < 0 or NaN)} for the all(v>=0) test (40)
+__global__ __launch_bounds__(PF_THREADS) void pfd_step_kernel(double *V, const unsigned char *F, long len, double N, double k1, double k2, double *red, const double *state) {
+    __shared__ double sred[PF_WAVES * 4];
+    const long k = blockIdx.x;
+    const bool done = state[2 * k + 1] != 0.0;
+    const double a = red[4 * k], b = 2.0 * red[4 * k + 1], c = red[4 * k + 2] - k2;
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+    if (!done) {
+        double *v = V + len * k;
+        const unsigned char *fl = F + len * k;
+        const double disc = b * b - 4.0 * a * c;
+        const double alphap = (-b + (disc > 0.0 ? sqrt(disc) : 0.0)) / (2.0 * a);  // real(sqrt(.)), projfunc.m:37
+        const double mid = k1 / (N - state[2 * k]);
+        for (long i = threadIdx.x; i < len; i += PF_THREADS) {
+            const double vi = v[i], w = vi - ((fl[i] & 1) ? 0.0 : mid);
+            const double vn = alphap * w + vi;
+            v[i] = vn;
+            if (!(vn >= 0.0)) r.a += 1.0;
+        }
+    }
+    r = block_red4(r, sred);
+    if (threadIdx.x == 0) { red[4 * k] = r.a; red[4 * k + 1] = 0.0; red[4 * k + 2] = 0.0; red[4 * k + 3] = 0.0; }
+}
+// in: red = {#negative} (global): 0 finishes the vector (projfunc.m:40-44); else Z = {v <= 0}, v(Z) = 0; out: red = {sum(v), |Z|} (49-51)
+__global__ __launch_bounds__(PF_THREADS) void pfd_zero_kernel(double *V, unsigned char *F, long len, double *red, double *state) {
+    __shared__ double sred[PF_WAVES * 4];
+    const long k = blockIdx.x;
+    const bool was_done = state[2 * k + 1] != 0.0;
+    const bool done = was_done || red[4 * k] == 0.0;
+    Red4 r = {0.0, 0.0, 0.0, 0.0};
+    if (!done) {
+        double *v = V + len * k;
+        unsigned char *fl = F + len * k;
+        for (long i = threadIdx.x; i < len; i += PF_THREADS) {
+            double vi = v[i];
+            unsigned char f = fl[i] & 2;
+            if (vi <= 0.0) { f |= 1; vi = 0.0; v[i] = 0.0; r.b += 1.0; }
+            fl[i] = f;
+            r.a += vi;
+        }
+    }
+    r = block_red4(r, sred);
+    if (threadIdx.x == 0) {
+        if (done) state[2 * k + 1] = 1.0;
+        red[4 * k] = r.a; red[4 * k + 1] = r.b; red[4 * k + 2] = 0.0; red[4 * k + 3] = 0.0;
+    }
+}
+__global__ __launch_bounds__(PF_THREADS) void pfd_store_kernel(float *X, const double *V, const unsigned char *F, long len) {
+    const long k = blockIdx.x;
+    for (long i = threadIdx.x; i < len; i += PF_THREADS) X[len * k + i] = (float)((F[len * k + i] & 2) ? -V[len * k + i] : V[len * k + i]);   // projfunc.m:58-60
+}
+
+nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, long N_total, double k1, double k2, int nn, const Comm &comm,
+                               double *v_scratch, unsigned char *flags, double *red) {
+    if (count <= 0 || len <= 0) return NMFX_OK;
+    const dim3 g(count), b(PF_THREADS);
+    double *state = red + 4L * count;
+    const double N = (double)N_total;
+    std::vector<double> host(4 * (size_t)count);
+    hipLaunchKernelGGL(pfd_init_kernel, g, b, 0, st, X, len, nn, v_scratch, flags, red, state);
+    nmfx_status rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM);
+    if (rc != NMFX_OK) return rc;
+    for (int j = 0; j <= PF_MAX_ITERS; ++j) {
+        hipLaunchKernelGGL(pfd_shift_sums_kernel, g, b, 0, st, v_scratch, flags, len, N, k1, red, state);
+        if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
+        hipLaunchKernelGGL(pfd_step_kernel, g, b, 0, st, v_scratch, flags, len, N, k1, k2, red, state);
+        if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
+        NMFX_HIP(hipMemcpyAsync(host.data(), red, sizeof(double) * host.size(), hipMemcpyDeviceToHost, st));
+        NMFX_HIP(hipStreamSynchronize(st));
+        bool all_done = true;                                                    // identical on every rank: red is the all-reduced copy
+        for (int k = 0; k < count; ++k) all_done &= host[4 * (size_t)k] == 0.0;
+        if (all_done) break;
+        hipLaunchKernelGGL(pfd_zero_kernel, g, b, 0, st, v_scratch, flags, len, red, state);
+        if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
+    }
+    hipLaunchKernelGGL(pfd_store_kernel, g, b, 0, st, X, v_scratch, flags, len);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 
 nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {

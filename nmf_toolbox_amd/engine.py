@@ -221,3 +221,85 @@ class Engine:
             _lib.check(self.lib.nmfx_engine_tag_work(self.h, t, C.byref(f), C.byref(b)))
             out[self.lib.nmfx_engine_profile_tag_name(t).decode()] = dict(ms_total=ms[t], launches=cnt[t], flops=f.value, bytes=b.value)
         return out
+
+
+# ---- nmfsc on column shards -------------------------------------------------------------------------
+class _DevPtr:
+    """a raw device pointer as a __cuda_array_interface__ object, so torch can wrap the library's buffers without copying"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr=typestr, data=(int(ptr), False), version=2, strides=None)
+
+
+def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed=False, H_fixed=False, maxiter=100, tolerance=1e-3,
+                  group=None, path=0, allreduce=None):
+    """nmfsc.m:57-245 with V / H column-sharded over the ranks of `group` and W replicated.
+
+    V: (n_local, m) fp32 CUDA tensor (= column-major m x n_local), W: (K, m), H: (n_local, K); W and H are updated in place
+    (W ends identical on every rank).  Every cross-rank sum is requested by libnmfx through a callback and served here by
+    torch.distributed (RCCL with the nccl backend): one [V*H' | H*H'] all-reduce per outer iteration, 8 bytes per objective
+    evaluation, 4*K doubles per projfunc reduction.  `allreduce(tensor, op)` replaces torch.distributed (tests).
+    Returns (cost ndarray, info dict).  tolerance < 0 disables the stop rule."""
+    import torch
+    dist = torch.distributed
+    lib = _lib.load()
+    if not (V.is_cuda and W.is_cuda and H.is_cuda):
+        raise _lib.NmfxError(_lib.NMFX_ERR_NO_DEVICE, "nmfsc_sharded needs CUDA/HIP tensors: there is no CPU fallback")
+    V, dev = V.contiguous(), V.device
+    assert W.is_contiguous() and H.is_contiguous() and W.dtype == H.dtype == V.dtype == torch.float32
+    n_local, m = V.shape
+    K = H.shape[1]
+    assert H.shape[0] == n_local and W.shape == (K, m)
+    use_dist = allreduce is None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if allreduce is None and use_dist:
+        ops = {_lib.REDUCE_SUM: dist.ReduceOp.SUM, _lib.REDUCE_MAX: dist.ReduceOp.MAX}
+
+        def allreduce(t, op):
+            dist.all_reduce(t, op=ops[op], group=group)
+    # nmfsc.m:57-62: data must be non-negative; V = V / max(V(:)) with the GLOBAL max
+    mm = torch.stack([V.max(), -V.min()]).double()
+    if allreduce is not None:
+        allreduce(mm, _lib.REDUCE_MAX)
+    vmax, vmin = float(mm[0]), -float(mm[1])
+    if vmin < 0:
+        raise ValueError("Negative values in data!")
+    Vs = V / vmax
+    nt = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+    if allreduce is not None:
+        allreduce(nt, _lib.REDUCE_SUM)
+    n_sum = int(round(float(nt[0])))
+    if n_total is None:
+        n_total = n_sum
+    assert int(n_total) == n_sum, "n_total does not match the sum of the shards' columns"
+    errors = []
+
+    def _cb(ctx, ptr, count, dtype, op, stream):
+        try:
+            t = torch.as_tensor(_DevPtr(ptr, count, "<f4" if dtype == _lib.F32 else "<f8"), device=dev)
+            allreduce(t, op)
+            return 0
+        except Exception as ex:   # never let an exception cross the C frame
+            errors.append(ex)
+            return 1
+
+    cb = _lib.ALLREDUCE_FN(_cb) if allreduce is not None else C.cast(None, _lib.ALLREDUCE_FN)
+    cost = np.zeros(int(maxiter) + 1)
+    tH, tW = np.zeros(int(maxiter), dtype=np.int32), np.zeros(int(maxiter), dtype=np.int32)
+    fw, fh = np.asarray([bool(W_fixed)], dtype=np.uint8), np.asarray([bool(H_fixed)], dtype=np.uint8)
+    p = _lib.Problem()
+    p.m, p.n, p.K_total, p.T, p.dtype = m, n_local, K, 1, _lib.F32
+    p.num_sources = 1
+    p.W_fixed, p.H_fixed = fw.ctypes.data_as(C.c_void_p), fh.ctypes.data_as(C.c_void_p)
+    p.maxiter, p.tolerance = int(maxiter), float(tolerance)
+    p.device = dev.index or 0
+    p.sc_W_sparsity, p.sc_H_sparsity, p.path = float(W_sparsity), float(H_sparsity), int(path)
+    r = _lib.Result()
+    r.cost, r.tries_H, r.tries_W = cost.ctypes.data_as(C.c_void_p), tH.ctypes.data_as(C.c_void_p), tW.ctypes.data_as(C.c_void_p)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.nmfx_nmfsc_dev(C.byref(p), Vs.data_ptr(), W.data_ptr(), H.data_ptr(), int(n_total), stream, cb, None, C.byref(r))
+    if errors:
+        raise errors[0]
+    _lib.check(rc)
+    info = dict(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0], stepsizeH=r.stepsize_H, stepsizeW=r.stepsize_W,
+                converged_early=bool(r.converged_early), vmax=vmax)
+    return cost[: r.cost_len].copy(), info

@@ -280,3 +280,126 @@ def test_cnmf_distributed_halo_exchange_two_processes(gpu_lib):
     assert np.array_equal(res[0][1], res[1][1])
     assert rel_fro(res[0][1].reshape(W.shape), W) < 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) < 1e-5
     assert rel_fro(res[0][3], c0) < 1e-6 and rel_fro(res[1][3], c0) < 1e-6
+
+
+# ---- nmfsc on column shards: distributed projfunc reductions, all-reduce through the callback ------
+class _ThreadRendezvous:
+    """all-reduce among `world` threads of ONE process that each drive a shard on the same GPU (stand-in for RCCL ranks)"""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots, self.result = world, [None] * world, None
+        self.barrier = threading.Barrier(world)
+
+    def allreduce(self, rank, t, op):
+        import torch
+        self.slots[rank] = t
+        self.barrier.wait()
+        if rank == 0:
+            st = torch.stack(self.slots)                    # fixed rank order: every "rank" gets bit-identical sums
+            self.result = st.sum(0) if op == 0 else st.max(0).values
+        self.barrier.wait()
+        t.copy_(self.result)
+        self.barrier.wait()
+
+
+def _nmfsc_threads(V, W0, H0, world, **kw):
+    import threading
+    import torch
+    from nmf_toolbox_amd.engine import colmajor_to_torch, nmfsc_sharded, shard_columns, torch_to_colmajor
+    rv = _ThreadRendezvous(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = shard_columns(V.shape[1], world, rank)
+            Vt, Wt, Ht = colmajor_to_torch(V[:, lo:hi], "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0[:, lo:hi], "cuda:0")
+            cost, info = nmfsc_sharded(Vt, Wt, Ht, allreduce=lambda t, op: rv.allreduce(rank, t, op), **kw)
+            torch.cuda.synchronize()
+            out[rank] = (torch_to_colmajor(Wt).reshape(W0.shape), torch_to_colmajor(Ht), cost, info)
+        except Exception as ex:   # a dead thread would leave the others in the barrier forever
+            errs.append(ex)
+            rv.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    if errs:
+        raise errs[0]
+    return out
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
+@pytest.mark.parametrize("world", [2, 4])
+def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world):
+    from oracle import nmf_oracle as O
+    m, n, K = 256, 1024, 64
+    V, W0, H0 = synth(m, n, K)
+    V = 2.5 * V                                                # the global max(V) rescale (nmfsc.m:62) spans the shards
+    cfg = dict(W_init=W0, H_init=H0, maxiter=12, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0 = {}
+    W, H, cost = O.nmfsc(V, K, cfg, info=i0)
+    res = _nmfsc_threads(V, W0, H0, world, W_sparsity=sW, H_sparsity=sH, maxiter=12, tolerance=1e-12)
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[2], res[0][2])      # W and cost replicated bit-for-bit
+    Hs = np.concatenate([r[1] for r in res], axis=1)
+    assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
+    assert rel_fro(res[0][0], W) <= 1e-5 and rel_fro(Hs, H) <= 1e-5, (rel_fro(res[0][0], W), rel_fro(Hs, H))
+    assert len(res[0][2]) == len(cost) and rel_fro(res[0][2], cost) <= 1e-6
+    if sH:                                                     # Hoyer postconditions hold on WHOLE rows of H (projfunc.m:3-7)
+        L1s = np.sqrt(n) - (np.sqrt(n) - 1) * sH
+        assert np.allclose(Hs.sum(1), L1s, rtol=1e-5) and np.allclose((Hs ** 2).sum(1), 1.0, rtol=1e-5) and Hs.min() >= 0
+
+
+def test_nmfsc_sharded_refuses_untileable_shards_and_negative_data(gpu_lib):
+    V, W0, H0 = synth(256, 600, 64)                            # 300 columns per shard: not a multiple of 128
+    with pytest.raises(Exception, match="fused kernels only"):
+        _nmfsc_threads(V, W0, H0, 2, H_sparsity=0.5, maxiter=2)
+    Vn = synth(256, 512, 64)[0]
+    Vn[3, 400] = -1.0                                          # only the second shard sees it: the check is global
+    with pytest.raises(ValueError, match="Negative values in data!"):
+        _nmfsc_threads(Vn, W0, H0[:, :512], 2, maxiter=2)
+
+
+def _nmfsc_dist_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_toolbox_amd.engine import colmajor_to_torch, nmfsc_sharded, shard_columns, torch_to_colmajor
+    m, n, K = 256, 1024, 64
+    V, W0, H0 = synth(m, n, K)
+    lo, hi = shard_columns(n, world, rank)
+    Vt, Wt, Ht = colmajor_to_torch(V[:, lo:hi], "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0[:, lo:hi], "cuda:0")
+    cost, info = nmfsc_sharded(Vt, Wt, Ht, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
+    torch.cuda.synchronize()
+    q.put((rank, torch_to_colmajor(Wt).reshape(m, K), torch_to_colmajor(Ht), cost, info["triesH"], info["triesW"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nmfsc_torch_distributed_two_processes(gpu_lib):
+    import torch.multiprocessing as mp
+    from oracle import nmf_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nmfsc_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    V, W0, H0 = synth(256, 1024, 64)
+    i0 = {}
+    W, H, cost = O.nmfsc(V, 64, dict(W_init=W0, H_init=H0, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12), info=i0)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][4] == i0["triesH"] and res[0][5] == i0["triesW"]
+    assert rel_fro(res[0][1], W) <= 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) <= 1e-5
+    assert rel_fro(res[0][3], cost) <= 1e-6
