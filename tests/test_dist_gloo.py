@@ -143,3 +143,99 @@ def test_sharded_loop_matches_unsharded_oracle(div, layout):
     assert rel(res[0][3], W) < 1e-11 and rel(Hs, H) < 1e-11
     for r in res:
         assert rel(r[5], cost) < 1e-12                              # every rank holds the global cost vector
+
+
+# ---- the distributed projfunc protocol of nmfsc on column shards ----------------------------------
+def _projfunc_phases(S_local, N, k1, k2, allreduce):
+    """float64 NumPy mirror of nmf_toolbox_amd/csrc/projfunc.hip::projfunc_cols_dist: K vectors at once, each split over the
+    ranks; `allreduce(array)` sums a (K, 4) array over ranks in place.  Phases: init -> [shift+sums -> step -> zero]*."""
+    K = S_local.shape[0]
+    v = S_local.astype(np.float64).copy()
+    Z = np.zeros_like(v, dtype=bool)
+    done = np.zeros(K, dtype=bool)
+    nz = np.zeros(K)
+    red = np.zeros((K, 4))
+    red[:, 0] = v.sum(1)
+    allreduce(red)
+    iters = np.ones(K, dtype=int)
+    while True:
+        tot, cnt = red[:, 0].copy(), red[:, 1].copy()
+        red[:] = 0
+        act = ~done
+        nz[act] = cnt[act]
+        shift, mid = (k1 - tot) / (N - nz), k1 / (N - nz)
+        for k in np.nonzero(act)[0]:
+            v[k, ~Z[k]] += shift[k]
+            w = np.where(Z[k], 0.0, v[k] - mid[k])
+            red[k, :3] = [(w * w).sum(), (w * v[k]).sum(), (v[k] * v[k]).sum()]
+        allreduce(red)
+        a, b, c = red[:, 0].copy(), 2 * red[:, 1], red[:, 2] - k2
+        red[:] = 0
+        for k in np.nonzero(act)[0]:
+            disc = b[k] * b[k] - 4 * a[k] * c[k]
+            alphap = (-b[k] + (np.sqrt(disc) if disc > 0 else 0.0)) / (2 * a[k])
+            w = np.where(Z[k], 0.0, v[k] - mid[k])
+            v[k] = alphap * w + v[k]
+            red[k, 0] = np.count_nonzero(~(v[k] >= 0))
+        allreduce(red)
+        if np.all(red[:, 0] == 0):
+            return v, iters
+        neg = red[:, 0].copy()
+        red[:] = 0
+        done |= neg == 0
+        for k in np.nonzero(~done)[0]:
+            iters[k] += 1
+            Z[k] = v[k] <= 0
+            v[k, Z[k]] = 0.0
+            red[k, :2] = [v[k].sum(), np.count_nonzero(Z[k])]
+        allreduce(red)
+
+
+def _pf_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_toolbox_amd.engine import shard_columns
+    rs = np.random.RandomState(5)
+    S = np.abs(rs.randn(7, 301)) + 1e-3
+    S[3] = np.abs(rs.randn(301)) ** 4                                  # a peaky row: more zeroing rounds than the others
+    lo, hi = shard_columns(301, world, rank)
+    N = 301
+    k1 = np.sqrt(N) - (np.sqrt(N) - 1) * 0.7
+
+    def allreduce(a):
+        t = torch.from_numpy(a)
+        dist.all_reduce(t)
+
+    v, iters = _projfunc_phases(S[:, lo:hi], N, k1, 1.0, allreduce)
+    q.put((rank, v, iters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_projfunc_protocol_matches_projfunc_m():
+    from oracle import nmf_oracle as O
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(5)
+    S = np.abs(rs.randn(7, 301)) + 1e-3
+    S[3] = np.abs(rs.randn(301)) ** 4
+    N = 301
+    k1 = np.sqrt(N) - (np.sqrt(N) - 1) * 0.7
+    V = np.concatenate([r[1] for r in res], axis=1)
+    assert np.array_equal(res[0][2], res[1][2])                           # same branch sequence on both ranks
+    its = []
+    for k in range(7):
+        v, it = O.projfunc(S[k], k1, 1.0, True)
+        its.append(it)
+        assert np.allclose(V[k], v, rtol=1e-12, atol=1e-14) and res[0][2][k] == it
+    assert len(set(its)) > 1                                              # rows really finished at different rounds
