@@ -105,7 +105,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("NMFX_BENCH_FORCE_DIST", "0") == "1"   # dev aid: run the N > 1 code path (RCCL all-reduce included) with one rank
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -145,13 +148,13 @@ def main():
             req.wait()
         torch.cuda.synchronize()
         V, H, halo = Vx, Hx, (hL, hR)
-    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo)
+    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo, use_dist=True if force_dist else None)
     eng.init()
     costs = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -165,11 +168,21 @@ def main():
     prof = eng.profile_read()
     eng.profile(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     c = costs[: args.warmup + args.steps].cpu().numpy()
 
+    # RCCL prints its version banner through C stdio, which is flushed only at exit: push every rank's buffered output out
+    # now so that rank 0's JSON line is the last thing on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1 or force_dist:
+        dist.barrier()
     if rank == 0:
         its = args.steps / dt
         f_alg = fmul * m * n * K * T
@@ -210,7 +223,7 @@ def main():
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
