@@ -1045,7 +1045,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mK * 4, hipMemcpyDeviceToDevice, st));
         NMFX_HIP(hipMemcpyAsync(Hk.p, dev->H, Kn * 4, hipMemcpyDeviceToDevice, st));
     }
-    const float *Vp = dev ? dev->V : Vp;
+    const float *Vp = dev ? dev->V : V.as<float>();
     float *Wd = W.as<float>(), *Wnew = Wn.as<float>(), *HTd = HT.as<float>(), *HnewT = HnT.as<float>();
     // rows of H (stored as the columns of an n_local x K transposed copy) through projfunc; on column shards every reduction of
     // projfunc.m:22-53 is a sum over ranks
