@@ -52,7 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _newer([src] + hdrs, obj):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed",
+                   "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
