@@ -118,7 +118,12 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(const FusedParams p) {
         const int b = (PROBE & 1) ? 0 : (t & 1);
         const int tn = t + 1 < ntiles ? t + 1 : t;           // the last tile re-fetches itself: keeps the body branch-free
         if (!(PROBE & 1) || t == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA rows of tile t and the V registers have landed
+            // own DMA rows of tile t have landed.  With a first product the 32 V loads of this tile were issued AFTER its DMA
+            // rows (loads return in order), and V is first needed in P2, a whole P1 (>= 3 us of MFMAs) later: leave them in
+            // flight instead of draining to vmcnt(0), which exposed one HBM round trip (~2 us of a 13.6 us tile at K = 256) per tile.
+            // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
+            if (NEED_S && !(PROBE & 4)) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
         }
         const float *Yt = lds + b * BUF;
