@@ -205,7 +205,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->Pbuf = c.take<float>(mKT);
         e->CC = c.take<float>((size_t)e->KT * e->KT);
         size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
-        size_t gg = std::max(g4, g5);
+        size_t gg = std::max(std::max(g4, g5), sizeof(float) * Kn * e->T);   // + T slabs of the z-batched H-step denominator
         if (gg > e->gemm_scratch_bytes) { e->gemm_scratch_bytes = gg; e->gemm_scratch = c.take<float>(gg / sizeof(float)); }
     }
     L.total = c.off;
@@ -681,14 +681,27 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             Scope s(e, TAG_GRAM);
             OpView wf{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
             TRY(small_gemm(e, e->KT, e->KT, e->m, wf, wf, e->CC, e->KT));
-            for (int t = 0; t < e->T; ++t) {
-                GemmParams g;
-                memset(&g, 0, sizeof(g));
-                g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
-                g.A = OpView{e->CC + (long)t * e->K, nullptr, (long)e->KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-                g.B = OpView{e->H + (long)e->K * t, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->nvalid - t, t, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
-                g.C = e->Gp; g.ldc = e->K; g.accumulate = t > 0; g.epi = EPI_STORE; g.splitk = 1;
+            GemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
+            g.A = OpView{e->CC, nullptr, (long)e->KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+            g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->nvalid, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
+            g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+            const size_t Kn = (size_t)e->K * e->n;
+            if (e->T > 1 && gemm_pipe_eligible(g) && e->gemm_scratch_bytes >= Kn * e->T * sizeof(float)) {
+                // all T shifts in ONE launch (blockIdx.z = t, slab t), then a deterministic slab sum
+                g.zbatch = e->T; g.zA_off = e->K; g.zB_off = e->K; g.zB_lim = 1; g.zB_tstride = -1;
+                g.C = e->gemm_scratch; g.slab_stride = (long)Kn;
                 TRY(launch_gemm(e->st, g));
+                TRY(reduce_slabs(e->st, e->gemm_scratch, e->T, (long)Kn, (long)Kn, e->Gp, 0));
+            } else {
+                for (int t = 0; t < e->T; ++t) {
+                    GemmParams gt = g;
+                    gt.A.p = e->CC + (long)t * e->K;
+                    gt.B.p = e->H + (long)e->K * t; gt.B.tstride = e->nvalid - t; gt.B.lim = t;
+                    gt.C = e->Gp; gt.accumulate = t > 0;
+                    TRY(launch_gemm(e->st, gt));
+                }
             }
         } else if (div_has_matrix_den(e->div)) {
             den_view(e, b);

@@ -14,6 +14,7 @@
 // buffer after them (one barrier per k-tile).  The MFMA roles are swapped (B tile feeds the "A"
 // port) so that lanes 0-31 of an accumulator register hold 32 CONSECUTIVE ROWS i of one column of
 // C: stores to C and loads of V in the epilogue are 128-byte contiguous segments.
+#include <cstdlib>
 #include <type_traits>
 
 #include "nmfx_internal.h"
@@ -406,7 +407,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
 
     long kbeg = 0, kend = p.Kc;
     float *C = p.C;
-    if (p.splitk > 1) {
+    OpView vA = p.A, vB = p.B;
+    if (p.zbatch > 0) {   // blockIdx.z = shift index t: same contraction on shifted operands, slab t
+        const int z = blockIdx.z;
+        vA.p += (long)z * p.zA_off;
+        vB.p += (long)z * p.zB_off;
+        vB.lim += z * p.zB_lim;
+        vB.tstride += z * p.zB_tstride;
+        C += (long)z * p.slab_stride;
+    } else if (p.splitk > 1) {
         kbeg = (long)blockIdx.z * p.kc_per_split;
         kend = kbeg + p.kc_per_split < p.Kc ? kbeg + p.kc_per_split : p.Kc;
         C += (long)blockIdx.z * p.slab_stride;
@@ -414,8 +423,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     const int ntiles = (int)((kend - kbeg) / BK);
 
     LA la; LB lb;
-    la.init(p.A, tid, i_tile0, kbeg);
-    lb.init(p.B, tid, j_tile0, kbeg);
+    la.init(vA, tid, i_tile0, kbeg);
+    lb.init(vB, tid, j_tile0, kbeg);
 
     f32x16 acc[NR][MR];
 #pragma unroll
@@ -428,13 +437,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     // compile-time unrolled helpers over the chunk pieces: pieces 0..NCH_A-1 belong to A, the rest to B
     auto issue_piece = [&](auto set_c, auto piece_c) {
         constexpr int SET = decltype(set_c)::value, PC = decltype(piece_c)::value;
-        if constexpr (PC < LA::NCH) la.template issue<SET, PC>(p.A);
-        else if constexpr (PC < NPIECE) lb.template issue<SET, PC - LA::NCH>(p.B);
+        if constexpr (PC < LA::NCH) la.template issue<SET, PC>(vA);
+        else if constexpr (PC < NPIECE) lb.template issue<SET, PC - LA::NCH>(vB);
     };
     auto commit_piece = [&](auto set_c, auto piece_c, float *buf) {
         constexpr int SET = decltype(set_c)::value, PC = decltype(piece_c)::value;
-        if constexpr (PC < LA::NCH) la.template commit<SET, PC>(p.A, buf);
-        else if constexpr (PC < NPIECE) lb.template commit<SET, PC - LA::NCH>(p.B, buf + A_SZ_AL);
+        if constexpr (PC < LA::NCH) la.template commit<SET, PC>(vA, buf);
+        else if constexpr (PC < NPIECE) lb.template commit<SET, PC - LA::NCH>(vB, buf + A_SZ_AL);
     };
     auto for_pieces = [&](auto f) {
         f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
@@ -446,9 +455,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     if (ntiles > 0) {
         // prologue: tile 0 -> set 0 -> LDS buffer 0; tile 1 (or 0 again) -> set 1, left in flight
         for_pieces([&](auto pc) { issue_piece(S0{}, pc); });
-        la.advance(p.A, ntiles > 1); lb.advance(p.B, ntiles > 1);
+        la.advance(vA, ntiles > 1); lb.advance(vB, ntiles > 1);
         for_pieces([&](auto pc) { issue_piece(S1{}, pc); });
-        la.advance(p.A, ntiles > 2); lb.advance(p.B, ntiles > 2);
+        la.advance(vA, ntiles > 2); lb.advance(vB, ntiles > 2);
         for_pieces([&](auto pc) { commit_piece(S0{}, pc, smem); });
     }
     __syncthreads();
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
         step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
         step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
         step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
-        la.advance(p.A, t + 3 < ntiles); lb.advance(p.B, t + 3 < ntiles);
+        la.advance(vA, t + 3 < ntiles); lb.advance(vB, t + 3 < ntiles);
         __syncthreads();
     };
     for (int t = 0; t < ntiles; t += 2) {
@@ -541,7 +550,7 @@ static nmfx_status launch_pipe_cfg(hipStream_t st, const GemmParams &p) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 grid((unsigned)(p.M / BM), (unsigned)(p.N / BN), (unsigned)(p.splitk > 1 ? p.splitk : 1));
+    dim3 grid((unsigned)(p.M / BM), (unsigned)(p.N / BN), (unsigned)(p.zbatch > 0 ? p.zbatch : (p.splitk > 1 ? p.splitk : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, p);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
@@ -604,22 +613,32 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
 }
 
+// pipelined kernel: tile-aligned, no powf maps, and stacked k-views whose t blocks are whole k-tiles
+static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &heavy) {
+    gemm_tile_shape(p.M, p.N, bm, bn);
+    const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
+    fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && view_fast_ok(p.A) && view_fast_ok(p.B);
+    heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
+    auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };
+    static const bool pipe_off = getenv("NMFX_GEMM_NOPIPE") != nullptr;   // dev switch: A/B the two kernels
+    return fast && !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && kspan >= BK;
+}
+bool gemm_pipe_eligible(const GemmParams &p) {
+    int bm, bn; bool fast, heavy;
+    return p.M > 0 && p.N > 0 && pipe_ok(p, bm, bn, fast, heavy);
+}
+
 nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
     if (blocks_out) *blocks_out = 0;
     if (p.M <= 0 || p.N <= 0) return NMFX_OK;
     int bm, bn;
-    gemm_tile_shape(p.M, p.N, bm, bn);
-    const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
-    bool fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && view_fast_ok(p.A) &&
-                view_fast_ok(p.B);
-    const bool heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
+    bool fast, heavy;
+    const bool pipe = pipe_ok(p, bm, bn, fast, heavy);
+    if (p.zbatch > 0 && !pipe) { set_error("launch_gemm: z-batched launch needs the pipelined kernel"); return NMFX_ERR_INVALID; }
     if (!fast || heavy) bm = bn = 128;
     if (heavy) fast = fast && (p.M % 128 == 0) && (p.N % 128 == 0);
     if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    // pipelined kernel: tile-aligned, no powf maps, and stacked k-views whose t blocks are whole k-tiles
-    auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };
-    static const bool pipe_off = getenv("NMFX_GEMM_NOPIPE") != nullptr;   // dev switch: A/B the two kernels
-    if (fast && !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && kspan >= BK) {
+    if (pipe) {
         if (bm == 64) return dispatch_pipe<64, 128>(st, p);
         if (bn == 64) return dispatch_pipe<128, 64>(st, p);
         return dispatch_pipe<128, 128>(st, p);

@@ -82,7 +82,13 @@ struct GemmParams {
     int splitk;          // >1: partial sums written to slabs C + z*slab_stride, reduced by reduce_slabs
     long slab_stride;
     long kc_per_split;   // multiple of BK
+    // z-batched launch (pipelined kernel only): blockIdx.z = t runs the SAME contraction on shifted operands and writes slab t,
+    //   A.p += t*zA_off, B.p += t*zB_off, B.lim += t*zB_lim, B.tstride += t*zB_tstride      (cnmf Gram H step: one launch for all t)
+    int zbatch;
+    long zA_off, zB_off;
+    int zB_lim, zB_tstride;
 };
+bool gemm_pipe_eligible(const GemmParams &p);   // would launch_gemm run the pipelined kernel on p? (required for zbatch)
 
 nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out = nullptr);
 // picks split-K, runs the GEMM and the deterministic slab reduction; scratch >= gemm_scratch_bytes(M,N,Kc)
