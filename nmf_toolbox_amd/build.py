@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libnmfx.so")
-SOURCES = ["gemm.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
+SOURCES = ["gemm_pipe.hip", "gemm.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
 ARCH = "gfx950"
 
 

@@ -17,57 +17,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "nmfx_internal.h"
+#include "gemm_common.h"
 
 namespace nmfx {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int NTHREADS = 256;
-
-__device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g) {
-    switch (v.mode) {
-    case VIEW_RC: off = r; g = 0; break;
-    case VIEW_HSTACK_RC: { int rr = r + v.lim; int t = rr / v.blk; int k = rr - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
-    case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim + v.goff; break;
-    case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
-    default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
-    }
-}
-__device__ __forceinline__ void dec_k(const OpView &v, int kc, long &off, int &g) {
-    switch (v.mode) {
-    case VIEW_RC: off = v.ld * kc; g = 0; break;
-    case VIEW_HSTACK_RC: off = v.ld * kc; g = kc + v.goff; break;
-    case VIEW_HSTACK_KC: { int t = kc / v.blk; int k = kc - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
-    case VIEW_WSTACK_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.tstride * t; g = 0; } break;
-    case VIEW_XSHIFT_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.ld * t; g = -t; } break;
-    default: off = kc; g = 0; break;  // VIEW_KC
-    }
-}
-
-__device__ __forceinline__ float mpow(float x, float e) {   // MATLAB x.^e for the exponents that occur: exact for 0 and 1
-    if (e == 0.0f) return 1.0f;
-    if (e == 1.0f) return x;
-    if (e == -1.0f) return 1.0f / x;
-    return powf(x, e);
-}
-template <bool HEAVY>
-__device__ __forceinline__ float pro1(int func, float x, float y, float e1 = 0.f, float e2 = 0.f) {
-    if (HEAVY && func == NMFX_PRO_POWPROD) return mpow(x, e1) * mpow(y, e2);
-    switch (func) {
-    case NMFX_PRO_RATIO: return x / y;
-    case NMFX_PRO_RATIO_SQ: return x / (y * y);
-    case NMFX_PRO_RECIP2: return 1.0f / y;
-    case NMFX_PRO_DIFF: return y - x;
-    default: return x;
-    }
-}
-template <bool HEAVY>
-__device__ __forceinline__ float4 pro4(int func, float4 x, float4 y, float e1, float e2) {
-    return make_float4(pro1<HEAVY>(func, x.x, y.x, e1, e2), pro1<HEAVY>(func, x.y, y.y, e1, e2), pro1<HEAVY>(func, x.z, y.z, e1, e2),
-                       pro1<HEAVY>(func, x.w, y.w, e1, e2));
-}
 
 // one thread's share of a BR x BK operand tile: NCH chunks of 4 elements along the contiguous direction
 template <int BR, bool KC, bool FAST, bool HEAVY>
@@ -165,16 +117,6 @@ struct Loader {
     }
 };
 
-template <bool HEAVY>
-__device__ __forceinline__ double div_term(int div, float v, float s, float al, float be) {
-    if (HEAVY && div == NMFX_DIV_AB)   // nmf.m:214 (the trailing "+ beta" is the reference's)
-        return (double)(powf(v, al) * powf(s, be)) - ((double)al * powf(v, al + be) + (double)be * powf(s, al + be) + (double)be) / ((double)al + (double)be);
-    switch (div) {
-    case NMFX_DIV_KL: return (double)(v * logf(v / s)) - (double)v + (double)s;     // nmf.m:210
-    case NMFX_DIV_IS: return (double)(logf(s / v) + v / s) - 1.0;                   // nmf.m:212
-    default: { float d = v - s; return (double)d * (double)d; }                     // nmf.m:208 (0.5 applied later)
-    }
-}
 
 // HEAVY: instantiations that carry the powf-based element maps / alpha-beta cost (kept out of the common kernels: the
 // inlined powf bodies cost registers and scratch in every variant otherwise)
@@ -297,279 +239,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-// =====================================================================================================================
-// Pipelined variant for tile-aligned problems (the hot instantiations of cnmf / the materialised paths).
-// Same tiling, LDS layout, MFMA roles and epilogue as gemm_kernel, but nothing is left outside the MFMA stream: a wave
-// issues in order, so every global load (two k-tiles ahead, into one of two register sets), every element map + LDS store
-// (one k-tile ahead) and every LDS operand read (one MFMA step ahead) is placed in the 64-cycle shadow of a specific MFMA
-// (sched_barrier after each).  Tile indices past the end are clamped instead of branched on: the redundant loads hit L2
-// and the redundant LDS stores land in the buffer nobody reads again.
-// =====================================================================================================================
-template <int BR, bool KC, bool PRO>
-struct PLoader {
-    static constexpr int NCH = BR * BK / 4 / NTHREADS;     // float4 chunks per thread per k-tile: 4 (BR = 128) or 2 (BR = 64)
-    static constexpr int LDS_STRIDE = BR + (KC ? 1 : 0);
-    static constexpr int CPR = KC ? (BK / 4) : (BR / 4);
-    static constexpr int LSTEP = NTHREADS / CPR;
-    float4 x[2][NCH];
-    float4 y[PRO ? 2 : 1][PRO ? NCH : 1];
-    int okm[2];                  // bit p: chunk p of the set is inside the view (shift zero-fill otherwise)
-    long offr[KC ? NCH : 1];
-    int gr[KC ? NCH : 1];
-    int c, q;
-    int kt, kin;                 // KC stacked views: t block and offset inside it of the NEXT tile to load (tile-uniform: blk % BK == 0)
-    long kc_next;                // first contraction index of the next tile to load
-
-    __device__ __forceinline__ void init(const OpView &v, int tid, int r_tile0, long kbeg) {
-        c = tid % CPR;
-        q = tid / CPR;
-        if (KC) {
-#pragma unroll
-            for (int p = 0; p < NCH; ++p) dec_r(v, r_tile0 + q + p * LSTEP, offr[p], gr[p]);
-        } else {
-            dec_r(v, r_tile0 + 4 * c, offr[0], gr[0]);
-        }
-        kc_next = kbeg;
-        kt = 0; kin = (int)kbeg;
-        if (KC && v.mode >= VIEW_HSTACK_KC) { kt = (int)(kbeg / v.blk); kin = (int)(kbeg - (long)kt * v.blk); }
-    }
-    // tile-uniform part of dec_k for the KC views
-    __device__ __forceinline__ void kc_uniform(const OpView &v, long &off, int &g) const {
-        switch (v.mode) {
-        case VIEW_HSTACK_KC: off = (long)kin - v.ld * kt; g = -kt; break;
-        case VIEW_WSTACK_KC: off = (long)kin + v.tstride * kt; g = 0; break;
-        case VIEW_XSHIFT_KC: off = (long)kin + v.ld * kt; g = -kt; break;
-        default: off = kc_next; g = 0; break;   // VIEW_KC
-        }
-    }
-    // issue the global load(s) of chunk P of the next tile into register set SET
-    template <int SET, int P>
-    __device__ __forceinline__ void issue(const OpView &v) {
-        long off; int g;
-        if (KC) {
-            long ok; int gk;
-            kc_uniform(v, ok, gk);
-            off = offr[P] + ok + 4 * c;
-            g = gr[P] + gk;
-        } else {
-            const long kc = kc_next + q + P * LSTEP;
-            off = offr[0] + v.ld * kc;
-            g = gr[0] + (v.mode == VIEW_HSTACK_RC ? (int)kc + v.goff : 0);
-        }
-        const bool ok = g >= 0;
-        if (P == 0) okm[SET] = 0;
-        okm[SET] |= ok ? (1 << P) : 0;
-        const long o = ok ? off : 0;            // out-of-view chunks read the view's first (always valid) element and are zeroed at commit
-        x[SET][P] = *reinterpret_cast<const float4 *>(v.p + o);
-        if (PRO) { if (v.p2) y[PRO ? SET : 0][PRO ? P : 0] = *reinterpret_cast<const float4 *>(v.p2 + o); }
-    }
-    // advance to the following tile unless `last` (clamped re-load of the final tile)
-    __device__ __forceinline__ void advance(const OpView &v, bool more) {
-        if (!more) return;
-        kc_next += BK;
-        if (KC && v.mode >= VIEW_HSTACK_KC) { kin += BK; if (kin >= v.blk) { kin -= v.blk; ++kt; } }
-    }
-    // element map + LDS store of chunk P of register set SET
-    template <int SET, int P>
-    __device__ __forceinline__ void commit(const OpView &v, float *S) {
-        float4 t = x[SET][P];
-        if (PRO) { if (v.func != NMFX_PRO_NONE) t = pro4<false>(v.func, t, y[PRO ? SET : 0][PRO ? P : 0], 0.f, 0.f); }
-        if (!((okm[SET] >> P) & 1)) t = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int line = q + P * LSTEP;
-        if (KC) {
-            S[(4 * c + 0) * LDS_STRIDE + line] = t.x;
-            S[(4 * c + 1) * LDS_STRIDE + line] = t.y;
-            S[(4 * c + 2) * LDS_STRIDE + line] = t.z;
-            S[(4 * c + 3) * LDS_STRIDE + line] = t.w;
-        } else {
-            *reinterpret_cast<float4 *>(&S[line * LDS_STRIDE + 4 * c]) = t;
-        }
-    }
-};
-
-template <int BM, int BN, bool A_KC, bool B_KC, bool PRO>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    using LA = PLoader<BM, A_KC, PRO>;
-    using LB = PLoader<BN, B_KC, PRO>;
-    constexpr int LDA_S = LA::LDS_STRIDE, LDB_S = LB::LDS_STRIDE;
-    constexpr int A_SZ_AL = (BK * LDA_S + 3) & ~3, B_SZ_AL = (BK * LDB_S + 3) & ~3;
-    constexpr int BUF_SZ = A_SZ_AL + B_SZ_AL;
-    constexpr int MR = BM / 64, NR = BN / 64, NM = MR * NR;
-    constexpr int NPIECE = LA::NCH + LB::NCH;            // 8, or 6 with a 64-wide tile
-    static_assert(NPIECE <= 8, "piece schedule assumes <= 8 chunks per tile");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wi0 = (wave & 1) * (BM / 2), wj0 = (wave >> 1) * (BN / 2);
-    const int i_tile0 = blockIdx.x * BM, j_tile0 = blockIdx.y * BN;
-
-    long kbeg = 0, kend = p.Kc;
-    float *C = p.C;
-    OpView vA = p.A, vB = p.B;
-    if (p.zbatch > 0) {   // blockIdx.z = shift index t: same contraction on shifted operands, slab t
-        const int z = blockIdx.z;
-        vA.p += (long)z * p.zA_off;
-        vB.p += (long)z * p.zB_off;
-        vB.lim += z * p.zB_lim;
-        vB.tstride += z * p.zB_tstride;
-        C += (long)z * p.slab_stride;
-    } else if (p.splitk > 1) {
-        kbeg = (long)blockIdx.z * p.kc_per_split;
-        kend = kbeg + p.kc_per_split < p.Kc ? kbeg + p.kc_per_split : p.Kc;
-        C += (long)blockIdx.z * p.slab_stride;
-    }
-    const int ntiles = (int)((kend - kbeg) / BK);
-
-    LA la; LB lb;
-    la.init(vA, tid, i_tile0, kbeg);
-    lb.init(vB, tid, j_tile0, kbeg);
-
-    f32x16 acc[NR][MR];
-#pragma unroll
-    for (int a = 0; a < NR; ++a)
-#pragma unroll
-        for (int b = 0; b < MR; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
-
-    // compile-time unrolled helpers over the chunk pieces: pieces 0..NCH_A-1 belong to A, the rest to B
-    auto issue_piece = [&](auto set_c, auto piece_c) {
-        constexpr int SET = decltype(set_c)::value, PC = decltype(piece_c)::value;
-        if constexpr (PC < LA::NCH) la.template issue<SET, PC>(vA);
-        else if constexpr (PC < NPIECE) lb.template issue<SET, PC - LA::NCH>(vB);
-    };
-    auto commit_piece = [&](auto set_c, auto piece_c, float *buf) {
-        constexpr int SET = decltype(set_c)::value, PC = decltype(piece_c)::value;
-        if constexpr (PC < LA::NCH) la.template commit<SET, PC>(vA, buf);
-        else if constexpr (PC < NPIECE) lb.template commit<SET, PC - LA::NCH>(vB, buf + A_SZ_AL);
-    };
-    auto for_pieces = [&](auto f) {
-        f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
-        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-
-    if (ntiles > 0) {
-        // prologue: tile 0 -> set 0 -> LDS buffer 0; tile 1 (or 0 again) -> set 1, left in flight
-        for_pieces([&](auto pc) { issue_piece(S0{}, pc); });
-        la.advance(vA, ntiles > 1); lb.advance(vB, ntiles > 1);
-        for_pieces([&](auto pc) { issue_piece(S1{}, pc); });
-        la.advance(vA, ntiles > 2); lb.advance(vB, ntiles > 2);
-        for_pieces([&](auto pc) { commit_piece(S0{}, pc, smem); });
-    }
-    __syncthreads();
-
-    // one k-tile: MFMAs on LDS buffer CUR; loads of tile t+2 into set CUR (its previous content, tile t, is already in LDS);
-    // commits of set CUR^1 (tile t+1) into LDS buffer CUR^1
-    auto tile = [&](auto cur_c, int t) {
-        constexpr int CUR = decltype(cur_c)::value;
-        const float *Ac = smem + CUR * BUF_SZ, *Bc = Ac + A_SZ_AL;
-        float *Nb = smem + (CUR ^ 1) * BUF_SZ;
-        float fa[2][NR], fb[2][MR];
-#pragma unroll
-        for (int a = 0; a < NR; ++a) fa[0][a] = Bc[h * LDB_S + wj0 + 32 * a + l31];
-#pragma unroll
-        for (int b = 0; b < MR; ++b) fb[0][b] = Ac[h * LDA_S + wi0 + 32 * b + l31];
-        auto step = [&](auto kk_c) {
-            constexpr int kk = decltype(kk_c)::value;
-            constexpr int cb = kk & 1, nb = cb ^ 1;
-#pragma unroll
-            for (int j = 0; j < NM; ++j) {
-                const int a = j / MR, b = j % MR;
-                if (kk + 1 < BK / 2) {   // operand registers of step kk+1, one or two per MFMA slot
-                    constexpr int per = (NR + MR + NM - 1) / NM;
-#pragma unroll
-                    for (int u = 0; u < per; ++u) {
-                        const int o = j * per + u;
-                        if (o < NR) fa[nb][o] = Bc[(2 * kk + 2 + h) * LDB_S + wj0 + 32 * o + l31];
-                        else if (o < NR + MR) fb[nb][o - NR] = Ac[(2 * kk + 2 + h) * LDA_S + wi0 + 32 * (o - NR) + l31];
-                    }
-                }
-                if (j == 0 && kk < 8) issue_piece(cur_c, std::integral_constant<int, (kk < 8 ? kk : 0)>{});
-                if (j == NM - 1 && kk >= 8) commit_piece(std::integral_constant<int, CUR ^ 1>{}, std::integral_constant<int, (kk >= 8 ? kk - 8 : 0)>{}, Nb);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][a], fb[cb][b], acc[a][b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-        step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-        step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
-        step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
-        la.advance(vA, t + 3 < ntiles); lb.advance(vB, t + 3 < ntiles);
-        __syncthreads();
-    };
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(S0{}, t);
-        if (t + 1 < ntiles) tile(S1{}, t + 1);
-    }
-
-    // epilogue: identical to gemm_kernel's (acc[a][b][e] = C[i][j], i = i_tile0+wi0+32b+l31, j = j_tile0+wj0+32a+(e&3)+8(e>>2)+4h)
-    double part = 0.0;
-#pragma unroll
-    for (int a = 0; a < NR; ++a)
-#pragma unroll
-        for (int b = 0; b < MR; ++b) {
-            const long i = i_tile0 + wi0 + 32 * b + l31;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long j = j_tile0 + wj0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float sv = acc[a][b][e];
-                if (p.epi == EPI_COST) {
-                    if (p.cost_ncols == 0 || j < p.cost_ncols) part += div_term<false>(p.cost_div, p.Vref[i + p.ldv * j], sv, p.cost_alpha, p.cost_beta);
-                    if (p.store_c) C[i + p.ldc * j] = sv;
-                } else {
-                    if (p.accumulate) sv += C[i + p.ldc * j];
-                    if (p.clamp0) sv = fmaxf(sv, 0.0f);
-                    C[i + p.ldc * j] = sv;
-                }
-            }
-        }
-    if (p.epi == EPI_COST) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        double *red = reinterpret_cast<double *>(smem);
-        __syncthreads();
-        if (lane == 0) red[wave] = part;
-        __syncthreads();
-        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    }
-}
-
-template <int BM, int BN, bool A_KC, bool B_KC, bool PRO>
-static nmfx_status launch_pipe_cfg(hipStream_t st, const GemmParams &p) {
-    using LA = PLoader<BM, A_KC, PRO>;
-    using LB = PLoader<BN, B_KC, PRO>;
-    constexpr int A_SZ_AL = (BK * LA::LDS_STRIDE + 3) & ~3, B_SZ_AL = (BK * LB::LDS_STRIDE + 3) & ~3;
-    const size_t lds = sizeof(float) * 2 * (A_SZ_AL + B_SZ_AL);
-    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, PRO>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    dim3 grid((unsigned)(p.M / BM), (unsigned)(p.N / BN), (unsigned)(p.zbatch > 0 ? p.zbatch : (p.splitk > 1 ? p.splitk : 1)));
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, p);
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
-}
-
-static bool is_kc(int mode);
-template <int BM, int BN>
-static nmfx_status dispatch_pipe(hipStream_t st, const GemmParams &p) {
-    const bool akc = is_kc(p.A.mode), bkc = is_kc(p.B.mode);
-    const bool pro = p.A.func != NMFX_PRO_NONE || p.B.func != NMFX_PRO_NONE;
-#define NMFX_PIPE(AK, BKC_)                                                                     \
-    return pro ? launch_pipe_cfg<BM, BN, AK, BKC_, true>(st, p) : launch_pipe_cfg<BM, BN, AK, BKC_, false>(st, p)
-    if (akc && bkc) { NMFX_PIPE(true, true); }
-    if (akc) { NMFX_PIPE(true, false); }
-    if (bkc) { NMFX_PIPE(false, true); }
-    NMFX_PIPE(false, false);
-#undef NMFX_PIPE
-}
-
 template <int BM, int BN, bool A_KC, bool B_KC, bool FAST, bool HEAVY = false>
 static nmfx_status launch_cfg(hipStream_t st, const GemmParams &p) {
     using LA = Loader<BM, A_KC, FAST, HEAVY>;
@@ -588,7 +257,6 @@ static nmfx_status launch_cfg(hipStream_t st, const GemmParams &p) {
     return NMFX_OK;
 }
 
-static bool is_kc(int mode) { return mode == VIEW_KC || mode == VIEW_HSTACK_KC || mode == VIEW_WSTACK_KC || mode == VIEW_XSHIFT_KC; }
 
 static bool view_fast_ok(const OpView &v) {
     if ((reinterpret_cast<uintptr_t>(v.p) & 15) || (v.p2 && (reinterpret_cast<uintptr_t>(v.p2) & 15))) return false;
@@ -638,11 +306,7 @@ nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
     if (!fast || heavy) bm = bn = 128;
     if (heavy) fast = fast && (p.M % 128 == 0) && (p.N % 128 == 0);
     if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    if (pipe) {
-        if (bm == 64) return dispatch_pipe<64, 128>(st, p);
-        if (bn == 64) return dispatch_pipe<128, 64>(st, p);
-        return dispatch_pipe<128, 128>(st, p);
-    }
+    if (pipe) return dispatch_pipe(st, p, bm, bn);
     if (heavy) return fast ? dispatch_views<128, 128, true, true>(st, p) : dispatch_views<128, 128, false, true>(st, p);
     if (bm == 64) return fast ? dispatch_views<64, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
     if (bn == 64) return fast ? dispatch_views<128, 64, true>(st, p) : dispatch_views<128, 128, false>(st, p);

@@ -1,0 +1,71 @@
+// Shared by gemm.hip (general kernel + host dispatch) and gemm_pipe.hip (pipelined kernel): view decoding, element maps,
+// divergence terms.
+#pragma once
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ void dec_r(const OpView &v, int r, long &off, int &g) {
+    switch (v.mode) {
+    case VIEW_RC: off = r; g = 0; break;
+    case VIEW_HSTACK_RC: { int rr = r + v.lim; int t = rr / v.blk; int k = rr - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
+    case VIEW_HSTACK_KC: off = v.ld * r; g = (v.tstride > 0 && r >= v.tstride) ? -(1 << 30) : r + v.lim + v.goff; break;
+    case VIEW_XSHIFT_KC: off = v.ld * r; g = v.lim - 1 - r; break;
+    default: off = v.ld * r; g = 0; break;  // VIEW_KC, VIEW_WSTACK_KC
+    }
+}
+__device__ __forceinline__ void dec_k(const OpView &v, int kc, long &off, int &g) {
+    switch (v.mode) {
+    case VIEW_RC: off = v.ld * kc; g = 0; break;
+    case VIEW_HSTACK_RC: off = v.ld * kc; g = kc + v.goff; break;
+    case VIEW_HSTACK_KC: { int t = kc / v.blk; int k = kc - t * v.blk; off = (long)k - v.ld * t; g = -t; } break;
+    case VIEW_WSTACK_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.tstride * t; g = 0; } break;
+    case VIEW_XSHIFT_KC: { int t = kc / v.blk; int i = kc - t * v.blk; off = (long)i + v.ld * t; g = -t; } break;
+    default: off = kc; g = 0; break;  // VIEW_KC
+    }
+}
+
+__device__ __forceinline__ float mpow(float x, float e) {   // MATLAB x.^e for the exponents that occur: exact for 0 and 1
+    if (e == 0.0f) return 1.0f;
+    if (e == 1.0f) return x;
+    if (e == -1.0f) return 1.0f / x;
+    return powf(x, e);
+}
+template <bool HEAVY>
+__device__ __forceinline__ float pro1(int func, float x, float y, float e1 = 0.f, float e2 = 0.f) {
+    if (HEAVY && func == NMFX_PRO_POWPROD) return mpow(x, e1) * mpow(y, e2);
+    switch (func) {
+    case NMFX_PRO_RATIO: return x / y;
+    case NMFX_PRO_RATIO_SQ: return x / (y * y);
+    case NMFX_PRO_RECIP2: return 1.0f / y;
+    case NMFX_PRO_DIFF: return y - x;
+    default: return x;
+    }
+}
+template <bool HEAVY>
+__device__ __forceinline__ float4 pro4(int func, float4 x, float4 y, float e1, float e2) {
+    return make_float4(pro1<HEAVY>(func, x.x, y.x, e1, e2), pro1<HEAVY>(func, x.y, y.y, e1, e2), pro1<HEAVY>(func, x.z, y.z, e1, e2),
+                       pro1<HEAVY>(func, x.w, y.w, e1, e2));
+}
+
+template <bool HEAVY>
+__device__ __forceinline__ double div_term(int div, float v, float s, float al, float be) {
+    if (HEAVY && div == NMFX_DIV_AB)   // nmf.m:214 (the trailing "+ beta" is the reference's)
+        return (double)(powf(v, al) * powf(s, be)) - ((double)al * powf(v, al + be) + (double)be * powf(s, al + be) + (double)be) / ((double)al + (double)be);
+    switch (div) {
+    case NMFX_DIV_KL: return (double)(v * logf(v / s)) - (double)v + (double)s;     // nmf.m:210
+    case NMFX_DIV_IS: return (double)(logf(s / v) + v / s) - 1.0;                   // nmf.m:212
+    default: { float d = v - s; return (double)d * (double)d; }                     // nmf.m:208 (0.5 applied later)
+    }
+}
+
+inline bool is_kc(int mode) { return mode == VIEW_KC || mode == VIEW_HSTACK_KC || mode == VIEW_WSTACK_KC || mode == VIEW_XSHIFT_KC; }
+// defined in gemm_pipe.hip: launches gemm_pipe_kernel<BM,BN,...> for (bm, bn) in {(128,128), (64,128), (128,64)}
+nmfx_status dispatch_pipe(hipStream_t st, const GemmParams &p, int bm, int bn);
+
+}  // namespace nmfx
