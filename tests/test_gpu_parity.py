@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def _check(got, ref, tol=TOL, cost_tol=1e-6):
+def _check(got, ref, tol=TOL, cost_tol=1e-6, cost_atol=0.0):
     (W, H, c), (W0, H0, c0) = got, ref
     cat = lambda x, ax: np.concatenate(x, axis=ax) if isinstance(x, list) else x
     assert type(W) is type(W0) and type(H) is type(H0)
@@ -21,6 +21,8 @@ def _check(got, ref, tol=TOL, cost_tol=1e-6):
     assert rel_fro(H, H0) <= tol, rel_fro(H, H0)
     if not np.all(np.isfinite(c0)):
         assert np.array_equal(np.isnan(c), np.isnan(c0)) and np.array_equal(c[~np.isnan(c0)], c0[~np.isnan(c0)])   # same +-Inf / NaN pattern
+    elif cost_atol > 0:      # exact-fit cases: the cost is rounding noise around zero, compare on the scale of the data
+        assert np.allclose(c, c0, rtol=cost_tol, atol=cost_atol), (c, c0)
     elif np.linalg.norm(c0) > 0:
         assert rel_fro(c, c0) <= cost_tol, rel_fro(c, c0)
     else:
@@ -317,3 +319,56 @@ def test_sort_dictionary_matches_oracle(gpu_lib):
         Wo, Ho = O.sort_dictionary(W, H)
         assert np.array_equal(Ws, Wo) and np.array_equal(Hs, Ho)
     assert gpu_lib.SortDictionary(g["W"])[1] is None
+
+
+# ---- edge shapes and degenerate inputs (the reference has no tests; these follow its semantics through the oracle) ---------
+@pytest.mark.parametrize("m,n,K", [(1, 1, 1), (3, 5, 1), (2, 40, 1), (40, 1, 2), (5, 4, 7), (129, 127, 3), (128, 128, 64), (130, 256, 64)])
+@pytest.mark.parametrize("div", ["euclidean", "kl", "is"])
+def test_nmf_edge_shapes(gpu_lib, m, n, K, div):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12)
+    _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg), tol=2e-5, cost_tol=1e-5, cost_atol=1e-6 * float((V ** 2).sum()))
+
+
+@pytest.mark.parametrize("m,n,K,T", [(4, 3, 1, 3), (7, 9, 2, 1), (33, 64, 4, 9), (64, 40, 32, 2), (128, 128, 64, 3)])
+def test_cnmf_edge_shapes(gpu_lib, m, n, K, T):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    for div in ("euclidean", "kl"):
+        cfg = dict(divergence=div, W_init=W0 if T > 1 else W0[:, :, 0], H_init=H0, maxiter=5, tolerance=1e-12)
+        _check(gpu_lib.cnmf(V, K, T, cfg), O.cnmf(V, K, T, cfg), tol=2e-5, cost_tol=1e-5, cost_atol=1e-6 * float((V ** 2).sum()))
+    with pytest.raises(Exception):
+        gpu_lib.cnmf(V, K, n + 1, dict(maxiter=1))          # context longer than the data
+
+
+def test_degenerate_inputs(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(64, 96, 4)
+    # everything fixed: nothing moves, the cost is constant and the strict-decrease stop rule (nmf.m:221) never fires
+    cfg = dict(W_init=W0, H_init=H0, W_fixed=True, H_fixed=True, maxiter=5)
+    W, H, c = gpu_lib.nmf(V, 4, cfg)
+    Wo, Ho, co = O.nmf(V, 4, cfg)
+    assert len(c) == len(co) == 5 and np.allclose(c, c[0]) and rel_fro(W, Wo) < 1e-6 and rel_fro(H, H0) < 1e-7
+    # zeros in V: KL cost is NaN every iteration (0*log(0)), W/H stay finite where the oracle's do
+    Vz = V.copy()
+    Vz[::7, ::5] = 0.0
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=4)
+    W, H, c = gpu_lib.nmf(Vz, 4, cfg)
+    Wo, Ho, co = O.nmf(Vz, 4, cfg)
+    assert len(c) == len(co) == 4 and np.all(np.isnan(c)) and np.all(np.isnan(co))
+    assert rel_fro(W, Wo) < 1e-5 and rel_fro(H, Ho) < 1e-5
+    # an all-zero column of V and a zero row of H_init: euclidean keeps them at zero
+    V2, H2 = V.copy(), H0.copy()
+    V2[:, 3] = 0.0
+    H2[1, :] = 0.0
+    cfg = dict(W_init=W0, H_init=H2, maxiter=5, tolerance=1e-12)
+    got, ref = gpu_lib.nmf(V2, 4, cfg), O.nmf(V2, 4, cfg)
+    assert np.array_equal(np.isnan(got[0]), np.isnan(ref[0])) and np.array_equal(np.isnan(got[1]), np.isnan(ref[1]))
+    ok = ~np.isnan(ref[1])
+    assert np.allclose(got[1][ok], ref[1][ok], rtol=1e-4, atol=1e-6) and np.all(got[1][1, ~np.isnan(got[1][1])] == 0)
+    # maxiter = 1 and a huge tolerance: one iteration, one cost entry (the stop rule needs iter > 1)
+    W, H, c = gpu_lib.nmf(V, 4, dict(W_init=W0, H_init=H0, maxiter=1, tolerance=1e9))
+    assert len(c) == 1
+    W, H, c = gpu_lib.nmf(V, 4, dict(W_init=W0, H_init=H0, maxiter=50, tolerance=1e9))
+    assert len(c) == 2                                      # stops at the first comparison it is allowed to make
