@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -184,8 +185,8 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->Gp = euc ? f.take<float>(Kn) : nullptr;
         e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
         e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
-        size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m);
-        e->gemm_scratch_bytes = euc ? std::max(g1, g2) : 0;
+        size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
+        e->gemm_scratch_bytes = euc ? std::max(std::max(g1, g2), g3) : 0;
         e->gemm_scratch = e->gemm_scratch_bytes ? f.take<float>(e->gemm_scratch_bytes / sizeof(float)) : nullptr;
         e->lamW = f.take<float>(e->K); e->lamH = f.take<float>(e->K);
         e->fixW = f.take<uint8_t>(e->K); e->fixH = f.take<uint8_t>(e->K);
@@ -653,7 +654,24 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         f.c_per_split = e->m / e->isplit_h;
         const int func = e->div == NMFX_DIV_KL ? 2 : 0;
         const bool kl = e->div == NMFX_DIV_KL;
-        if (e->isplit_h == 1 && e->algo != 3) {
+        static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
+        if (func == 0 && !euc_fused_h) {
+            // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
+            // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
+            {
+                Scope s(e, TAG_HNUM);
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->K; g.N = e->n; g.Kc = e->m;
+                g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{e->V, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.C = e->Gn; g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
+            }
+            Scope s(e, TAG_SMALL);
+            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        } else if (e->isplit_h == 1 && e->algo != 3) {
             f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
@@ -1047,8 +1065,9 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     TRY(stage.alloc(STAGE_ELEMS * 8));
     const int nparts = (int)gemm_grid_blocks(m, n);
     TRY(part.alloc(sizeof(double) * nparts)); TRY(costd.alloc(64 + sizeof(double) * K));
-    size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n);
+    size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n), sb3 = gemm_scratch_bytes(K, n, m);
     if (sb2 > sb) sb = sb2;
+    if (sb3 > sb) sb = sb3;
     TRY(scratch.alloc(sb));
     if (!dev) {
         TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
@@ -1134,6 +1153,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
     auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
+        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_TERMS") != nullptr;   // dev switch: A/B
+        if (sc_fused_terms) {
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;
         memset(&f, 0, sizeof(f));
@@ -1141,6 +1162,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         f.out = isplit_h == 1 ? Gb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
         TRY(launch_fused(st, f, isplit_h, false, 0, true, 0));
         if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Gb.as<float>(), 0));
+        } else
+        // W'*V has no first product: the pipelined GEMM beats the register-stationary kernel on a plain contraction
+        TRY(kk_gemm(K, n, m, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Vp, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                    Gb.as<float>(), K));
         TRY(kk_gemm(K, K, m, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
         return kk_gemm(K, n, K, OpView{KKb.as<float>(), nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                        OpView{Hx, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, Denb.as<float>(), K);
@@ -1148,12 +1173,17 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx'); N_ has room for K*K more floats: [N | Hx*Hx'] is what column shards sum
     auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
         float *KK = N_ + mK;
+        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_TERMS") != nullptr;   // dev switch: A/B
+        if (sc_fused_terms) {
         FusedParams f;
         memset(&f, 0, sizeof(f));
         f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
         f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
         TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
         if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));
+        } else
+        TRY(kk_gemm(m, K, n, OpView{Vp, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                    N_, m));
         TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KK, K));
         if (comm.active()) TRY(comm.allreduce(N_, (long)(mK + (size_t)K * K), NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
         return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
