@@ -323,7 +323,7 @@ int gemm_pick_split(long M, long N, long Kc) {
     const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long ktiles = (Kc + BK - 1) / BK;
     int split = 1;
-    if (tiles < 256 && ktiles >= 8) {
+    if (tiles < 512 && ktiles >= 8) {   // two workgroups fit a CU: aim for >= 512 of them
         split = (int)((512 + tiles - 1) / tiles);
         if (split > 128) split = 128;   // K x K Grams over n: one output tile, all parallelism must come from the contraction
         if (split > ktiles / 4) split = (int)(ktiles / 4);
