@@ -46,17 +46,16 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
 
     `backend` provides wstep_partial(), wstep_finish(), hstep(), the tensor `packed` (this rank's W-step sums, in place
     all-reducible) and _copy_cost(dst) (this rank's cost partial into a 1-element fp64 tensor).  One all-reduce of
-    `packed` per iteration is the only data-path collective; the 8-byte cost all-reduce exists because nmf.m returns
-    the cost vector and evaluates its stop rule on it (nmf.m:206-224).
+    `packed` per iteration is the only data-path collective.  nmf.m returns the cost vector (nmf.m:206-218): the ranks'
+    partials are collected per iteration and summed over ranks ONCE at the end (8*iters bytes) -- this loop runs a fixed
+    number of iterations, so no per-iteration cost collective is needed (the stop rule lives in the blocking host API).
     On the fused path (backend.cost_lags == True) the cost of iteration i is a by-product of the W-step pass of iteration
     i+1; the last one needs backend.cost_pass().
     """
     lag = bool(getattr(backend, "cost_lags", False))
 
     def emit(idx):
-        tmp = cost_out[idx:idx + 1]
-        backend._copy_cost(tmp)
-        dist.all_reduce(tmp, group=group)
+        backend._copy_cost(cost_out[idx:idx + 1])
 
     for it in range(iters):
         backend.wstep_partial()
@@ -73,6 +72,8 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
     if lag and iters > 0 and cost_out is not None:
         backend.cost_pass()
         emit(iters - 1)
+    if iters > 0 and cost_out is not None:
+        dist.all_reduce(cost_out[:iters], group=group)        # local partials -> global costs, one small collective
 
 
 class Engine:
