@@ -201,6 +201,12 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e);
  * columns from the neighbouring ranks; nmfx_engine_hstep_finish then refreshes V_hat / the cost with the new H. */
 nmfx_status nmfx_engine_defer_hstep_finish(nmfx_engine *e, int32_t defer);
 nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e);
+/* Row-chunked form of wstep_partial (fused path): chunk c of nchunks computes rows [c*m/nchunks, (c+1)*m/nchunks) of the W-step
+ * sums into a contiguous block of `packed`; nmfx_engine_packed_chunk gives the element range that is final after chunk c (the last
+ * one carries the small tail).  The multi-GPU driver all-reduces chunk c while chunk c+1 computes; wstep_finish reads the chunked
+ * layout.  m must be a multiple of 128*nchunks.  nmfx_engine_wstep_partial == one chunk. */
+nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks);
+nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks, size_t *offset, size_t *count);
 /* make the engine's cost refer to the CURRENT (W, H): no-op when it already does, else one fused S = W*H pass */
 nmfx_status nmfx_engine_cost_pass(nmfx_engine *e);
 int32_t nmfx_engine_is_fused(nmfx_engine *e);   /* 1 = fused kernels (cost lags one pass), 2 = Gram-form cnmf, 0 = materialised V_hat */

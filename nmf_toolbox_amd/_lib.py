@@ -23,7 +23,7 @@ EXPORTS = [
     "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass", "nmfx_engine_is_fused", "nmfx_engine_defer_hstep_finish", "nmfx_engine_hstep_finish", "nmfx_engine_cost_ptr", "nmfx_engine_copy_cost", "nmfx_engine_set_rank0",
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
-    "nmfx_engine_set_constraint", "nmfx_nmfsc_dev",
+    "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
 ]
 
 
@@ -104,6 +104,8 @@ def load():
     lib.nmfx_engine_hstep_finish.argtypes = [C.c_void_p]
     for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass"):
         getattr(lib, name).argtypes = [C.c_void_p]
+    lib.nmfx_engine_wstep_partial_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.nmfx_engine_packed_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.nmfx_engine_copy_cost.argtypes = [C.c_void_p, C.c_void_p]
     lib.nmfx_engine_set_rank0.argtypes = [C.c_void_p, C.c_int32]

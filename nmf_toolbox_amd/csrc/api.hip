@@ -90,6 +90,8 @@ struct nmfx_engine {
     bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
     float *CC;                // KT x KT Gram of the stacked W (gram path)
     int nsplit_w, isplit_h;
+    int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
+    int chunk_parts;          // cost partials written by the chunks so far
     float *WT, *slabs, *Pbuf, *GW;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
     // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
@@ -179,7 +181,8 @@ Layout layout(nmfx_engine *e, void *ws) {
         Carver f(ws);
         e->Vhat = nullptr;
         e->WT = f.take<float>(mKT);
-        e->slabs = f.take<float>(std::max((size_t)e->nsplit_w * mKT, (size_t)e->isplit_h * Kn));
+        // row-chunked W steps use more splits on fewer rows: rows*split per launch never exceeds max(nsplit_w, 2) * m / 2
+        e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
         e->Gn = f.take<float>(Kn);
         const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
         e->Gp = euc ? f.take<float>(Kn) : nullptr;
@@ -193,7 +196,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
         e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
         e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
-        e->n_cost_partials = (int)((e->m / 128) * e->nsplit_w);
+        e->n_cost_partials = (int)((e->m / 128) * 64);   // any (row chunk, split) decomposition of the W-step pass
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
         e->sumV = f.take<double>(1);
@@ -401,28 +404,54 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
                        e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV);
 }
 
-// fused W-step pass (K2) or cost-only pass over the local shard; cost refers to the CURRENT (W, H)
-nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
+// grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
+int fused_split(long blocks, long extent) {
+    int s = 1;
+    while (blocks * s < 256 && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
+    return s;
+}
+
+// fused W-step pass (K2) or cost-only pass over rows [row0, row0 + rows) of the local shard.  N of those rows goes to `out`
+// as a contiguous rows x K block; cost partials are appended at e->chunk_parts.
+nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out) {
+    const int split = fused_split(rows / 128, e->n);
+    if ((size_t)split * rows * e->K > (size_t)std::max(e->nsplit_w, 2) * e->m * e->K || e->chunk_parts + (rows / 128) * split > e->n_cost_partials) {
+        set_error("fused W-step: row chunk too small for the workspace");
+        return NMFX_ERR_INVALID;
+    }
     FusedParams f;
     memset(&f, 0, sizeof(f));
-    f.X = e->W; f.xs_r = 1; f.xs_k = e->m;
-    f.Y = e->H; f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->K;
-    f.c_per_split = e->n / e->nsplit_w;
-    f.out = e->nsplit_w == 1 ? e->packed : e->slabs;
-    f.slab_stride = e->m * (long)e->K; f.os_r = 1; f.os_k = e->m;
-    f.cost_partials = e->cost_partials;
+    f.X = e->W + row0; f.xs_r = 1; f.xs_k = e->m;
+    f.Y = e->H; f.D = e->V + row0; f.ldd = e->m; f.R = rows; f.Cn = e->n; f.K = e->K;
+    f.c_per_split = e->n / split;
+    f.out = split == 1 ? out : e->slabs;
+    f.slab_stride = rows * (long)e->K; f.os_r = 1; f.os_k = rows;
+    f.cost_partials = e->cost_partials + e->chunk_parts;
     const int func = e->div == NMFX_DIV_KL ? 3 : 1;
     {
         Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
-        TRY(launch_fused(e->st, f, e->nsplit_w, true, func, do_g2, 0));
+        TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
     }
+    e->chunk_parts += (int)((rows / 128) * split);
+    if (do_g2 && split > 1) {
+        Scope s(e, TAG_SMALL);
+        TRY(reduce_slabs(e->st, e->slabs, split, f.slab_stride, f.slab_stride, out, 0));
+    }
+    return NMFX_OK;
+}
+// after the last row chunk: rowsum(H) (KL: also the W-step denominator, nmf.m:153) and the cost of the CURRENT (W, H)
+nmfx_status fused_wpass_finish(nmfx_engine *e) {
     Scope s(e, TAG_SMALL);
-    if (do_g2 && e->nsplit_w > 1) TRY(reduce_slabs(e->st, e->slabs, e->nsplit_w, f.slab_stride, f.slab_stride, e->packed, 0));
     const bool kl = e->div == NMFX_DIV_KL;
-    if (kl) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));   // also the W-step denominator (nmf.m:153)
-    TRY(cost_from_partials(e, (int)((e->m / 128) * e->nsplit_w), kl));
+    if (kl) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+    TRY(cost_from_partials(e, e->chunk_parts, kl));
     e->cost_valid = true;
     return NMFX_OK;
+}
+nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
+    e->chunk_parts = 0;
+    TRY(fused_wpass_rows(e, do_g2, 0, e->m, e->packed));
+    return fused_wpass_finish(e);
 }
 
 nmfx_status refresh_w_derived(nmfx_engine *e) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
@@ -549,22 +578,62 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
 }
 
 // local sums of the W step: packed = [N | P]  or  [N | Pvec]        nmf.m:149-164 / cnmf.m:187-192
+static nmfx_status fused_wstep_tail(nmfx_engine *e);
+static nmfx_status generic_wstep_partial(nmfx_engine *e);
 nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
-    const size_t mKT = (size_t)e->m * e->KT;
     if (e->fused) {
         // one pass over V: N = (V./(W*H)) * H' (KL) or V*H' (euclidean), and the cost of the current (W, H) as a by-product
+        e->w_chunks = 1;
         TRY(fused_wpass(e, true));
-        if (e->div == NMFX_DIV_KL) {
-            Scope s(e, TAG_SMALL);
-            TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
-        } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
-            Scope s(e, TAG_GRAM);
-            TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                           OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
-        }
-        return NMFX_OK;
+        return fused_wstep_tail(e);
     }
+    return generic_wstep_partial(e);
+}
+
+// what follows the last row chunk of a fused W-step partial: the small tail of `packed`
+static nmfx_status fused_wstep_tail(nmfx_engine *e) {
+    const size_t mKT = (size_t)e->m * e->KT;
+    if (e->div == NMFX_DIV_KL) {
+        Scope s(e, TAG_SMALL);
+        TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
+    } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
+        Scope s(e, TAG_GRAM);
+        TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
+    }
+    return NMFX_OK;
+}
+
+// row-chunked form of the fused W-step partial (overlap of the all-reduce with compute on column shards): chunk c of nchunks
+// computes rows [c*m/nchunks, (c+1)*m/nchunks) of N into the contiguous block packed + c*(m/nchunks)*K; after the last chunk the
+// tail ([rowsum(H)] or [H*H']) and the lagged cost are ready.  wstep_finish reads the chunked layout.
+nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks) {
+    NMFX_HIP(hipSetDevice(e->device));
+    if (!e->fused) { set_error("nmfx_engine_wstep_partial_chunk: fused path only"); return NMFX_ERR_UNSUPPORTED; }
+    if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % (128L * nchunks) != 0) { set_error("nmfx_engine_wstep_partial_chunk: m must split into nchunks multiples of 128 rows"); return NMFX_ERR_INVALID; }
+    const long rows = e->m / nchunks;
+    if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; }
+    TRY(fused_wpass_rows(e, true, rows * chunk, rows, e->packed + (size_t)chunk * rows * e->K));
+    if (chunk + 1 < nchunks) return NMFX_OK;
+    TRY(fused_wpass_finish(e));
+    return fused_wstep_tail(e);
+}
+// element range of `packed` that becomes final with chunk c (the last one carries the tail): what the caller all-reduces
+nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks, size_t *offset, size_t *count) {
+    if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % nchunks != 0) { set_error("nmfx_engine_packed_chunk: bad chunk"); return NMFX_ERR_INVALID; }
+    const size_t per = (size_t)(e->m / nchunks) * e->KT, mKT = (size_t)e->m * e->KT;
+    size_t tail = 0;
+    if (e->fused) tail = e->div == NMFX_DIV_EUCLIDEAN ? (size_t)e->K * e->K : (size_t)e->KT;
+    else if (nchunks != 1) { set_error("nmfx_engine_packed_chunk: only the fused path chunks its W step"); return NMFX_ERR_UNSUPPORTED; }
+    else tail = e->gram ? (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? mKT : (size_t)e->KT);
+    *offset = per * chunk;
+    *count = per + (chunk + 1 == nchunks ? tail : 0);
+    return NMFX_OK;
+}
+
+static nmfx_status generic_wstep_partial(nmfx_engine *e) {
+    const size_t mKT = (size_t)e->m * e->KT;
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
@@ -593,6 +662,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         const size_t mK = (size_t)e->m * e->K;
         WUpdateParams p{};
         p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = 1;
+        p.n_chunks = e->w_chunks > 1 ? e->w_chunks : 1;   // row-chunked partial: N is stored as contiguous (m/chunks x K) blocks
         p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
         if (e->div == NMFX_DIV_KL) {
             Scope s(e, TAG_SMALL);

@@ -165,12 +165,15 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     const int k = c % p.K;
     if (p.fixW && p.fixW[k]) return;
     float *w = p.W + p.m * c;
-    const float *nn = p.N + p.m * c;
+    // numerator column c: plain m x KT layout, or n_chunks contiguous (cr x KT) row blocks (chunk ch holds rows [ch*cr, (ch+1)*cr))
+    const int nch = p.n_chunks > 1 ? p.n_chunks : 1;
+    const long cr = p.m / nch;
+    const long KT = (long)p.K * p.T;
     const float *pp = p.P ? p.P + p.m * c : nullptr;
     const float pv = p.Pvec ? (float)p.Pvec[c] : 0.0f;
     double dn = 0.0, dp = 0.0;
     const float lam = p.lamW ? p.lamW[k] : 0.0f;
-    const bool vec = (p.m & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(nn) | reinterpret_cast<uintptr_t>(pp)) & 15) == 0;
+    const bool vec = (cr & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(p.N) | reinterpret_cast<uintptr_t>(pp)) & 15) == 0;
     const bool plain = p.rule == 1;   // lnmf.m:69: W .* (N ./ max(P, eps)), no diagonal terms; the column statistic is the L1 sum
     auto upd = [&](float wi, float ni, float pi, float fdn, float fdp) {
         float neg = plain ? ni : fmaf(wi, fdn, ni);
@@ -180,37 +183,45 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     };
     double ss = 0.0;
     if (vec) {
-        const long m4 = p.m / 4;
-        float4 *w4 = reinterpret_cast<float4 *>(w);
-        const float4 *n4 = reinterpret_cast<const float4 *>(nn), *p4 = reinterpret_cast<const float4 *>(pp);
+        const long c4n = cr / 4;
         const float4 pvv = make_float4(pv, pv, pv, pv);
-        for (long i = threadIdx.x; i < m4; i += 256) {
-            const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
-            dn += ((double)a.x * c4.x + (double)a.y * c4.y) + ((double)a.z * c4.z + (double)a.w * c4.w);
-            dp += ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w);
+        for (int ch = 0; ch < nch; ++ch) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(w + ch * cr), *n4 = reinterpret_cast<const float4 *>(p.N + ch * cr * KT + cr * c);
+            const float4 *p4 = reinterpret_cast<const float4 *>(pp ? pp + ch * cr : nullptr);
+            for (long i = threadIdx.x; i < c4n; i += 256) {
+                const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
+                dn += ((double)a.x * c4.x + (double)a.y * c4.y) + ((double)a.z * c4.z + (double)a.w * c4.w);
+                dp += ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w);
+            }
         }
         dn = block_sum<4>(dn, red);
         dp = block_sum<4>(dp, red);
         const float fdn = (float)dn, fdp = (float)dp;
-        for (long i = threadIdx.x; i < m4; i += 256) {
-            const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
-            float4 o;
-            o.x = upd(a.x, b.x, c4.x, fdn, fdp); o.y = upd(a.y, b.y, c4.y, fdn, fdp);
-            o.z = upd(a.z, b.z, c4.z, fdn, fdp); o.w = upd(a.w, b.w, c4.w, fdn, fdp);
-            w4[i] = o;
-            ss += plain ? ((double)o.x + o.y) + ((double)o.z + o.w) : ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+        for (int ch = 0; ch < nch; ++ch) {
+            float4 *w4 = reinterpret_cast<float4 *>(w + ch * cr);
+            const float4 *n4 = reinterpret_cast<const float4 *>(p.N + ch * cr * KT + cr * c);
+            const float4 *p4 = reinterpret_cast<const float4 *>(pp ? pp + ch * cr : nullptr);
+            for (long i = threadIdx.x; i < c4n; i += 256) {
+                const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
+                float4 o;
+                o.x = upd(a.x, b.x, c4.x, fdn, fdp); o.y = upd(a.y, b.y, c4.y, fdn, fdp);
+                o.z = upd(a.z, b.z, c4.z, fdn, fdp); o.w = upd(a.w, b.w, c4.w, fdn, fdp);
+                w4[i] = o;
+                ss += plain ? ((double)o.x + o.y) + ((double)o.z + o.w) : ((double)o.x * o.x + (double)o.y * o.y) + ((double)o.z * o.z + (double)o.w * o.w);
+            }
         }
     } else {
+        auto nat = [&](long i) { const long ch = i / cr; return p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
         for (long i = threadIdx.x; i < p.m; i += 256) {
             const float wi = w[i];
             dn += (double)wi * (double)(pp ? pp[i] : pv);
-            dp += (double)wi * (double)nn[i];
+            dp += (double)wi * (double)nat(i);
         }
         dn = block_sum<4>(dn, red);
         dp = block_sum<4>(dp, red);
         const float fdn = (float)dn, fdp = (float)dp;
         for (long i = threadIdx.x; i < p.m; i += 256) {
-            const float wn = upd(w[i], nn[i], pp ? pp[i] : pv, fdn, fdp);
+            const float wn = upd(w[i], nat(i), pp ? pp[i] : pv, fdn, fdp);
             w[i] = wn;
             ss += plain ? (double)wn : (double)wn * (double)wn;
         }

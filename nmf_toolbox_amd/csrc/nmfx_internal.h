@@ -144,6 +144,7 @@ struct WUpdateParams {
     double *sumsq;       // out [K*T]: sum of squares of the updated (un-normalised) columns
     float inv_exp;       // outer exponent 1/alpha (1 = none)
     int rule;            // 0: nmf/cnmf (diag terms, sum of squares out); 1: lnmf (plain ratio, column sum out)
+    int n_chunks;        // <= 1: N is m x K column-major.  c > 1: N = c contiguous (m/c x K) row blocks (row-chunked W-step partial)
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,

@@ -46,7 +46,8 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
 
     `backend` provides wstep_partial(), wstep_finish(), hstep(), the tensor `packed` (this rank's W-step sums, in place
     all-reducible) and _copy_cost(dst) (this rank's cost partial into a 1-element fp64 tensor).  One all-reduce of
-    `packed` per iteration is the only data-path collective.  nmf.m returns the cost vector (nmf.m:206-218): the ranks'
+    `packed` per iteration is the only data-path collective; a backend with n_chunks > 1 computes `packed` in row chunks
+    (wstep_partial_chunk / packed_chunk) and the same bytes travel as n_chunks pipelined all-reduces.  nmf.m returns the cost vector (nmf.m:206-218): the ranks'
     partials are collected per iteration and summed over ranks ONCE at the end (8*iters bytes) -- this loop runs a fixed
     number of iterations, so no per-iteration cost collective is needed (the stop rule lives in the blocking host API).
     On the fused path (backend.cost_lags == True) the cost of iteration i is a by-product of the W-step pass of iteration
@@ -57,11 +58,24 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
     def emit(idx):
         backend._copy_cost(cost_out[idx:idx + 1])
 
+    nch = int(getattr(backend, "n_chunks", 1))
     for it in range(iters):
-        backend.wstep_partial()
-        if lag and it > 0 and cost_out is not None:
-            emit(it - 1)
-        dist.all_reduce(backend.packed, group=group)          # the ONE exchange step of an iteration
+        if nch > 1:
+            # row-chunked W step: the all-reduce of chunk c (async, on the collective's own stream) overlaps the compute of
+            # chunk c+1; the lagged cost is complete after the last chunk
+            works = []
+            for c in range(nch):
+                backend.wstep_partial_chunk(c, nch)
+                works.append(dist.all_reduce(backend.packed_chunk(c, nch), group=group, async_op=True))
+            if lag and it > 0 and cost_out is not None:
+                emit(it - 1)
+            for w in works:
+                w.wait()
+        else:
+            backend.wstep_partial()
+            if lag and it > 0 and cost_out is not None:
+                emit(it - 1)
+            dist.all_reduce(backend.packed, group=group)      # the ONE exchange step of an iteration
         backend.wstep_finish()
         backend.hstep()
         if getattr(backend, "has_halos", False):
@@ -80,7 +94,7 @@ class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
     def __init__(self, V, W, H, divergence="euclidean", T=1, algorithm="nmf", lamW=None, lamH=None, fixW=None, fixH=None,
-                 group=None, use_dist=None, path=0, halo=(0, 0), n_valid=None):
+                 group=None, use_dist=None, path=0, halo=(0, 0), n_valid=None, n_chunks=None):
         import torch
         self.torch = torch
         if not (V.is_cuda and W.is_cuda and H.is_cuda):
@@ -129,6 +143,9 @@ class Engine:
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
         self.path_kind = int(self.lib.nmfx_engine_is_fused(self.h))
         self.cost_lags = self.path_kind == 1
+        # row chunks of the W-step partial on column shards (all-reduce / compute overlap): fused path, m a multiple of 256
+        world = dist.get_world_size(group) if self.dist else 1
+        self.n_chunks = int(n_chunks) if n_chunks is not None else (2 if (world > 1 and self.path_kind == 1 and self.m % 256 == 0) else 1)
         self.has_halos = bool(self.hL or self.hR)
         if self.has_halos:   # V_hat / cost are refreshed only after the neighbours' new H columns have arrived
             _lib.check(self.lib.nmfx_engine_defer_hstep_finish(self.h, 1))
@@ -146,6 +163,15 @@ class Engine:
     # ---- the four phases (HIP kernels on this rank's shard) -------------------------------------
     def wstep_partial(self):
         _lib.check(self.lib.nmfx_engine_wstep_partial(self.h))
+
+    def wstep_partial_chunk(self, chunk, nchunks):
+        _lib.check(self.lib.nmfx_engine_wstep_partial_chunk(self.h, int(chunk), int(nchunks)))
+
+    def packed_chunk(self, chunk, nchunks):
+        """the slice of `packed` that is final after chunk `chunk` (the last one carries the tail)"""
+        off, cnt = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self.lib.nmfx_engine_packed_chunk(self.h, int(chunk), int(nchunks), C.byref(off), C.byref(cnt)))
+        return self.packed[off.value:off.value + cnt.value]
 
     def wstep_finish(self):
         _lib.check(self.lib.nmfx_engine_wstep_finish(self.h))

@@ -18,7 +18,8 @@ from conftest import EPS, synth
 class NumpyShard:
     """one rank's phases in float64 (mirrors nmf_toolbox_amd/csrc/api.hip's engine, same packed layouts)"""
 
-    def __init__(self, V, W, H, div, layout, lamW, lamH, fixW, fixH, rank0):
+    def __init__(self, V, W, H, div, layout, lamW, lamH, fixW, fixH, rank0, n_chunks=1):
+        self.n_chunks = n_chunks                           # > 1: row-chunked W-step partial, packed = [chunk 0 | chunk 1 | ... | tail]
         self.V, self.W, self.H, self.div, self.layout = V, W.copy(), H.copy(), div, layout
         self.m, self.n = V.shape
         self.K = W.shape[1]
@@ -54,10 +55,34 @@ class NumpyShard:
         else:
             p[mk:] = (S @ self.H.T).ravel(order="F")
 
+    def wstep_partial_chunk(self, c, nch):
+        """rows [c*m/nch, (c+1)*m/nch) of N as a contiguous (m/nch x K) block; tail and lagged cost with the last chunk"""
+        cr = self.m // nch
+        if c == 0:
+            S = self.W @ self.H
+            A = self.V / S if self.div == "kl" else self.V
+            self._N = A @ self.H.T
+        p = self.packed.numpy()
+        p[c * cr * self.K:(c + 1) * cr * self.K] = self._N[c * cr:(c + 1) * cr].ravel(order="F")
+        if c == nch - 1:
+            mk = self.m * self.K
+            if self.cost_lags:
+                self._cost()
+            p[mk:] = self.H.sum(1) if self.div == "kl" else (self.H @ self.H.T).ravel(order="F")
+
+    def packed_chunk(self, c, nch):
+        cr = self.m // nch
+        hi = (c + 1) * cr * self.K if c < nch - 1 else self.packed.numel()
+        return self.packed[c * cr * self.K:hi]
+
     def wstep_finish(self):
         mk = self.m * self.K
         p = self.packed.numpy()
-        N = p[:mk].reshape(self.m, self.K, order="F")
+        if self.n_chunks > 1:
+            cr = self.m // self.n_chunks
+            N = np.concatenate([p[c * cr * self.K:(c + 1) * cr * self.K].reshape(cr, self.K, order="F") for c in range(self.n_chunks)], axis=0)
+        else:
+            N = p[:mk].reshape(self.m, self.K, order="F")
         if self.div == "kl":
             P = np.broadcast_to(p[mk:][None, :], N.shape)
         elif self.layout == "fused":
@@ -88,7 +113,7 @@ class NumpyShard:
         dst[0] = self.cost_local
 
 
-def _worker(rank, world, port, div, layout, iters, q):
+def _worker(rank, world, port, div, layout, iters, q, n_chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -100,7 +125,7 @@ def _worker(rank, world, port, div, layout, iters, q):
     fixW = np.array([0, 0, 0, 0, 1, 1])
     fixH = np.array([1, 1, 0, 0, 0, 0])
     lo, hi = shard_columns(n, world, rank)
-    be = NumpyShard(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0)
+    be = NumpyShard(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0, n_chunks)
     cost = torch.zeros(iters, dtype=torch.float64)
     run_sharded_iterations(be, iters, dist, None, cost)
     q.put((rank, lo, hi, be.W, be.H, cost.numpy().copy()))
@@ -117,14 +142,14 @@ def _free_port():
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
-@pytest.mark.parametrize("layout", ["generic", "fused"])
-def test_sharded_loop_matches_unsharded_oracle(div, layout):
+@pytest.mark.parametrize("layout,n_chunks", [("generic", 1), ("fused", 1), ("fused", 3)])
+def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks):
     from oracle import nmf_oracle as O
     world, iters = 2, 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q, n_chunks)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

@@ -27,8 +27,8 @@ def _engines(torch, V, W0, H0, div, parts, path):
     return engs
 
 
-def _run_emulated(torch, engs, iters):
-    """run_sharded_iterations with all_reduce == explicit sum over the engines of this process"""
+def _run_emulated(torch, engs, iters, nch=1):
+    """run_sharded_iterations with all_reduce == explicit sum over the engines of this process (nch > 1: row-chunked W step)"""
     costs = []
     lag = engs[0].cost_lags
 
@@ -40,15 +40,26 @@ def _run_emulated(torch, engs, iters):
         return c
 
     for it in range(iters):
-        for e in engs:
-            e.wstep_partial()
+        if nch > 1:
+            for c in range(nch):
+                for e in engs:
+                    e.wstep_partial_chunk(c, nch)
+                s = engs[0].packed_chunk(c, nch).clone()
+                for e in engs[1:]:
+                    s += e.packed_chunk(c, nch)
+                for e in engs:
+                    e.packed_chunk(c, nch).copy_(s)
+        else:
+            for e in engs:
+                e.wstep_partial()
+            s = engs[0].packed.clone()
+            for e in engs[1:]:
+                s += e.packed
+            for e in engs:
+                e.packed.copy_(s)
         if lag and it > 0:
             costs.append(total_cost())
-        s = engs[0].packed.clone()
-        for e in engs[1:]:
-            s += e.packed
         for e in engs:
-            e.packed.copy_(s)
             e.wstep_finish()
             e.hstep()
         if not lag:
@@ -75,6 +86,28 @@ def test_two_shards_equal_oracle(gpu_lib, div, path, m, n, K):
     Hg = np.concatenate([torch_to_colmajor(e.H) for e in engs], axis=1)
     assert np.array_equal(Wg[0], Wg[1])                      # replicated W stays bit-identical
     assert rel_fro(Wg[0], W) < 1e-5 and rel_fro(Hg, H) < 1e-5 and rel_fro(cost, c0) < 1e-6
+
+
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
+@pytest.mark.parametrize("nch", [2, 4])
+def test_row_chunked_wstep_equals_oracle(gpu_lib, div, nch):
+    """The W-step partial computed in row chunks (what lets the all-reduce of one chunk overlap the compute of the next) gives the
+    same factors: chunked `packed` layout, chunk-aware W update, lagged cost assembled from all chunks' partials."""
+    import torch
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd.engine import torch_to_colmajor
+    m, n, K = 512, 1024, 64
+    V, W0, H0 = synth(m, n, K)
+    engs = _engines(torch, V, W0, H0, div, [(0, 512), (512, 1024)], 2)
+    costs = _run_emulated(torch, engs, 8, nch=nch)
+    torch.cuda.synchronize()
+    W, H, c0 = O.nmf(V, K, dict(divergence=div, W_init=W0, H_init=H0, maxiter=8, tolerance=1e-300))
+    Wg = torch_to_colmajor(engs[0].W).reshape(m, K)
+    Hg = np.concatenate([torch_to_colmajor(e.H) for e in engs], axis=1)
+    assert np.array_equal(Wg, torch_to_colmajor(engs[1].W).reshape(m, K))
+    assert rel_fro(Wg, W) < 1e-5 and rel_fro(Hg, H) < 1e-5 and rel_fro(costs, c0) < 1e-6
+    with pytest.raises(Exception, match="multiples of 128"):
+        engs[0].wstep_partial_chunk(0, 3)
 
 
 def test_baseline_sized_shards_match_unsharded(gpu_lib):
