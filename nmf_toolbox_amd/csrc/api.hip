@@ -889,7 +889,10 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_HNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + 2.0 * e->K * n); break;
     case TAG_HDEN: b = 4.0 * (m * n + m * KT + 2.0 * e->K * n); break;
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
-    case TAG_FUSED_W: *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK;
+    case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
+        const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
+        *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
+    }
     case TAG_FUSED_H: *flops = (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
     case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
