@@ -196,7 +196,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
         e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
         e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
-        e->n_cost_partials = (int)((e->m / 128) * 64);   // any (row chunk, split) decomposition of the W-step pass
+        e->n_cost_partials = (int)(e->m / 128) + 8 * 512;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 512 each, or = blocks)
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
         e->sumV = f.take<double>(1);
