@@ -144,6 +144,7 @@ struct Layout {
 };
 
 bool div_has_matrix_den(int div) { return div != NMFX_DIV_KL; }
+int fused_split(long blocks, long extent, int K);
 
 // carve (or just size, when ws == nullptr) the workspace
 Layout layout(nmfx_engine *e, void *ws) {
@@ -196,7 +197,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
         e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
         e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
-        e->n_cost_partials = (int)(e->m / 128) + 8 * 512;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 512 each, or = blocks)
+        e->n_cost_partials = (int)(e->m / 128) + 8 * 1024;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 1024 each, or = blocks)
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
         e->sumV = f.take<double>(1);
@@ -282,13 +283,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->gram = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
-        auto pick = [](long blocks, long extent) {   // grid.y so that blocks*split >= 256 while extent/split stays a multiple of 64
-            int s = 1;
-            while (blocks * s < 256 && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
-            return s;
-        };
-        e->nsplit_w = pick(e->m / 128, e->n);
-        e->isplit_h = pick(e->n / 128, e->m);
+        e->nsplit_w = fused_split(e->m / 128, e->n, e->K);
+        e->isplit_h = fused_split(e->n / 128, e->m, e->K);
     }
     return NMFX_OK;
 }
@@ -405,16 +401,17 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
 }
 
 // grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
-int fused_split(long blocks, long extent) {
+int fused_split(long blocks, long extent, int K) {
+    const long target = K <= 128 ? 512 : 256;   // K <= 128 kernels fit two workgroups per CU
     int s = 1;
-    while (blocks * s < 256 && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
+    while (blocks * s < target && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
     return s;
 }
 
 // fused W-step pass (K2) or cost-only pass over rows [row0, row0 + rows) of the local shard.  N of those rows goes to `out`
 // as a contiguous rows x K block; cost partials are appended at e->chunk_parts.
 nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out) {
-    const int split = fused_split(rows / 128, e->n);
+    const int split = fused_split(rows / 128, e->n, e->K);
     if ((size_t)split * rows * e->K > (size_t)std::max(e->nsplit_w, 2) * e->m * e->K || e->chunk_parts + (rows / 128) * split > e->n_cost_partials) {
         set_error("fused W-step: row chunk too small for the workspace");
         return NMFX_ERR_INVALID;
@@ -1203,9 +1200,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     DevBuf WTb, slabs, Gb, Denb, KKb, fparts;
     int nsplit_w = 1, isplit_h = 1;
     if (fast) {
-        auto pick = [](long blocks, long extent) { int s_ = 1; while (blocks * s_ < 256 && extent % (64L * s_ * 2) == 0 && extent / (s_ * 2) >= 64) s_ *= 2; return s_; };
-        nsplit_w = pick(m / 128, n);
-        isplit_h = pick(n / 128, m);
+        nsplit_w = fused_split(m / 128, n, K);
+        isplit_h = fused_split(n / 128, m, K);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
         TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * (m / 128) * nsplit_w));
     }
@@ -1226,7 +1222,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
     auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
-        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_TERMS") != nullptr;   // dev switch: A/B
+        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
         if (sc_fused_terms) {
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;
@@ -1246,7 +1242,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx'); N_ has room for K*K more floats: [N | Hx*Hx'] is what column shards sum
     auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
         float *KK = N_ + mK;
-        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_TERMS") != nullptr;   // dev switch: A/B
+        // V*H' (N = K wide): the register-stationary kernel (R = V, two workgroups per CU at K <= 128) beats the split-K GEMM here
+        static const bool sc_fused_terms = getenv("NMFX_SC_GEMM_WTERMS") == nullptr;   // dev switch: A/B
         if (sc_fused_terms) {
         FusedParams f;
         memset(&f, 0, sizeof(f));

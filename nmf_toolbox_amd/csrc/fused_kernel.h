@@ -26,7 +26,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 // FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0>
-__global__ __launch_bounds__(256, 1) void fused_kernel(const FusedParams p) {
+__global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDY = K + 4;
     constexpr int NKB = K / 32;
