@@ -40,6 +40,8 @@ WORKLOADS = {
     "c4": ("cnmf", "euclidean", 4096, 16384, 64, 8, 12.0),
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
     "c3_shard8": ("nmf", "kl", 16384, 8192, 256, 1, 8.0),     # what ONE of 8 ranks holds at c3 (dev aid for the small-kernel overheads)
+    "c3_shard4": ("nmf", "kl", 16384, 16384, 256, 1, 8.0),
+    "c3_shard2": ("nmf", "kl", 16384, 32768, 256, 1, 8.0),
 }
 
 
