@@ -72,6 +72,9 @@ def cpu_baseline(alg, div, m, n, K, T, budget_s=40.0):
     while ns * 2 <= n and pilot * (ns * 2 / pilot_n) * 4 <= budget_s:   # 1 + (1+2) iterations must fit the budget
         ns *= 2
     per_iter = per_iter_seconds(ns, 2) if ns > pilot_n else pilot
+    k = min(10, int(12.0 / max(per_iter, 1e-3)))                        # spend ~10-20 s of CPU work on the final measurement
+    if k > 2:
+        per_iter = per_iter_seconds(ns, k)
     return dict(value=(1.0 / per_iter) * ns / n, unit="iterations/s", cores=int(threads), kind="port",
                 sample="float64 NumPy/OpenBLAS literal restatement of %s.m (%s), V=%dx%d (first %d of %d columns), K=%d%s: %.4f s/iter on the sample, "
                        "scaled by %d/%d (cost is linear in n)" % (alg, div, m, ns, ns, n, K, (", T=%d" % T) if T > 1 else "", per_iter, ns, n))
