@@ -136,3 +136,25 @@ def cnmfsc(V, W_init, H_init, sW=0.0, sH=0.0, fixW=False, fixH=False, maxiter=10
     if rc == 1:
         raise ValueError("Negative values in data!")
     return W, H, cost[: ncost.value], dict(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0])
+
+
+def constrainednmf_sorted(V_sorted, W_init, Z_init, seg, div="euclidean", lamW=0.0, lamZ=0.0, fixW=False, fixZ=False, maxiter=100, tol=1e-3):
+    """constrainednmf.m:183-258 on label-sorted samples; `seg` = column ranges of the rows of A (see nmf_oracle.c).  Returns W, H (sorted), Z, cost."""
+    V, W, Z = _f(V_sorted), _f(W_init), _f(Z_init)
+    m, n = V.shape
+    K, nz = Z.shape
+    H = np.zeros((K, n), order="F")
+    seg = np.ascontiguousarray(seg, dtype=np.int64)
+    cost = np.zeros(maxiter)
+    it = C.c_int(0)
+    lib().oracle_constrainednmf(m, n, K, _p(V), _p(W), _p(Z), _p(H), seg.ctypes.data_as(C.c_void_p), int(nz), DIV[div], C.c_double(lamW), C.c_double(lamZ),
+                                int(fixW), int(fixZ), int(maxiter), C.c_double(tol), _p(cost), C.byref(it))
+    return W, H, Z, cost[: it.value]
+
+
+def sort_dictionary_order(W):
+    W = _f(W)
+    m, K = W.shape
+    order = np.zeros(K, dtype=np.int32)
+    lib().oracle_sort_dictionary_order(m, K, _p(W), order.ctypes.data_as(C.c_void_p))
+    return order

@@ -555,3 +555,93 @@ int oracle_cnmfsc(int m, int n, int K, int T, const double *Vin, double *W, doub
     free(V); free(Vh); free(W0); free(neg); free(pos); free(Xn); free(stepW);
     return 0;
 }
+
+/* constrainednmf.m:183-258 on label-SORTED samples (the caller has done lines 147-170: processed labels, stable sort, permuted
+ * V); seg[0..nz] are the column ranges of the non-zeros of A's rows (A = [I 0; 0 C], constrainednmf.m:166-170), so
+ * X*A' is a segmented column sum and Z*A a segment broadcast.  div: 0 euclidean, 1 kl, 2 is.  W (m x K), Z (K x nz) in/out,
+ * H (K x n) out = Z*A in sorted order. */
+int oracle_constrainednmf(int m, int n, int K, const double *V, double *W, double *Z, double *H, const long *seg, int nz, int div,
+                          double lamW, double lamZ, int fixW, int fixZ, int maxiter, double tol, double *cost, int *iters_run) {
+    size_t mn = (size_t)m * n;
+    double *Vh = dalloc(mn), *A = dalloc(mn), *B = dalloc(mn);
+    double *N = dalloc((size_t)m * K), *P = dalloc((size_t)m * K);
+    double *Gn = dalloc((size_t)K * n), *Gp = dalloc((size_t)K * n);
+    for (int k = 0; k < K; ++k) { /* constrainednmf.m:144-145 */
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += W[i + (size_t)m * k] * W[i + (size_t)m * k];
+        s = 1.0 / sqrt(s);
+        for (int i = 0; i < m; ++i) W[i + (size_t)m * k] *= s;
+    }
+    for (int c = 0; c < nz; ++c) /* H = Z*A, constrainednmf.m:177 */
+        for (long j = seg[c]; j < seg[c + 1]; ++j)
+            for (int k = 0; k < K; ++k) H[k + (size_t)K * j] = Z[k + (size_t)K * c];
+    oracle_reconstruct(m, n, K, 1, W, H, Vh); /* 179 */
+    *iters_run = maxiter;
+    for (int it = 0; it < maxiter; ++it) {
+        if (!fixW) { /* 185-209: nmf's W step */
+            div_maps(div, mn, V, Vh, A, B, 0);
+            x_times_ht(m, n, K, 0, A, H, N);
+            x_times_ht(m, n, K, 0, B, H, P);
+            for (int k = 0; k < K; ++k) {
+                double *w = W + (size_t)m * k, *nn = N + (size_t)m * k, *pp = P + (size_t)m * k;
+                double dn = 0.0, dp = 0.0, ss = 0.0;
+                for (int i = 0; i < m; ++i) { dn += w[i] * pp[i]; dp += w[i] * nn[i]; }
+                for (int i = 0; i < m; ++i) {
+                    double neg = nn[i] + w[i] * dn, pos = pp[i] + w[i] * dp;
+                    w[i] = w[i] * (neg / fmax_nan(pos + lamW, EPS)); /* 207 */
+                    ss += w[i] * w[i];
+                }
+                ss = 1.0 / sqrt(ss); /* 208 */
+                for (int i = 0; i < m; ++i) w[i] *= ss;
+            }
+        }
+        oracle_reconstruct(m, n, K, 1, W, H, Vh); /* 210 */
+        if (!fixZ) { /* 213-236 */
+            div_maps(div, mn, V, Vh, A, B, 0);
+            memset(Gn, 0, sizeof(double) * (size_t)K * n);
+            memset(Gp, 0, sizeof(double) * (size_t)K * n);
+            wt_times_x_acc(m, n, K, 0, W, A, Gn);
+            wt_times_x_acc(m, n, K, 0, W, B, Gp);
+            for (int c = 0; c < nz; ++c)
+                for (int k = 0; k < K; ++k) {
+                    double neg = 0.0, pos = 0.0;
+                    for (long j = seg[c]; j < seg[c + 1]; ++j) { neg += Gn[k + (size_t)K * j]; pos += Gp[k + (size_t)K * j]; } /* ... * A' */
+                    Z[k + (size_t)K * c] *= neg / fmax_nan(pos + lamZ, EPS); /* 235 */
+                }
+        }
+        for (int c = 0; c < nz; ++c) /* 237 */
+            for (long j = seg[c]; j < seg[c + 1]; ++j)
+                for (int k = 0; k < K; ++k) H[k + (size_t)K * j] = Z[k + (size_t)K * c];
+        oracle_reconstruct(m, n, K, 1, W, H, Vh); /* 238 */
+        double l1w = 0.0, l1z = 0.0;
+        for (size_t e = 0; e < (size_t)m * K; ++e) l1w += fabs(W[e]);
+        for (size_t e = 0; e < (size_t)K * nz; ++e) l1z += fabs(Z[e]);
+        cost[it] = div_cost(div, mn, V, Vh) + lamW * l1w + lamZ * l1z; /* 241-251 */
+        if (it > 0 && cost[it] < cost[it - 1] && cost[it - 1] - cost[it] < tol) { /* 254-257 */
+            *iters_run = it + 1;
+            break;
+        }
+    }
+    free(Vh); free(A); free(B); free(N); free(P); free(Gn); free(Gp);
+    return 0;
+}
+
+/* SortDictionary.m:33-43: 0-based stable order of the columns of W (m x K) by centre of gravity */
+void oracle_sort_dictionary_order(int m, int K, const double *W, int *order) {
+    int *cog = (int *)calloc((size_t)K, sizeof(int));
+    for (int j = 0; j < K; ++j) {
+        const double *w = W + (size_t)m * j;
+        double total = 0.0, cs = 0.0;
+        for (int i = 0; i < m; ++i) total += w[i]; /* W_sum(end, j): the sequential cumulative sum */
+        int idx = 0;
+        for (int i = 0; i < m; ++i) { cs += w[i]; if (cs <= total / 2) idx = i + 1; } /* find(..., 1, 'last') */
+        cog[j] = idx ? idx : 1;
+    }
+    for (int j = 0; j < K; ++j) order[j] = j;
+    for (int a = 1; a < K; ++a) { /* insertion sort: stable, like MATLAB's sort */
+        int v = order[a], b = a - 1;
+        while (b >= 0 && cog[order[b]] > cog[v]) { order[b + 1] = order[b]; --b; }
+        order[b + 1] = v;
+    }
+    free(cog);
+}

@@ -188,6 +188,12 @@ def test_constrainednmf_golden(div):
         cols = np.nonzero(lab == c)[0]
         assert np.all(H[:, cols] == H[:, cols[:1]])
     assert np.all(np.diff(cost) <= 1e-9 * cost[0])
+    # the independent C restatement works on the label-sorted problem: same W / Z / cost, H up to the sample permutation
+    sidx = np.argsort(np.where(lab < 0, -1, np.searchsorted(np.unique(lab[lab >= 0]), lab) + 1), kind="stable")
+    zcol = g["A_nnz_cols"][sidx]
+    seg = np.concatenate([[0], np.cumsum(np.bincount(zcol, minlength=g["Z0"].shape[1]))])
+    Wc, Hc, Zc, cc = CO.constrainednmf_sorted(V[:, sidx], W0, g["Z0"], seg, div=div, lamZ=0.05, maxiter=20, tol=1e-12)
+    assert rel_fro(Wc, W) < 1e-11 and rel_fro(Zc, Z) < 1e-11 and rel_fro(cc, cost) < 1e-11 and rel_fro(Hc, H[:, sidx]) < 1e-11
 
 
 def test_constrainednmf_reduces_to_nmf_when_nothing_is_labelled():
@@ -214,6 +220,8 @@ def test_sort_dictionary_golden():
     Ws, Hs = O.sort_dictionary(W, np.array([[1.0], [2.0], [3.0]]))
     assert np.array_equal(Ws, W[:, [2, 0, 1]]) and np.array_equal(Hs.ravel(), [3.0, 1.0, 2.0])
     assert O.sort_dictionary(W)[1] is None
+    assert np.array_equal(CO.sort_dictionary_order(W), [2, 0, 1])
+    assert np.array_equal(g["W"][:, CO.sort_dictionary_order(g["W"])], g["W_sorted"])
 
 
 def test_matlab_semantics():
