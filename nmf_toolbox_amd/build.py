@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libnmfx.so")
-SOURCES = ["gemm_pipe.hip", "gemm.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
+SOURCES = ["gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_k128_192.hip", "fused_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
 ARCH = "gfx950"
 
 
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(srcs), 6)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(srcs), 8)) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _newer(objs, OUT):
         tl = _torch_lib_dir()

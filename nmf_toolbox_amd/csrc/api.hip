@@ -272,11 +272,11 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         set_error("nmfx_engine: lnmf is defined for the KL divergence only (lnmf.m:69,76,81)");
         return NMFX_ERR_INVALID;
     }
-    // fused path eligibility: nmf rules, KL or euclidean, K in {64,128,256}, tileable shard
+    // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
                           e->m % 128 == 0 && e->n % 128 == 0 && e->hL == 0 && e->hR == 0;
     if (d->path == 2 && !eligible) {
-        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K in {64,128,256}, m %% 128 == 0, n %% 128 == 0)");
+        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K a multiple of 32 up to 256, m %% 128 == 0, n %% 128 == 0)");
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
@@ -722,7 +722,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         const int func = e->div == NMFX_DIV_KL ? 2 : 0;
         const bool kl = e->div == NMFX_DIV_KL;
         static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
-        if (func == 0 && !euc_fused_h) {
+        if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
             // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
             {
@@ -1122,7 +1122,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     const bool fast = p->path != 1 && fused_supported(K) && m % 128 == 0 && n % 128 == 0;
     if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
     if (comm.active() && !fast) {
-        set_error("nmfsc on column shards runs on the fused kernels only: K in {64,128,256}, m %% 128 == 0, n_local %% 128 == 0");
+        set_error("nmfsc on column shards runs on the fused kernels only: K a multiple of 32 up to 256, m %% 128 == 0, n_local %% 128 == 0");
         return NMFX_ERR_UNSUPPORTED;
     }
     if (!dev) TRY(V.alloc(mn * 4));
@@ -1222,7 +1222,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
     auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
-        static const bool sc_fused_terms = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
+        static const bool sc_fused_env = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
+        const bool sc_fused_terms = sc_fused_env || K % 64 != 0;   // the GEMM is only pipelined for tile-aligned outputs
         if (sc_fused_terms) {
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;

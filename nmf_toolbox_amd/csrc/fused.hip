@@ -21,59 +21,28 @@
 // wave-instruction, no VGPRs) into a double buffer with row stride K+4 floats: ds_read_b128 down a
 // column (first contraction) and ds_read_b32 along a row (second contraction) are both conflict-free.
 // v_mfma_f32_32x32x2_f32 issues every 64 cycles per SIMD; each MFMA needs at most one ds_read.
-#include "fused_kernel.h"
+#include "nmfx_internal.h"
 
 namespace nmfx {
 
-template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI>
-static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) {
-    const size_t ldsb = sizeof(float) * 2 * FT_C * (K + 4);
-    auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr_done = true;
-    }
-    dim3 grid((unsigned)(p.R / FT_ROWS), (unsigned)nsplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
-    NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
-}
+bool fused_supported(int K) { return K >= 32 && K <= 256 && K % 32 == 0; }
 
-template <int K, bool D_RC, bool DO_G2, int EPI>
-static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, int func) {
-    switch (func) {
-    case 0: if (DO_G2) return launch_one<K, D_RC, 0, DO_G2, EPI>(st, p, nsplit); break;
-    case 1: return launch_one<K, D_RC, 1, DO_G2, EPI>(st, p, nsplit);
-    case 2: if (DO_G2) return launch_one<K, D_RC, 2, DO_G2, EPI>(st, p, nsplit); break;
-    case 3: return launch_one<K, D_RC, 3, DO_G2, EPI>(st, p, nsplit);
-    }
-    set_error("launch_fused: unsupported functor %d", func);
-    return NMFX_ERR_UNSUPPORTED;
-}
-
-template <int K>
-static nmfx_status launch_k(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
-    if (!do_g2) return d_rc ? launch_f<K, true, false, 0>(st, p, nsplit, func) : NMFX_ERR_UNSUPPORTED;   // cost-only pass
-    if (d_rc) return launch_f<K, true, true, 0>(st, p, nsplit, func);                                    // W step: slabs out
-    if (epi == 1) return launch_f<K, false, true, 1>(st, p, nsplit, func);                               // H step, fused update
-    return launch_f<K, false, true, 0>(st, p, nsplit, func);                                             // H step, slabs out
-}
-
-bool fused_supported(int K) { return K == 64 || K == 128 || K == 256; }
+// one translation unit per K group (fused_k*.hip): the 8 x 14 instantiations compile in parallel
+nmfx_status launch_fused_k32_96(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
+nmfx_status launch_fused_k128_192(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
+nmfx_status launch_fused_k224_256(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
 // nsplit: number of contraction ranges (grid.y); c_per_split must be a multiple of FT_C and R of FT_ROWS
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
+    constexpr int FT_ROWS = 128, FT_C = 64;   // fused_kernel.h: stationary rows per workgroup, streamed rows per tile
     if (p.R % FT_ROWS || p.Cn % FT_C || p.c_per_split % FT_C || nsplit < 1) {
         set_error("launch_fused: shape not tileable (R=%ld Cn=%ld c_per_split=%ld)", p.R, p.Cn, p.c_per_split);
         return NMFX_ERR_INVALID;
     }
-    switch (p.K) {
-    case 64: return launch_k<64>(st, p, nsplit, d_rc, func, do_g2, epi);
-    case 128: return launch_k<128>(st, p, nsplit, d_rc, func, do_g2, epi);
-    case 256: return launch_k<256>(st, p, nsplit, d_rc, func, do_g2, epi);
-    default: set_error("launch_fused: K=%d not supported", p.K); return NMFX_ERR_UNSUPPORTED;
-    }
+    if (!fused_supported(p.K)) { set_error("launch_fused: K=%d not supported (multiples of 32 up to 256)", p.K); return NMFX_ERR_UNSUPPORTED; }
+    if (p.K <= 96) return launch_fused_k32_96(st, p, nsplit, d_rc, func, do_g2, epi);
+    if (p.K <= 192) return launch_fused_k128_192(st, p, nsplit, d_rc, func, do_g2, epi);
+    return launch_fused_k224_256(st, p, nsplit, d_rc, func, do_g2, epi);
 }
 
 }  // namespace nmfx

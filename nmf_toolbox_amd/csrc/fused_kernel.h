@@ -170,16 +170,12 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             }
             if ((FUNC == 1 && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
-        // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements of half jb
+        // fillers behind the i-th MFMA of a phase with M = K/2 MFMAs that hosts the 16 elements x 4 micro-ops of half jb: slot i runs
+        // micro-ops [64*i/M, 64*(i+1)/M) in element order (one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
         auto emap_fill = [&](int jb, int i, int M) {
-            const int P = M / 16;                             // MFMAs per element (8 at K=256, 4 at 128, 2 at 64)
-            const int reg = i / P, rem = i % P;
-            if (P >= 4) {
-                if (rem % (P / 4) == 0) emap_u(jb, reg, rem / (P / 4));
-            } else {                                          // P == 2: two micro-ops behind each MFMA
-                emap_u(jb, reg, 2 * rem);
-                emap_u(jb, reg, 2 * rem + 1);
-            }
+            const int q0 = 64 * i / M, q1 = 64 * (i + 1) / M;
+#pragma unroll
+            for (int q = q0; q < q1; ++q) emap_u(jb, q >> 2, q & 3);
         };
         auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + 8 * g + 4 * h); };
         if (NEED_S) {

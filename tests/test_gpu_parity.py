@@ -128,7 +128,8 @@ def test_reconstruct(gpu_lib):
 
 # ---- fused kernels (S = W*H never stored): eligible shapes, both split and un-split epilogues -----------------------
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
-@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10)])
+@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10),
+                                         (256, 512, 32, 12), (256, 640, 96, 12), (128, 512, 160, 10), (256, 384, 192, 10), (128, 256, 224, 10)])
 def test_nmf_fused_matches_oracle_and_generic(gpu_lib, div, m, n, K, iters):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K)
@@ -176,19 +177,20 @@ def test_cnmf_ab_divergence(gpu_lib, alpha, beta):
 
 
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
-def test_nmfsc_fused_path_matches_oracle(gpu_lib, sW, sH):
+@pytest.mark.parametrize("K", [64, 96])
+def test_nmfsc_fused_path_matches_oracle(gpu_lib, sW, sH, K):
     """nmfsc on the fused kernels (objective = fused cost pass, gradients in Gram form) vs the oracle: identical line-search branches."""
     from oracle import nmf_oracle as O
-    V, W0, H0 = synth(256, 1024, 64)
+    V, W0, H0 = synth(256, 1024, K)
     cfg = dict(W_init=W0, H_init=H0, maxiter=20, tolerance=1e-12)
     if sW:
         cfg["W_sparsity"] = sW
     if sH:
         cfg["H_sparsity"] = sH
     i0, i1, i2 = {}, {}, {}
-    ref = O.nmfsc(V, 64, cfg, info=i0)
-    got = gpu_lib.nmfsc(V, 64, dict(cfg, nmfx_path=2), info=i1)
-    gen = gpu_lib.nmfsc(V, 64, dict(cfg, nmfx_path=1), info=i2)
+    ref = O.nmfsc(V, K, cfg, info=i0)
+    got = gpu_lib.nmfsc(V, K, dict(cfg, nmfx_path=2), info=i1)
+    gen = gpu_lib.nmfsc(V, K, dict(cfg, nmfx_path=1), info=i2)
     assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
     assert i2["triesH"] == i0["triesH"] and i2["triesW"] == i0["triesW"]
     _check(got, ref)
