@@ -281,15 +281,19 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
 }
 
-// pipelined kernel: tile-aligned, no powf maps, and stacked k-views whose t blocks are whole k-tiles
+// pipelined kernel: no powf maps, 16-byte aligned views whose contiguous dimension is a multiple of 4 (edge tiles in M, N and the
+// last k-tile are guarded chunk-wise), and stacked k-views whose t blocks are whole k-tiles
 static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &heavy) {
     gemm_tile_shape(p.M, p.N, bm, bn);
     const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
-    fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && view_fast_ok(p.A) && view_fast_ok(p.B);
+    const bool views = view_fast_ok(p.A) && view_fast_ok(p.B);
+    fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && views;
     heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
     auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };
+    const bool a_dim = is_kc(p.A.mode) ? p.Kc % 4 == 0 : p.M % 4 == 0;
+    const bool b_dim = is_kc(p.B.mode) ? p.Kc % 4 == 0 : p.N % 4 == 0;
     static const bool pipe_off = getenv("NMFX_GEMM_NOPIPE") != nullptr;   // dev switch: A/B the two kernels
-    return fast && !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && kspan >= BK;
+    return views && a_dim && b_dim && !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && (p.splitk <= 1 || kspan % BK == 0);
 }
 bool gemm_pipe_eligible(const GemmParams &p) {
     int bm, bn; bool fast, heavy;

@@ -26,17 +26,25 @@ struct PLoader {
     long offr[KC ? NCH : 1];
     int gr[KC ? NCH : 1];
     int c, q;
+    int rowok;                   // bit p: the rows of chunk p exist (r < R); edge tiles of M / N that are not tile multiples
+    long kend;                   // contraction indices >= kend read as zero (last k-tile of a Kc that is not a multiple of BK)
     int kt, kin;                 // KC stacked views: t block and offset inside it of the NEXT tile to load (tile-uniform: blk % BK == 0)
     long kc_next;                // first contraction index of the next tile to load
 
-    __device__ __forceinline__ void init(const OpView &v, int tid, int r_tile0, long kbeg) {
+    __device__ __forceinline__ void init(const OpView &v, int tid, int r_tile0, long kbeg, long R, long kend_) {
         c = tid % CPR;
         q = tid / CPR;
+        kend = kend_;
+        rowok = 0;
         if (KC) {
 #pragma unroll
-            for (int p = 0; p < NCH; ++p) dec_r(v, r_tile0 + q + p * LSTEP, offr[p], gr[p]);
+            for (int p = 0; p < NCH; ++p) {
+                dec_r(v, r_tile0 + q + p * LSTEP, offr[p], gr[p]);
+                rowok |= (r_tile0 + q + p * LSTEP < R) ? (1 << p) : 0;
+            }
         } else {
             dec_r(v, r_tile0 + 4 * c, offr[0], gr[0]);
+            rowok = (r_tile0 + 4 * c < R) ? 1 : 0;           // R % 4 == 0: a chunk of 4 rows is inside or outside as a whole
         }
         kc_next = kbeg;
         kt = 0; kin = (int)kbeg;
@@ -60,10 +68,12 @@ struct PLoader {
             kc_uniform(v, ok, gk);
             off = offr[P] + ok + 4 * c;
             g = gr[P] + gk;
+            if (!((rowok >> P) & 1) || kc_next + 4 * c >= kend) g = -1;   // Kc % 4 == 0: a chunk of 4 k is inside or outside as a whole
         } else {
             const long kc = kc_next + q + P * LSTEP;
             off = offr[0] + v.ld * kc;
             g = gr[0] + (v.mode == VIEW_HSTACK_RC ? (int)kc + v.goff : 0);
+            if (!rowok || kc >= kend) g = -1;
         }
         const bool ok = g >= 0;
         if (P == 0) okm[SET] = 0;
@@ -129,11 +139,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
         kend = kbeg + p.kc_per_split < p.Kc ? kbeg + p.kc_per_split : p.Kc;
         C += (long)blockIdx.z * p.slab_stride;
     }
-    const int ntiles = (int)((kend - kbeg) / BK);
+    const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
 
     LA la; LB lb;
-    la.init(vA, tid, i_tile0, kbeg);
-    lb.init(vB, tid, j_tile0, kbeg);
+    la.init(vA, tid, i_tile0, kbeg, p.M, kend);
+    lb.init(vB, tid, j_tile0, kbeg, p.N, kend);
 
     f32x16 acc[NR][MR];
 #pragma unroll
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long j = j_tile0 + wj0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (i >= p.M || j >= p.N) continue;       // edge tiles
                 float sv = acc[a][b][e];
                 if (p.epi == EPI_COST) {
                     if (p.cost_ncols == 0 || j < p.cost_ncols) part += div_term<false>(p.cost_div, p.Vref[i + p.ldv * j], sv, p.cost_alpha, p.cost_beta);
@@ -259,7 +270,7 @@ static nmfx_status launch_pipe_cfg(hipStream_t st, const GemmParams &p) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 grid((unsigned)(p.M / BM), (unsigned)(p.N / BN), (unsigned)(p.zbatch > 0 ? p.zbatch : (p.splitk > 1 ? p.splitk : 1)));
+    dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN), (unsigned)(p.zbatch > 0 ? p.zbatch : (p.splitk > 1 ? p.splitk : 1)));
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, p);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
