@@ -281,36 +281,39 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
 }
 
-// pipelined kernel: no powf maps, 16-byte aligned views whose contiguous dimension is a multiple of 4 (edge tiles in M, N and the
-// last k-tile are guarded chunk-wise), and stacked k-views whose t blocks are whole k-tiles
-static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &heavy) {
+// pipelined kernel: no powf maps and stacked k-views whose t blocks are whole k-tiles.  vec = float4 loads: 16-byte aligned views
+// whose contiguous dimension is a multiple of 4 (edge tiles in M, N and the last k-tile are guarded chunk-wise); otherwise the
+// dword-load variant (odd leading dimensions), which only needs stacked r-views to keep 4-element chunks inside one t block.
+static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &heavy, bool &vec) {
     gemm_tile_shape(p.M, p.N, bm, bn);
     const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
     const bool views = view_fast_ok(p.A) && view_fast_ok(p.B);
     fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && views;
     heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
     auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };
+    auto rview_ok = [](const OpView &v) { return v.mode != VIEW_HSTACK_RC || v.blk % 4 == 0; };
     const bool a_dim = is_kc(p.A.mode) ? p.Kc % 4 == 0 : p.M % 4 == 0;
     const bool b_dim = is_kc(p.B.mode) ? p.Kc % 4 == 0 : p.N % 4 == 0;
+    vec = views && a_dim && b_dim;
     static const bool pipe_off = getenv("NMFX_GEMM_NOPIPE") != nullptr;   // dev switch: A/B the two kernels
-    return views && a_dim && b_dim && !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && (p.splitk <= 1 || kspan % BK == 0);
+    return !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && rview_ok(p.A) && rview_ok(p.B) && (p.splitk <= 1 || kspan % BK == 0);
 }
 bool gemm_pipe_eligible(const GemmParams &p) {
-    int bm, bn; bool fast, heavy;
-    return p.M > 0 && p.N > 0 && pipe_ok(p, bm, bn, fast, heavy);
+    int bm, bn; bool fast, heavy, vec;
+    return p.M > 0 && p.N > 0 && pipe_ok(p, bm, bn, fast, heavy, vec);
 }
 
 nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
     if (blocks_out) *blocks_out = 0;
     if (p.M <= 0 || p.N <= 0) return NMFX_OK;
     int bm, bn;
-    bool fast, heavy;
-    const bool pipe = pipe_ok(p, bm, bn, fast, heavy);
+    bool fast, heavy, vec;
+    const bool pipe = pipe_ok(p, bm, bn, fast, heavy, vec);
     if (p.zbatch > 0 && !pipe) { set_error("launch_gemm: z-batched launch needs the pipelined kernel"); return NMFX_ERR_INVALID; }
     if (!fast || heavy) bm = bn = 128;
     if (heavy) fast = fast && (p.M % 128 == 0) && (p.N % 128 == 0);
     if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    if (pipe) return dispatch_pipe(st, p, bm, bn);
+    if (pipe) return dispatch_pipe(st, p, bm, bn, vec);
     if (heavy) return fast ? dispatch_views<128, 128, true, true>(st, p) : dispatch_views<128, 128, false, true>(st, p);
     if (bm == 64) return fast ? dispatch_views<64, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
     if (bn == 64) return fast ? dispatch_views<128, 64, true>(st, p) : dispatch_views<128, 128, false>(st, p);

@@ -14,7 +14,9 @@ namespace nmfx {
 // (sched_barrier after each).  Tile indices past the end are clamped instead of branched on: the redundant loads hit L2
 // and the redundant LDS stores land in the buffer nobody reads again.
 // =====================================================================================================================
-template <int BR, bool KC, bool PRO>
+// VEC: float4 loads (16-byte aligned views whose contiguous dimension is a multiple of 4).  !VEC: four dword loads per chunk at
+// immediate offsets and per-element masks, for odd leading dimensions (m = 513, 1025, ... spectrogram bins) and odd M / N / Kc.
+template <int BR, bool KC, bool PRO, bool VEC>
 struct PLoader {
     static constexpr int NCH = BR * BK / 4 / NTHREADS;     // float4 chunks per thread per k-tile: 4 (BR = 128) or 2 (BR = 64)
     static constexpr int LDS_STRIDE = BR + (KC ? 1 : 0);
@@ -27,6 +29,8 @@ struct PLoader {
     int gr[KC ? NCH : 1];
     int c, q;
     int rowok;                   // bit p: the rows of chunk p exist (r < R); edge tiles of M / N that are not tile multiples
+    int nval[2][VEC ? 1 : NCH];  // !VEC: leading elements of chunk p that are inside the matrix (0..4)
+    int rval;                    // !VEC, RC: valid rows of this thread's 4-row chunk
     long kend;                   // contraction indices >= kend read as zero (last k-tile of a Kc that is not a multiple of BK)
     int kt, kin;                 // KC stacked views: t block and offset inside it of the NEXT tile to load (tile-uniform: blk % BK == 0)
     long kc_next;                // first contraction index of the next tile to load
@@ -44,7 +48,9 @@ struct PLoader {
             }
         } else {
             dec_r(v, r_tile0 + 4 * c, offr[0], gr[0]);
-            rowok = (r_tile0 + 4 * c < R) ? 1 : 0;           // R % 4 == 0: a chunk of 4 rows is inside or outside as a whole
+            rowok = (r_tile0 + 4 * c < R) ? 1 : 0;           // VEC: R % 4 == 0, a chunk of 4 rows is inside or outside as a whole
+            const long left = R - (r_tile0 + 4 * c);
+            rval = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
         }
         kc_next = kbeg;
         kt = 0; kin = (int)kbeg;
@@ -78,9 +84,26 @@ struct PLoader {
         const bool ok = g >= 0;
         if (P == 0) okm[SET] = 0;
         okm[SET] |= ok ? (1 << P) : 0;
-        const long o = ok ? off : 0;            // out-of-view chunks read the view's first (always valid) element and are zeroed at commit
-        x[SET][P] = *reinterpret_cast<const float4 *>(v.p + o);
-        if (PRO) { if (v.p2) y[PRO ? SET : 0][PRO ? P : 0] = *reinterpret_cast<const float4 *>(v.p2 + o); }
+        if (VEC) {
+            const long o = ok ? off : 0;        // out-of-view chunks read the view's first (always valid) element and are zeroed at commit
+            x[SET][P] = *reinterpret_cast<const float4 *>(v.p + o);
+            if (PRO) { if (v.p2) y[PRO ? SET : 0][PRO ? P : 0] = *reinterpret_cast<const float4 *>(v.p2 + o); }
+        } else {
+            // elements past the edge of a straddling chunk would be out of bounds on the last column: clamp each address
+            int nv;
+            if (KC) { const long left = kend - (kc_next + 4 * c); nv = left >= 4 ? 4 : (left > 0 ? (int)left : 0); }
+            else nv = rval;
+            if (!ok) nv = 0;
+            nval[SET][VEC ? 0 : P] = nv;
+            const float *b1 = v.p + (nv > 0 ? off : 0);
+            x[SET][P] = make_float4(b1[0], b1[nv > 1 ? 1 : 0], b1[nv > 2 ? 2 : 0], b1[nv > 3 ? 3 : 0]);
+            if (PRO) {
+                if (v.p2) {
+                    const float *b2 = v.p2 + (nv > 0 ? off : 0);
+                    y[PRO ? SET : 0][PRO ? P : 0] = make_float4(b2[0], b2[nv > 1 ? 1 : 0], b2[nv > 2 ? 2 : 0], b2[nv > 3 ? 3 : 0]);
+                }
+            }
+        }
     }
     // advance to the following tile unless `last` (clamped re-load of the final tile)
     __device__ __forceinline__ void advance(const OpView &v, bool more) {
@@ -94,6 +117,13 @@ struct PLoader {
         float4 t = x[SET][P];
         if (PRO) { if (v.func != NMFX_PRO_NONE) t = pro4<false>(v.func, t, y[PRO ? SET : 0][PRO ? P : 0], 0.f, 0.f); }
         if (!((okm[SET] >> P) & 1)) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!VEC) {   // mask after the element map: 0/0 of padding must not become NaN in the tile
+            const int nv = nval[SET][VEC ? 0 : P];
+            if (nv < 4) t.w = 0.f;
+            if (nv < 3) t.z = 0.f;
+            if (nv < 2) t.y = 0.f;
+            if (nv < 1) t.x = 0.f;
+        }
         const int line = q + P * LSTEP;
         if (KC) {
             S[(4 * c + 0) * LDS_STRIDE + line] = t.x;
@@ -106,11 +136,11 @@ struct PLoader {
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool PRO>
+template <int BM, int BN, bool A_KC, bool B_KC, bool PRO, bool VEC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using LA = PLoader<BM, A_KC, PRO>;
-    using LB = PLoader<BN, B_KC, PRO>;
+    using LA = PLoader<BM, A_KC, PRO, VEC>;
+    using LB = PLoader<BN, B_KC, PRO, VEC>;
     constexpr int LDA_S = LA::LDS_STRIDE, LDB_S = LB::LDS_STRIDE;
     constexpr int A_SZ_AL = (BK * LDA_S + 3) & ~3, B_SZ_AL = (BK * LDB_S + 3) & ~3;
     constexpr int BUF_SZ = A_SZ_AL + B_SZ_AL;
@@ -258,13 +288,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool PRO>
+template <int BM, int BN, bool A_KC, bool B_KC, bool PRO, bool VEC>
 static nmfx_status launch_pipe_cfg(hipStream_t st, const GemmParams &p) {
-    using LA = PLoader<BM, A_KC, PRO>;
-    using LB = PLoader<BN, B_KC, PRO>;
+    using LA = PLoader<BM, A_KC, PRO, VEC>;
+    using LB = PLoader<BN, B_KC, PRO, VEC>;
     constexpr int A_SZ_AL = (BK * LA::LDS_STRIDE + 3) & ~3, B_SZ_AL = (BK * LB::LDS_STRIDE + 3) & ~3;
     const size_t lds = sizeof(float) * 2 * (A_SZ_AL + B_SZ_AL);
-    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, PRO>;
+    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, PRO, VEC>;
     static bool attr_done = false;
     if (!attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -276,12 +306,12 @@ static nmfx_status launch_pipe_cfg(hipStream_t st, const GemmParams &p) {
     return NMFX_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 static nmfx_status dispatch_pipe_t(hipStream_t st, const GemmParams &p) {
     const bool akc = is_kc(p.A.mode), bkc = is_kc(p.B.mode);
     const bool pro = p.A.func != NMFX_PRO_NONE || p.B.func != NMFX_PRO_NONE;
 #define NMFX_PIPE(AK, BKC_)                                                                     \
-    return pro ? launch_pipe_cfg<BM, BN, AK, BKC_, true>(st, p) : launch_pipe_cfg<BM, BN, AK, BKC_, false>(st, p)
+    return pro ? launch_pipe_cfg<BM, BN, AK, BKC_, true, VEC>(st, p) : launch_pipe_cfg<BM, BN, AK, BKC_, false, VEC>(st, p)
     if (akc && bkc) { NMFX_PIPE(true, true); }
     if (akc) { NMFX_PIPE(true, false); }
     if (bkc) { NMFX_PIPE(false, true); }
@@ -289,10 +319,11 @@ static nmfx_status dispatch_pipe_t(hipStream_t st, const GemmParams &p) {
 #undef NMFX_PIPE
 }
 
-nmfx_status dispatch_pipe(hipStream_t st, const GemmParams &p, int bm, int bn) {
-    if (bm == 64) return dispatch_pipe_t<64, 128>(st, p);
-    if (bn == 64) return dispatch_pipe_t<128, 64>(st, p);
-    return dispatch_pipe_t<128, 128>(st, p);
+nmfx_status dispatch_pipe(hipStream_t st, const GemmParams &p, int bm, int bn, bool vec) {
+    if (!vec) return dispatch_pipe_t<128, 128, false>(st, p);   // unaligned views: dword loads, one tile shape
+    if (bm == 64) return dispatch_pipe_t<64, 128, true>(st, p);
+    if (bn == 64) return dispatch_pipe_t<128, 64, true>(st, p);
+    return dispatch_pipe_t<128, 128, true>(st, p);
 }
 
 }  // namespace nmfx
