@@ -177,6 +177,9 @@ typedef struct {
                                  2 = lnmf rules (lnmf.m:59,69-70,76: L1 columns, plain ratio, sqrt H update);
                                  0 = nmf rules (nmf.m:130-134,169: unit-L2 columns); 1 = cnmf rules
                                  (cnmf.m:157-166,196-199: slab Frobenius norm T, H rescaled at init only) */
+    int32_t K_valid;          /* 0 = all K_total components are real.  Otherwise components k >= K_valid are zero padding (zero
+                                 columns of W / rows of H, marked fixed by the caller) that only rounds K up to a kernel-friendly
+                                 size: they contribute exact zeros everywhere and are skipped by the initial normalisation */
 } nmfx_engine_desc;
 
 /* bytes of device scratch the engine needs (caller allocates: torch tensor / hipMalloc) */

@@ -69,6 +69,7 @@ struct nmfx_engine {
     long nvalid;              // columns of V that exist globally (<= n + hR)
     float *Hext;              // base of the K x (hL + n + hR) buffer; H points at its centre
     int K, T, KT, div, algo;
+    int K_valid;              // components k >= K_valid are zero padding (0 = none)
     double alpha, beta;       // NMFX_DIV_AB only; alpha == 0 selects the dual update equations (nmf.m:124-128)
     int device;
     hipStream_t st;
@@ -248,6 +249,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_INVALID;
     }
     e->K = d->K_total;
+    e->K_valid = (d->K_valid > 0 && d->K_valid < d->K_total) ? d->K_valid : 0;
+    if (e->K_valid && d->algorithm == 1) { set_error("nmfx_engine: K padding is not defined for cnmf"); return NMFX_ERR_INVALID; }
     e->T = d->T;
     e->KT = d->K_total * d->T;
     e->div = d->divergence;
@@ -559,7 +562,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
     {
         Scope s(e, TAG_SMALL);
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out, e->K_valid));
         if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
         if (e->fused) {
             e->cost_valid = false;
@@ -995,11 +998,18 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     }
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     TRY(check_device(p->device));
-    const int K = p->K_total, S = p->num_sources;
+    const int Kt = p->K_total, S = p->num_sources;
+    // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
+    // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
+    const int dv = p->divergence;
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && p->m % 128 == 0 && p->n % 128 == 0 && p->path != 1 &&
+                     (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN);
+    const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
     std::vector<float> lw(K, 0.f), lh(K, 0.f);
     std::vector<uint8_t> fw(K, 0), fh(K, 0);
+    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
     for (int s = 0, k0 = 0; s < S; ++s) {
-        const int Ks = p->K_s ? p->K_s[s] : K;
+        const int Ks = p->K_s ? p->K_s[s] : Kt;
         for (int k = k0; k < k0 + Ks; ++k) {
             if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
             if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
@@ -1012,6 +1022,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     d.m = p->m; d.n_local = p->n; d.K_total = K; d.T = p->T; d.divergence = p->divergence; d.alpha = p->alpha; d.beta = p->beta;
     d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
     d.device = p->device; d.stream = nullptr; d.algorithm = algorithm; d.path = p->path;
+    d.K_valid = pad ? Kt : 0;
     size_t ws_bytes = 0, packed_count = 0;
     TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
     TRY(nmfx_engine_packed_count(&d, &packed_count));
@@ -1021,11 +1032,22 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     TRY(stage.alloc(STAGE_ELEMS * 8));
     hipStream_t st = nullptr;
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0, stage, STAGE_ELEMS));
-    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
-    if (algorithm != 3) TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
-    else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
+    const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
+    DevBuf tmp;   // K x cols staging of the un-padded row-interleaved arrays (H, Z)
+    if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
+    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0, stage, STAGE_ELEMS));   // the first K columns of the m x K_pad array
+    if (pad) NMFX_HIP(hipMemsetAsync(W.as<float>() + mKt, 0, (mKT - mKt) * 4, st));
+    if (algorithm != 3) {
+        if (pad) {
+            TRY(upload(st, p->H_init, p->dtype, tmp.as<float>(), Ktn, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, tmp.as<float>(), Kt, H.as<float>(), K, p->n));
+        } else TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    } else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
         TRY(Z.alloc((size_t)K * nz * 4));
-        TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0, stage, STAGE_ELEMS));
+        if (pad) {
+            TRY(upload(st, Z_init, p->dtype, tmp.as<float>(), (size_t)Kt * nz, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, tmp.as<float>(), Kt, Z.as<float>(), K, nz));
+        } else TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0, stage, STAGE_ELEMS));
     }
     nmfx_engine *e = nullptr;
     TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
@@ -1070,9 +1092,16 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
         r->cost_len = p->maxiter;
     }
-    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKT, stage, STAGE_ELEMS);
-    if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
-    if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz, stage, STAGE_ELEMS);
+    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS);
+    if (s == NMFX_OK && pad) {
+        s = repack_rows(st, H.as<float>(), K, tmp.as<float>(), Kt, p->n);
+        if (s == NMFX_OK) s = download(st, tmp.as<float>(), p->dtype, r->H, Ktn, stage, STAGE_ELEMS);
+        if (s == NMFX_OK && algorithm == 3) s = repack_rows(st, Z.as<float>(), K, tmp.as<float>(), Kt, nz);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, tmp.as<float>(), p->dtype, Z_out, (size_t)Kt * nz, stage, STAGE_ELEMS);
+    } else {
+        if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz, stage, STAGE_ELEMS);
+    }
     nmfx_engine_destroy(e);
     return s;
 }

@@ -238,9 +238,10 @@ nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
 // nmf.m:169   W(:,k) <- W(:,k) * (1/sqrt(sum W(:,k).^2))
 // cnmf.m:196-199  W(:,k,:) <- W(:,k,:) / (norm(squeeze(W(:,k,:)),'fro') / T)
 __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix,
-                                                          int cnmf_rule, double *f_out) {
+                                                          int cnmf_rule, double *f_out, int kvalid) {
     const int c = blockIdx.x, k = c % K, t = c / K;
     if (fix && fix[k]) return;
+    if (kvalid > 0 && k >= kvalid) return;   // zero padding components (nmfx_engine_desc.K_valid): 0 * (1/0) must not turn into NaN
     float *w = W + m * c;
     if (cnmf_rule == 1) {
         double s = 0.0;
@@ -260,8 +261,24 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
     }
 }
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
-                        double *f_out) {
-    hipLaunchKernelGGL(w_normalize_kernel, dim3(K * T), dim3(256), 0, st, W, m, K, T, sumsq, fix, cnmf_rule, f_out);
+                        double *f_out, int kvalid) {
+    hipLaunchKernelGGL(w_normalize_kernel, dim3(K * T), dim3(256), 0, st, W, m, K, T, sumsq, fix, cnmf_rule, f_out, kvalid);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// dst (rd x cols) <- src (rs x cols), both column-major: rows beyond rs are zero (padding K), rows beyond rd are dropped (un-padding)
+__global__ void repack_rows_kernel(const float *src, int rs, float *dst, int rd, long count) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const int k = (int)(idx % rd);
+    const long j = idx / rd;
+    dst[idx] = k < rs ? src[k + (long)rs * j] : 0.0f;
+}
+nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols) {
+    const long count = (long)rd * cols;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, src, rs, dst, rd, count);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -148,7 +148,8 @@ struct WUpdateParams {
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
-                        double *f_out);
+                        double *f_out, int kvalid = 0);
+nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,

@@ -129,7 +129,8 @@ def test_reconstruct(gpu_lib):
 # ---- fused kernels (S = W*H never stored): eligible shapes, both split and un-split epilogues -----------------------
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
 @pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10),
-                                         (256, 512, 32, 12), (256, 640, 96, 12), (128, 512, 160, 10), (256, 384, 192, 10), (128, 256, 224, 10)])
+                                         (256, 512, 32, 12), (256, 640, 96, 12), (128, 512, 160, 10), (256, 384, 192, 10), (128, 256, 224, 10),
+                                         (256, 512, 40, 12), (128, 384, 100, 10), (128, 256, 7, 15), (256, 256, 250, 8)])   # K padded to 64 / 128 / 32 / 256
 def test_nmf_fused_matches_oracle_and_generic(gpu_lib, div, m, n, K, iters):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K)
@@ -374,3 +375,23 @@ def test_degenerate_inputs(gpu_lib):
     assert len(c) == 1
     W, H, c = gpu_lib.nmf(V, 4, dict(W_init=W0, H_init=H0, maxiter=50, tolerance=1e9))
     assert len(c) == 2                                      # stops at the first comparison it is allowed to make
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+def test_fused_path_with_padded_K_multi_source(gpu_lib, div):
+    """K = 12 (three sources, sparsity, fixed ones) on a tileable shape: the blocking API pads K to 32 with zero fixed components
+    and runs the fused kernels; the padding must be invisible."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 384, 12)
+    Ks = [3, 4, 5]
+    cfg = dict(divergence=div, W_init=[W0[:, :3], W0[:, 3:7], W0[:, 7:]], H_init=[H0[:3], H0[3:7], H0[7:]], W_sparsity=[0.1, 0.0, 0.05],
+               H_sparsity=[0.0, 0.2, 0.0], W_fixed=[False, True, False], H_fixed=[False, False, True], maxiter=25, tolerance=1e-12)
+    ref = O.nmf(V, Ks, cfg)
+    _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_path=2)), ref)
+    _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_path=1)), ref)
+    lab = _labels(384, 4, 0.4, 3)
+    nz = int(np.count_nonzero(lab == -1)) + len(np.unique(lab[lab >= 0]))
+    Z0 = np.fmax(np.random.RandomState(9).rand(12, nz), 2.0 ** -52)
+    c2 = dict(divergence=div, W_init=W0, Z_init=Z0, maxiter=10, tolerance=1e-12)
+    got, want = gpu_lib.constrainednmf(V, lab, 12, dict(c2, nmfx_path=2)), O.constrainednmf(V, lab, 12, c2)
+    assert rel_fro(got[0], want[0]) <= TOL and rel_fro(got[2], want[2]) <= TOL and rel_fro(got[4], want[4]) <= 1e-6
