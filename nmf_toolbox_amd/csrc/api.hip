@@ -91,6 +91,7 @@ struct nmfx_engine {
     bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
     float *CC;                // KT x KT Gram of the stacked W (gram path)
     int nsplit_w, isplit_h;
+    long cps_w, cps_h;        // streamed extent per split (multiples of 64; the last split may be shorter)
     int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
     int chunk_parts;          // cost partials written by the chunks so far
     float *WT, *slabs, *Pbuf, *GW;
@@ -145,7 +146,7 @@ struct Layout {
 };
 
 bool div_has_matrix_den(int div) { return div != NMFX_DIV_KL; }
-int fused_split(long blocks, long extent, int K);
+int fused_split(long blocks, long extent, int K, long *c_per_split);
 
 // carve (or just size, when ws == nullptr) the workspace
 Layout layout(nmfx_engine *e, void *ws) {
@@ -198,7 +199,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
         e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
         e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
-        e->n_cost_partials = (int)(e->m / 128) + 8 * 1024;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 1024 each, or = blocks)
+        e->n_cost_partials = (int)((e->m + 127) / 128) + 8 * 1024;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 1024 each, or = blocks)
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
         e->sumV = f.take<double>(1);
@@ -277,17 +278,17 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
-                          e->m % 128 == 0 && e->n % 128 == 0 && e->hL == 0 && e->hR == 0;
+                          e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
     if (d->path == 2 && !eligible) {
-        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf, kl/euclidean, K a multiple of 32 up to 256, m %% 128 == 0, n %% 128 == 0)");
+        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf / lnmf / constrainednmf rules, kl or euclidean, K a multiple of 32 up to 256)");
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
     e->gram = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
-        e->nsplit_w = fused_split(e->m / 128, e->n, e->K);
-        e->isplit_h = fused_split(e->n / 128, e->m, e->K);
+        e->nsplit_w = fused_split((e->m + 127) / 128, e->n, e->K, &e->cps_w);
+        e->isplit_h = fused_split((e->n + 127) / 128, e->m, e->K, &e->cps_h);
     }
     return NMFX_OK;
 }
@@ -404,18 +405,23 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
 }
 
 // grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
-int fused_split(long blocks, long extent, int K) {
+int fused_split(long blocks, long extent, int K, long *c_per_split) {
     const long target = K <= 128 ? 512 : 256;   // K <= 128 kernels fit two workgroups per CU
-    int s = 1;
-    while (blocks * s < target && extent % (64L * s * 2) == 0 && extent / (s * 2) >= 64) s *= 2;
-    return s;
+    const long tiles = (extent + 63) / 64;
+    long s = 1;
+    while (blocks * s < target && s * 2 <= tiles) s *= 2;   // every split keeps at least one 64-wide tile
+    const long per = (tiles + s - 1) / s;                   // tiles per split; trailing splits that would be empty are dropped
+    *c_per_split = per * 64;
+    return (int)((tiles + per - 1) / per);
 }
 
 // fused W-step pass (K2) or cost-only pass over rows [row0, row0 + rows) of the local shard.  N of those rows goes to `out`
 // as a contiguous rows x K block; cost partials are appended at e->chunk_parts.
 nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out) {
-    const int split = fused_split(rows / 128, e->n, e->K);
-    if ((size_t)split * rows * e->K > (size_t)std::max(e->nsplit_w, 2) * e->m * e->K || e->chunk_parts + (rows / 128) * split > e->n_cost_partials) {
+    long cps = 0;
+    const long blocks = (rows + 127) / 128;
+    const int split = fused_split(blocks, e->n, e->K, &cps);
+    if ((size_t)split * rows * e->K > (size_t)std::max(e->nsplit_w, 2) * e->m * e->K || e->chunk_parts + blocks * split > e->n_cost_partials) {
         set_error("fused W-step: row chunk too small for the workspace");
         return NMFX_ERR_INVALID;
     }
@@ -423,7 +429,7 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
     memset(&f, 0, sizeof(f));
     f.X = e->W + row0; f.xs_r = 1; f.xs_k = e->m;
     f.Y = e->H; f.D = e->V + row0; f.ldd = e->m; f.R = rows; f.Cn = e->n; f.K = e->K;
-    f.c_per_split = e->n / split;
+    f.c_per_split = cps;
     f.out = split == 1 ? out : e->slabs;
     f.slab_stride = rows * (long)e->K; f.os_r = 1; f.os_k = rows;
     f.cost_partials = e->cost_partials + e->chunk_parts;
@@ -432,7 +438,7 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
         Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
         TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
     }
-    e->chunk_parts += (int)((rows / 128) * split);
+    e->chunk_parts += (int)(blocks * split);
     if (do_g2 && split > 1) {
         Scope s(e, TAG_SMALL);
         TRY(reduce_slabs(e->st, e->slabs, split, f.slab_stride, f.slab_stride, out, 0));
@@ -721,7 +727,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         memset(&f, 0, sizeof(f));
         f.X = e->H; f.xs_r = e->K; f.xs_k = 1;
         f.Y = e->WT; f.D = e->V; f.ldd = e->m; f.R = e->n; f.Cn = e->m; f.K = e->K;
-        f.c_per_split = e->m / e->isplit_h;
+        f.c_per_split = e->cps_h;
         const int func = e->div == NMFX_DIV_KL ? 2 : 0;
         const bool kl = e->div == NMFX_DIV_KL;
         static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
@@ -1002,7 +1008,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
-    const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && p->m % 128 == 0 && p->n % 128 == 0 && p->path != 1 &&
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 &&
                      (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
     std::vector<float> lw(K, 0.f), lh(K, 0.f);
@@ -1228,9 +1234,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
     DevBuf WTb, slabs, Gb, Denb, KKb, fparts;
     int nsplit_w = 1, isplit_h = 1;
+    long cps_w = n, cps_h = m;
     if (fast) {
-        nsplit_w = fused_split(m / 128, n, K);
-        isplit_h = fused_split(n / 128, m, K);
+        nsplit_w = fused_split(m / 128, n, K, &cps_w);
+        isplit_h = fused_split(n / 128, m, K, &cps_h);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
         TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * (m / 128) * nsplit_w));
     }
@@ -1238,7 +1245,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
         f.cost_partials = fparts.as<double>();
         TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
         return read_obj(st, fparts.as<double>(), (int)((m / 128) * nsplit_w), costd.as<double>(), obj, &comm);
@@ -1257,7 +1264,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = m / isplit_h;
+        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = cps_h;
         f.out = isplit_h == 1 ? Gb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
         TRY(launch_fused(st, f, isplit_h, false, 0, true, 0));
         if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Gb.as<float>(), 0));
@@ -1277,7 +1284,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         if (sc_fused_terms) {
         FusedParams f;
         memset(&f, 0, sizeof(f));
-        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = n / nsplit_w;
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
         f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
         TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
         if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));

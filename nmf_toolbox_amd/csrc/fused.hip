@@ -27,22 +27,25 @@ namespace nmfx {
 
 bool fused_supported(int K) { return K >= 32 && K <= 256 && K % 32 == 0; }
 
-// one translation unit per K group (fused_k*.hip): the 8 x 14 instantiations compile in parallel
-nmfx_status launch_fused_k32_96(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
-nmfx_status launch_fused_k128_192(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
-nmfx_status launch_fused_k224_256(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
+// one translation unit per K group and per extent kind (fused_k*.hip, fused_rag_k*.hip): the instantiations compile in parallel
+#define NMFX_DECL(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi)
+NMFX_DECL(launch_fused_k32_96); NMFX_DECL(launch_fused_k128_192); NMFX_DECL(launch_fused_k224_256);
+NMFX_DECL(launch_fused_rag_k32_96); NMFX_DECL(launch_fused_rag_k128_192); NMFX_DECL(launch_fused_rag_k224_256);
+#undef NMFX_DECL
 
-// nsplit: number of contraction ranges (grid.y); c_per_split must be a multiple of FT_C and R of FT_ROWS
+// nsplit: number of contraction ranges (grid.y); c_per_split must be a multiple of 64.  R (stationary rows) and Cn (streamed extent)
+// that are not multiples of 128 / 64 select the RAG instantiations (masked edges).
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
     constexpr int FT_ROWS = 128, FT_C = 64;   // fused_kernel.h: stationary rows per workgroup, streamed rows per tile
-    if (p.R % FT_ROWS || p.Cn % FT_C || p.c_per_split % FT_C || nsplit < 1) {
-        set_error("launch_fused: shape not tileable (R=%ld Cn=%ld c_per_split=%ld)", p.R, p.Cn, p.c_per_split);
+    if (p.R <= 0 || p.Cn <= 0 || p.c_per_split % FT_C || p.c_per_split <= 0 || nsplit < 1 || (long)(nsplit - 1) * p.c_per_split >= p.Cn) {
+        set_error("launch_fused: bad split (R=%ld Cn=%ld c_per_split=%ld nsplit=%d)", p.R, p.Cn, p.c_per_split, nsplit);
         return NMFX_ERR_INVALID;
     }
     if (!fused_supported(p.K)) { set_error("launch_fused: K=%d not supported (multiples of 32 up to 256)", p.K); return NMFX_ERR_UNSUPPORTED; }
-    if (p.K <= 96) return launch_fused_k32_96(st, p, nsplit, d_rc, func, do_g2, epi);
-    if (p.K <= 192) return launch_fused_k128_192(st, p, nsplit, d_rc, func, do_g2, epi);
-    return launch_fused_k224_256(st, p, nsplit, d_rc, func, do_g2, epi);
+    const bool rag = p.R % FT_ROWS != 0 || p.Cn % FT_C != 0;
+    if (p.K <= 96) return rag ? launch_fused_rag_k32_96(st, p, nsplit, d_rc, func, do_g2, epi) : launch_fused_k32_96(st, p, nsplit, d_rc, func, do_g2, epi);
+    if (p.K <= 192) return rag ? launch_fused_rag_k128_192(st, p, nsplit, d_rc, func, do_g2, epi) : launch_fused_k128_192(st, p, nsplit, d_rc, func, do_g2, epi);
+    return rag ? launch_fused_rag_k224_256(st, p, nsplit, d_rc, func, do_g2, epi) : launch_fused_k224_256(st, p, nsplit, d_rc, func, do_g2, epi);
 }
 
 }  // namespace nmfx

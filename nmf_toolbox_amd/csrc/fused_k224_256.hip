@@ -5,8 +5,8 @@ namespace nmfx {
 
 nmfx_status launch_fused_k224_256(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
     switch (p.K) {
-    case 224: return launch_k<224>(st, p, nsplit, d_rc, func, do_g2, epi);
-    case 256: return launch_k<256>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 224: return launch_k<224, false>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 256: return launch_k<256, false>(st, p, nsplit, d_rc, func, do_g2, epi);
     default: set_error("launch_fused: K=%d not in this group", p.K); return NMFX_ERR_UNSUPPORTED;
     }
 }

@@ -5,9 +5,9 @@ namespace nmfx {
 
 nmfx_status launch_fused_k32_96(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
     switch (p.K) {
-    case 32: return launch_k<32>(st, p, nsplit, d_rc, func, do_g2, epi);
-    case 64: return launch_k<64>(st, p, nsplit, d_rc, func, do_g2, epi);
-    case 96: return launch_k<96>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 32: return launch_k<32, false>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 64: return launch_k<64, false>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 96: return launch_k<96, false>(st, p, nsplit, d_rc, func, do_g2, epi);
     default: set_error("launch_fused: K=%d not in this group", p.K); return NMFX_ERR_UNSUPPORTED;
     }
 }

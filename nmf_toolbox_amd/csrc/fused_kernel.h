@@ -25,7 +25,10 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 
 // FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
-template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0>
+// RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
+// themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
+// elements and cost terms are masked to zero, so they add nothing to the second product.  Two extra VALU ops per element.
+template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool RAG = false>
 __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDY = K + 4;
@@ -44,13 +47,14 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
     const long r = r0 + l31;
     const long cbeg = (long)blockIdx.y * p.c_per_split;
     const long cend = cbeg + p.c_per_split < p.Cn ? cbeg + p.c_per_split : p.Cn;
-    const int ntiles = (int)((cend - cbeg) / FT_C);
+    const int ntiles = RAG ? (int)((cend - cbeg + FT_C - 1) / FT_C) : (int)((cend - cbeg) / FT_C);
+    const bool row_ok = !RAG || r < p.R;
 
     // stationary operand: B-port register s holds X(r, k = 8*(s>>2) + 4*h + (s&3))
     float xreg[NEED_S ? K / 2 : 1];
     if (NEED_S) {
 #pragma unroll
-        for (int s = 0; s < K / 2; ++s) xreg[s] = p.X[r * p.xs_r + (long)(8 * (s >> 2) + 4 * h + (s & 3)) * p.xs_k];
+        for (int s = 0; s < K / 2; ++s) xreg[s] = row_ok ? p.X[r * p.xs_r + (long)(8 * (s >> 2) + 4 * h + (s & 3)) * p.xs_k] : 0.0f;
     }
 
     f32x16 acc[DO_G2 ? NKB : 1];
@@ -75,15 +79,22 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(y_voff), "s"(ysrd), "s"(dst), "s"(soff) : "memory");
     };
-    auto y_srd = [&](int t) { return make_srd(p.Y + (cbeg + (long)t * FT_C) * K, (unsigned)(FT_C * K * 4)); };
+    // streamed rows left in tile t (FT_C except in the last, partial tile of a ragged extent): rows past them read as zero
+    auto tile_rows = [&](int t) -> int {
+        if (!RAG) return FT_C;
+        const long left = cend - (cbeg + (long)t * FT_C);
+        return left >= FT_C ? FT_C : (left > 0 ? (int)left : 0);
+    };
+    auto y_srd = [&](int t) { return make_srd(p.Y + (cbeg + (long)t * FT_C) * K, (unsigned)(tile_rows(t) * K * 4)); };
 
     // V tile of step t: d[jb*16 + reg] = V(r, c = c0 + 32*jb + rowmap(reg, h))
     float d[32];
     const unsigned d_voff = D_RC ? (unsigned)((r + 4 * h * p.ldd) * 4) : (unsigned)((p.ldd * (r - r_wg0) + 4 * h) * 4);
+    const long wg_rows = RAG ? (p.R - r_wg0 < FT_ROWS ? p.R - r_wg0 : (long)FT_ROWS) : (long)FT_ROWS;   // stationary rows this workgroup really has
     const __amdgpu_buffer_rsrc_t d_srd_fixed =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * r_wg0), 0, (int)(unsigned)(FT_ROWS * p.ldd * 4), 0x00020000);   // !D_RC
+        __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * r_wg0), 0, (int)(unsigned)(wg_rows * p.ldd * 4), 0x00020000);   // !D_RC
     auto d_srd = [&](int t) {
-        if (D_RC) return __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(FT_C * p.ldd * 4), 0x00020000);
+        if (D_RC) return __builtin_amdgcn_make_buffer_rsrc((void *)(p.D + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
         return d_srd_fixed;
     };
     // piece i of 16: D_RC two dwords (columns c0 + 32*jb + {(reg&3) + 8*(reg>>2)}), else half of the 8 float4 (one per even i)
@@ -150,22 +161,24 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
         float tc = 0.0f;
+        const int cvh = RAG ? tile_rows(t) - 4 * h : 0;       // streamed index 32*jb + (reg&3) + 8*(reg>>2) + 4*h of this tile is real iff its h-free part < cvh
         float es[2], er[2];                                   // element-map pipeline state: S value, reciprocal / quotient
         auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
             const int sl = reg & 1;
             if (PROBE & 2) { if (u == 0) asm volatile("" : "+v"(sacc[jb][reg])); return; }
             const float v = d[jb * 16 + reg];
+            const bool live = !RAG || (32 * jb + (reg & 3) + 8 * (reg >> 2)) < cvh;   // streamed index inside the matrix
             if (FUNC >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
-                if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = er[sl]; }                    // q = V ./ V_hat
+                if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
                 if (FUNC == 3) {
                     if (u == 2) er[sl] = (PROBE & 8) ? er[sl] * 1.25f : __builtin_amdgcn_logf(er[sl]);   // log2(q)
-                    if (u == 3) tc = fmaf(v, er[sl], tc);   // sum(V_hat - V) is added in closed form by the caller (see FusedParams)
+                    if (u == 3) tc = live ? fmaf(v, er[sl], tc) : tc;   // sum(V_hat - V) is added in closed form by the caller (see FusedParams)
                 }
             } else {
                 if (u == 0) {
-                    if (FUNC == 1) { const float e = v - sacc[jb][reg]; tc = fmaf(e, e, tc); }   // nmf.m:208
-                    sacc[jb][reg] = v;
+                    if (FUNC == 1) { const float e = v - sacc[jb][reg]; tc = live ? fmaf(e, e, tc) : tc; }   // nmf.m:208
+                    sacc[jb][reg] = live ? v : 0.0f;
                 }
             }
             if ((FUNC == 1 && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
         }
         dma_some(ROWS_PER_WAVE);
-        cost += (double)tc;
+        cost += row_ok ? (double)tc : 0.0;   // rows past R hold garbage (possibly NaN): theirs alone, never summed
     }
 
     // epilogue: acc[kb][reg] = O(k = 32*kb + rowmap(reg,h), r)
@@ -248,7 +261,8 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) out[r * p.os_r + (long)(32 * kb + rowmap(reg, h)) * p.os_k] = acc[kb][reg];
+                for (int reg = 0; reg < 16; ++reg)
+                    if (row_ok) out[r * p.os_r + (long)(32 * kb + rowmap(reg, h)) * p.os_k] = acc[kb][reg];
         } else {
             // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
 #pragma unroll
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int k = 32 * kb + rowmap(reg, h);
-                    if (p.fix && p.fix[k]) continue;
+                    if (!row_ok || (p.fix && p.fix[k])) continue;
                     const long idx = (long)k + (long)K * r;
                     if (p.sqrt_rule) { p.Hio[idx] = sqrtf(p.Hio[idx] * acc[kb][reg]); continue; }   // lnmf.m:76
                     const float den = p.den ? p.den[idx] : (float)p.denvec[k];

@@ -1,0 +1,14 @@
+// Fused-kernel instantiations for K in {224, 256}, ragged extents (RAG) (see fused.hip / fused_kernel.h).
+#include "fused_launch.h"
+
+namespace nmfx {
+
+nmfx_status launch_fused_rag_k224_256(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
+    switch (p.K) {
+    case 224: return launch_k<224, true>(st, p, nsplit, d_rc, func, do_g2, epi);
+    case 256: return launch_k<256, true>(st, p, nsplit, d_rc, func, do_g2, epi);
+    default: set_error("launch_fused: K=%d not in this group", p.K); return NMFX_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace nmfx

@@ -395,3 +395,38 @@ def test_fused_path_with_padded_K_multi_source(gpu_lib, div):
     c2 = dict(divergence=div, W_init=W0, Z_init=Z0, maxiter=10, tolerance=1e-12)
     got, want = gpu_lib.constrainednmf(V, lab, 12, dict(c2, nmfx_path=2)), O.constrainednmf(V, lab, 12, c2)
     assert rel_fro(got[0], want[0]) <= TOL and rel_fro(got[2], want[2]) <= TOL and rel_fro(got[4], want[4]) <= 1e-6
+
+
+# ---- ragged shapes on the fused kernels (masked edges): m, n arbitrary, K arbitrary <= 256 ---------------------------------------
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
+@pytest.mark.parametrize("m,n,K,iters", [(129, 131, 32, 10), (513, 1000, 40, 10), (200, 70, 64, 12), (64, 64, 32, 8), (1025, 300, 100, 8),
+                                         (65, 65, 7, 10), (128, 65, 64, 8), (129, 128, 96, 8), (300, 4097, 160, 5), (2049, 257, 256, 4)])
+def test_nmf_fused_ragged_shapes(gpu_lib, div, m, n, K, iters):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.nmf(V, K, cfg)
+    fused = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=2))
+    _check(fused, ref, tol=2e-5, cost_tol=2e-6)
+    _check(gpu_lib.nmf(V, K, cfg), ref, tol=2e-5, cost_tol=2e-6)        # auto picks the same kernels for these shapes
+
+
+def test_fused_ragged_other_algorithms(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(257, 333, 24)
+    cfg = dict(W_init=W0 / W0.sum(0), H_init=H0, maxiter=10, tolerance=1e-12)
+    got, ref = gpu_lib.lnmf(V, 24, dict(cfg, nmfx_path=2)), O.lnmf(V, 24, cfg)
+    assert rel_fro(got[0], ref[0]) <= 2e-5 and rel_fro(got[1], ref[1]) <= 2e-5 and rel_fro(got[2], ref[2]) <= 2e-6
+    lab = _labels(333, 5, 0.3, 8)
+    nz = int(np.count_nonzero(lab == -1)) + len(np.unique(lab[lab >= 0]))
+    Z0 = np.fmax(np.random.RandomState(9).rand(24, nz), 2.0 ** -52)
+    for div in ("kl", "euclidean"):
+        c2 = dict(divergence=div, W_init=W0, Z_init=Z0, maxiter=8, tolerance=1e-12, Z_sparsity=0.05)
+        got, want = gpu_lib.constrainednmf(V, lab, 24, dict(c2, nmfx_path=2)), O.constrainednmf(V, lab, 24, c2)
+        assert rel_fro(got[0], want[0]) <= 2e-5 and rel_fro(got[2], want[2]) <= 2e-5 and rel_fro(got[4], want[4]) <= 2e-6
+    # zeros in V on a ragged shape: NaN cost exactly like the reference, finite factors where the reference's are
+    Vz = V.copy()
+    Vz[::9, ::7] = 0.0
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3)
+    got, ref = gpu_lib.nmf(Vz, 24, dict(cfg, nmfx_path=2)), O.nmf(Vz, 24, cfg)
+    assert np.all(np.isnan(got[2])) and np.all(np.isnan(ref[2])) and rel_fro(got[0], ref[0]) < 2e-5 and rel_fro(got[1], ref[1]) < 2e-5
