@@ -1154,10 +1154,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
     DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch, pfv, pff, pfr;
-    const bool fast = p->path != 1 && fused_supported(K) && m % 128 == 0 && n % 128 == 0;
+    const bool fast = p->path != 1 && fused_supported(K) && ((m >= 64 && n >= 64) || p->path == 2);   // ragged m / n: masked-edge kernels
     if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
     if (comm.active() && !fast) {
-        set_error("nmfsc on column shards runs on the fused kernels only: K a multiple of 32 up to 256, m %% 128 == 0, n_local %% 128 == 0");
+        set_error("nmfsc on column shards runs on the fused kernels only: K a multiple of 32 up to 256");
         return NMFX_ERR_UNSUPPORTED;
     }
     if (!dev) TRY(V.alloc(mn * 4));
@@ -1236,10 +1236,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     int nsplit_w = 1, isplit_h = 1;
     long cps_w = n, cps_h = m;
     if (fast) {
-        nsplit_w = fused_split(m / 128, n, K, &cps_w);
-        isplit_h = fused_split(n / 128, m, K, &cps_h);
+        nsplit_w = fused_split((m + 127) / 128, n, K, &cps_w);
+        isplit_h = fused_split((n + 127) / 128, m, K, &cps_h);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
-        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * (m / 128) * nsplit_w));
+        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * ((m + 127) / 128) * nsplit_w));
     }
     // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
@@ -1248,7 +1248,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
         f.cost_partials = fparts.as<double>();
         TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
-        return read_obj(st, fparts.as<double>(), (int)((m / 128) * nsplit_w), costd.as<double>(), obj, &comm);
+        return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
     };
     auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
         GemmParams g;

@@ -430,3 +430,19 @@ def test_fused_ragged_other_algorithms(gpu_lib):
     cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3)
     got, ref = gpu_lib.nmf(Vz, 24, dict(cfg, nmfx_path=2)), O.nmf(Vz, 24, cfg)
     assert np.all(np.isnan(got[2])) and np.all(np.isnan(ref[2])) and rel_fro(got[0], ref[0]) < 2e-5 and rel_fro(got[1], ref[1]) < 2e-5
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0)])
+def test_nmfsc_fused_ragged(gpu_lib, sW, sH):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(129, 200, 32)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=12, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1 = {}, {}
+    ref = O.nmfsc(V, 32, cfg, info=i0)
+    got = gpu_lib.nmfsc(V, 32, dict(cfg, nmfx_path=2), info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    _check(got, ref, tol=2e-5, cost_tol=2e-6)

@@ -389,14 +389,28 @@ def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world):
         assert np.allclose(Hs.sum(1), L1s, rtol=1e-5) and np.allclose((Hs ** 2).sum(1), 1.0, rtol=1e-5) and Hs.min() >= 0
 
 
-def test_nmfsc_sharded_refuses_untileable_shards_and_negative_data(gpu_lib):
-    V, W0, H0 = synth(256, 600, 64)                            # 300 columns per shard: not a multiple of 128
+def test_nmfsc_sharded_refuses_unsupported_K_and_negative_data(gpu_lib):
+    V, W0, H0 = synth(256, 600, 20)                            # K = 20: no fused kernel, and the sharded nmfsc has no other path
     with pytest.raises(Exception, match="fused kernels only"):
         _nmfsc_threads(V, W0, H0, 2, H_sparsity=0.5, maxiter=2)
     Vn = synth(256, 512, 64)[0]
     Vn[3, 400] = -1.0                                          # only the second shard sees it: the check is global
+    W0, H0 = synth(256, 512, 64)[1:]
     with pytest.raises(ValueError, match="Negative values in data!"):
-        _nmfsc_threads(Vn, W0, H0[:, :512], 2, maxiter=2)
+        _nmfsc_threads(Vn, W0, H0, 2, maxiter=2)
+
+
+def test_nmfsc_ragged_column_shards_equal_oracle(gpu_lib):
+    """300 + 300 columns (not multiples of 128) and m = 257: the masked-edge kernels under the sharded nmfsc"""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(257, 600, 32)
+    cfg = dict(W_init=W0, H_init=H0, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
+    i0 = {}
+    W, H, cost = O.nmfsc(V, 32, cfg, info=i0)
+    res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
+    Hs = np.concatenate([r[1] for r in res], axis=1)
+    assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
+    assert rel_fro(res[0][0], W) <= 2e-5 and rel_fro(Hs, H) <= 2e-5 and rel_fro(res[0][2], cost) <= 2e-6
 
 
 def _nmfsc_dist_worker(rank, world, port, q):
