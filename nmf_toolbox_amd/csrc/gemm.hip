@@ -281,7 +281,7 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
 }
 
-// pipelined kernel: no powf maps and stacked k-views whose t blocks are whole k-tiles.  vec = float4 loads: 16-byte aligned views
+// pipelined kernel: no powf maps.  vec = float4 loads: 16-byte aligned views
 // whose contiguous dimension is a multiple of 4 (edge tiles in M, N and the last k-tile are guarded chunk-wise); otherwise the
 // dword-load variant (odd leading dimensions), which only needs stacked r-views to keep 4-element chunks inside one t block.
 static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &heavy, bool &vec) {
@@ -290,7 +290,7 @@ static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &hea
     const bool views = view_fast_ok(p.A) && view_fast_ok(p.B);
     fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && views;
     heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
-    auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };
+    auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk >= 4; };   // a 4-chunk crosses at most one block edge
     auto rview_ok = [](const OpView &v) { return v.mode != VIEW_HSTACK_RC || v.blk % 4 == 0; };
     const bool a_dim = is_kc(p.A.mode) ? p.Kc % 4 == 0 : p.M % 4 == 0;
     const bool b_dim = is_kc(p.B.mode) ? p.Kc % 4 == 0 : p.N % 4 == 0;

@@ -32,7 +32,8 @@ struct PLoader {
     int nval[2][VEC ? 1 : NCH];  // !VEC: leading elements of chunk p that are inside the matrix (0..4)
     int rval;                    // !VEC, RC: valid rows of this thread's 4-row chunk
     long kend;                   // contraction indices >= kend read as zero (last k-tile of a Kc that is not a multiple of BK)
-    int kt, kin;                 // KC stacked views: t block and offset inside it of the NEXT tile to load (tile-uniform: blk % BK == 0)
+    int kt, kin;                 // KC stacked views: t block and offset inside it of THIS THREAD's chunk (kc_next + 4c) in the next tile to load
+    int q32, r32;                // BK / blk, BK % blk: how (kt, kin) move per k-tile
     long kc_next;                // first contraction index of the next tile to load
 
     __device__ __forceinline__ void init(const OpView &v, int tid, int r_tile0, long kbeg, long R, long kend_) {
@@ -53,16 +54,20 @@ struct PLoader {
             rval = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
         }
         kc_next = kbeg;
-        kt = 0; kin = (int)kbeg;
-        if (KC && v.mode >= VIEW_HSTACK_KC) { kt = (int)(kbeg / v.blk); kin = (int)(kbeg - (long)kt * v.blk); }
+        kt = 0; kin = 0; q32 = 0; r32 = 0;
+        if (KC && v.mode >= VIEW_HSTACK_KC) {   // any block length: the (t, offset) pair is per thread and walks with the tiles
+            const long kc0 = kbeg + 4 * c;
+            kt = (int)(kc0 / v.blk); kin = (int)(kc0 - (long)kt * v.blk);
+            q32 = BK / v.blk; r32 = BK - q32 * v.blk;
+        }
     }
-    // tile-uniform part of dec_k for the KC views
-    __device__ __forceinline__ void kc_uniform(const OpView &v, long &off, int &g) const {
+    // dec_k of this thread's chunk (contraction index kc_next + 4c) for the KC views
+    __device__ __forceinline__ void kc_thread(const OpView &v, long &off, int &g) const {
         switch (v.mode) {
         case VIEW_HSTACK_KC: off = (long)kin - v.ld * kt; g = -kt; break;
         case VIEW_WSTACK_KC: off = (long)kin + v.tstride * kt; g = 0; break;
         case VIEW_XSHIFT_KC: off = (long)kin + v.ld * kt; g = -kt; break;
-        default: off = kc_next; g = 0; break;   // VIEW_KC
+        default: off = kc_next + 4 * c; g = 0; break;   // VIEW_KC
         }
     }
     // issue the global load(s) of chunk P of the next tile into register set SET
@@ -71,8 +76,8 @@ struct PLoader {
         long off; int g;
         if (KC) {
             long ok; int gk;
-            kc_uniform(v, ok, gk);
-            off = offr[P] + ok + 4 * c;
+            kc_thread(v, ok, gk);
+            off = offr[P] + ok;
             g = gr[P] + gk;
             if (!((rowok >> P) & 1) || kc_next + 4 * c >= kend) g = -1;   // Kc % 4 == 0: a chunk of 4 k is inside or outside as a whole
         } else {
@@ -89,18 +94,31 @@ struct PLoader {
             x[SET][P] = *reinterpret_cast<const float4 *>(v.p + o);
             if (PRO) { if (v.p2) y[PRO ? SET : 0][PRO ? P : 0] = *reinterpret_cast<const float4 *>(v.p2 + o); }
         } else {
-            // elements past the edge of a straddling chunk would be out of bounds on the last column: clamp each address
-            int nv;
-            if (KC) { const long left = kend - (kc_next + 4 * c); nv = left >= 4 ? 4 : (left > 0 ? (int)left : 0); }
-            else nv = rval;
-            if (!ok) nv = 0;
+            // elements past the edge of a straddling chunk would be out of bounds on the last column: clamp each address.  In a
+            // stacked k-view whose block length is not a multiple of 4 the chunk may also cross into the next t block: those
+            // elements live at another address and under the next block's (stricter) shift guard -- validity stays a prefix.
+            int lim;
+            if (KC) { const long left = kend - (kc_next + 4 * c); lim = left >= 4 ? 4 : (left > 0 ? (int)left : 0); }
+            else lim = rval;
+            if (!ok) lim = 0;
+            long eo1 = 1, eo2 = 2, eo3 = 3;
+            int nv = lim;
+            if (KC && v.mode >= VIEW_HSTACK_KC) {
+                const long dwrap = -(long)v.blk + (v.mode == VIEW_HSTACK_KC ? -v.ld : (v.mode == VIEW_WSTACK_KC ? v.tstride : v.ld));
+                const bool gnext = v.mode == VIEW_WSTACK_KC || g - 1 >= 0;     // shift guard of block t + 1
+                const int first_wrapped = v.blk - kin;                             // elements e >= first_wrapped belong to block t + 1
+                if (first_wrapped <= 1) eo1 += dwrap;
+                if (first_wrapped <= 2) eo2 += dwrap;
+                if (first_wrapped <= 3) eo3 += dwrap;
+                if (!gnext && first_wrapped < nv) nv = first_wrapped;
+            }
             nval[SET][VEC ? 0 : P] = nv;
             const float *b1 = v.p + (nv > 0 ? off : 0);
-            x[SET][P] = make_float4(b1[0], b1[nv > 1 ? 1 : 0], b1[nv > 2 ? 2 : 0], b1[nv > 3 ? 3 : 0]);
+            x[SET][P] = make_float4(b1[0], b1[nv > 1 ? eo1 : 0], b1[nv > 2 ? eo2 : 0], b1[nv > 3 ? eo3 : 0]);
             if (PRO) {
                 if (v.p2) {
                     const float *b2 = v.p2 + (nv > 0 ? off : 0);
-                    y[PRO ? SET : 0][PRO ? P : 0] = make_float4(b2[0], b2[nv > 1 ? 1 : 0], b2[nv > 2 ? 2 : 0], b2[nv > 3 ? 3 : 0]);
+                    y[PRO ? SET : 0][PRO ? P : 0] = make_float4(b2[0], b2[nv > 1 ? eo1 : 0], b2[nv > 2 ? eo2 : 0], b2[nv > 3 ? eo3 : 0]);
                 }
             }
         }
@@ -109,7 +127,7 @@ struct PLoader {
     __device__ __forceinline__ void advance(const OpView &v, bool more) {
         if (!more) return;
         kc_next += BK;
-        if (KC && v.mode >= VIEW_HSTACK_KC) { kin += BK; if (kin >= v.blk) { kin -= v.blk; ++kt; } }
+        if (KC && v.mode >= VIEW_HSTACK_KC) { kt += q32; kin += r32; if (kin >= v.blk) { kin -= v.blk; ++kt; } }
     }
     // element map + LDS store of chunk P of register set SET
     template <int SET, int P>
