@@ -313,7 +313,14 @@ nmfx_status launch_gemm(hipStream_t st, const GemmParams &p, long *blocks_out) {
     if (!fast || heavy) bm = bn = 128;
     if (heavy) fast = fast && (p.M % 128 == 0) && (p.N % 128 == 0);
     if (blocks_out) *blocks_out = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    if (pipe) return dispatch_pipe(st, p, bm, bn, vec);
+    if (pipe) {
+        const long kspan = p.splitk > 1 ? p.kc_per_split : p.Kc;
+        int tm, tn;
+        gemm_tile_shape(p.M, p.N, tm, tn);
+        auto ktile_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk % BK == 0; };   // tile-uniform t
+        const bool whole = vec && p.M % tm == 0 && p.N % tn == 0 && p.Kc % BK == 0 && kspan % BK == 0 && ktile_ok(p.A) && ktile_ok(p.B);
+        return whole ? dispatch_pipe_whole(st, p, tm, tn) : dispatch_pipe_edge(st, p, bm, bn, vec);
+    }
     if (heavy) return fast ? dispatch_views<128, 128, true, true>(st, p) : dispatch_views<128, 128, false, true>(st, p);
     if (bm == 64) return fast ? dispatch_views<64, 128, true>(st, p) : dispatch_views<128, 128, false>(st, p);
     if (bn == 64) return fast ? dispatch_views<128, 64, true>(st, p) : dispatch_views<128, 128, false>(st, p);

@@ -65,7 +65,8 @@ __device__ __forceinline__ double div_term(int div, float v, float s, float al, 
 }
 
 inline bool is_kc(int mode) { return mode == VIEW_KC || mode == VIEW_HSTACK_KC || mode == VIEW_WSTACK_KC || mode == VIEW_XSHIFT_KC; }
-// defined in gemm_pipe.hip: launches gemm_pipe_kernel<BM,BN,...> for (bm, bn) in {(128,128), (64,128), (128,64)}
-nmfx_status dispatch_pipe(hipStream_t st, const GemmParams &p, int bm, int bn, bool vec);
+// launch gemm_pipe_kernel<BM,BN,...> for (bm, bn) in {(128,128), (64,128), (128,64)}
+nmfx_status dispatch_pipe_whole(hipStream_t st, const GemmParams &p, int bm, int bn);            // gemm_pipe.hip
+nmfx_status dispatch_pipe_edge(hipStream_t st, const GemmParams &p, int bm, int bn, bool vec);   // gemm_pipe_edge.hip
 
 }  // namespace nmfx
