@@ -291,7 +291,7 @@ static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &hea
     fast = (p.M % bm == 0) && (p.N % bn == 0) && (p.Kc % BK == 0) && (kspan % BK == 0) && views;
     heavy = p.A.func == NMFX_PRO_POWPROD || p.B.func == NMFX_PRO_POWPROD || (p.epi == EPI_COST && p.cost_div == NMFX_DIV_AB);
     auto kview_ok = [](const OpView &v) { return !(v.mode >= VIEW_HSTACK_KC && is_kc(v.mode)) || v.blk >= 4; };   // a 4-chunk crosses at most one block edge
-    auto rview_ok = [](const OpView &v) { return v.mode != VIEW_HSTACK_RC || v.blk % 4 == 0; };
+    auto rview_ok = [](const OpView &) { return true; };   // stacked r-views with K % 4 != 0: the dword variant decodes every row of a chunk
     const bool a_dim = is_kc(p.A.mode) ? p.Kc % 4 == 0 : p.M % 4 == 0;
     const bool b_dim = is_kc(p.B.mode) ? p.Kc % 4 == 0 : p.N % 4 == 0;
     vec = views && a_dim && b_dim;

@@ -34,6 +34,8 @@ struct PLoader {
     int rowok;                   // bit p: the rows of chunk p exist (r < R); edge tiles of M / N that are not tile multiples
     int nval[2][VEC ? 1 : NCH];  // !VEC: leading elements of chunk p that are inside the matrix (0..4)
     int rval;                    // !VEC, RC: valid rows of this thread's 4-row chunk
+    long eoff[(!VEC && !KC) ? 4 : 1];   // !VEC, RC: dec_r of each of the 4 rows (a stacked r-view with K % 4 != 0 changes t block inside a chunk)
+    int eg[(!VEC && !KC) ? 4 : 1];
     long kend;                   // contraction indices >= kend read as zero (last k-tile of a Kc that is not a multiple of BK)
     int kt, kin;                 // KC stacked views: t block and offset inside it of THIS THREAD's chunk (kc_next + 4c) in the next tile to load
     int q32, r32;                // BK / blk, BK % blk: how (kt, kin) move per k-tile
@@ -55,6 +57,10 @@ struct PLoader {
             rowok = (r_tile0 + 4 * c < R) ? 1 : 0;           // VEC: R % 4 == 0, a chunk of 4 rows is inside or outside as a whole
             const long left = R - (r_tile0 + 4 * c);
             rval = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+            if (!VEC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dec_r(v, r_tile0 + 4 * c + e, eoff[(!VEC && !KC) ? e : 0], eg[(!VEC && !KC) ? e : 0]);
+            }
         }
         kc_next = kbeg;
         kt = 0; kin = 0; q32 = 0; r32 = 0;
@@ -109,6 +115,16 @@ struct PLoader {
             if (!ok) lim = 0;
             long eo1 = 1, eo2 = 2, eo3 = 3;
             int nv = lim;
+            if (!KC) {   // rows of the chunk decoded one by one (their shift guards only get stricter along the chunk: validity stays a prefix)
+                const long kc = kc_next + q + P * LSTEP;
+                const int gk = v.mode == VIEW_HSTACK_RC ? (int)kc + v.goff : 0;
+                eo1 = eoff[(!VEC && !KC) ? 1 : 0] - eoff[0];
+                eo2 = eoff[(!VEC && !KC) ? 2 : 0] - eoff[0];
+                eo3 = eoff[(!VEC && !KC) ? 3 : 0] - eoff[0];
+                if (nv > 1 && eg[(!VEC && !KC) ? 1 : 0] + gk < 0) nv = 1;
+                if (nv > 2 && eg[(!VEC && !KC) ? 2 : 0] + gk < 0) nv = 2;
+                if (nv > 3 && eg[(!VEC && !KC) ? 3 : 0] + gk < 0) nv = 3;
+            }
             if (KC && v.mode >= VIEW_HSTACK_KC) {
                 const long dwrap = -(long)v.blk + (v.mode == VIEW_HSTACK_KC ? -v.ld : (v.mode == VIEW_WSTACK_KC ? v.tstride : v.ld));
                 const bool gnext = v.mode == VIEW_WSTACK_KC || g - 1 >= 0;     // shift guard of block t + 1
