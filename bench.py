@@ -153,8 +153,7 @@ def main():
             req.wait()
         torch.cuda.synchronize()
         V, H, halo = Vx, Hx, (hL, hR)
-    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo, use_dist=True if force_dist else None,
-                 n_chunks=int(os.environ["NMFX_W_CHUNKS"]) if "NMFX_W_CHUNKS" in os.environ else None)
+    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo, use_dist=True if force_dist else None)
     eng.init()
     costs = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
 

@@ -12,6 +12,7 @@ computed redundantly and identically on every rank, so W stays bit-identical acr
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -143,9 +144,13 @@ class Engine:
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
         self.path_kind = int(self.lib.nmfx_engine_is_fused(self.h))
         self.cost_lags = self.path_kind == 1
-        # row chunks of the W-step partial on column shards (all-reduce / compute overlap): fused path, m a multiple of 256
-        world = dist.get_world_size(group) if self.dist else 1
-        self.n_chunks = int(n_chunks) if n_chunks is not None else (2 if (world > 1 and self.path_kind == 1 and self.m % 256 == 0) else 1)
+        # row chunks of the W-step partial on column shards (all-reduce of chunk c overlapping the compute of chunk c+1): fused
+        # path, m a multiple of 128*n_chunks.  Off (1) unless asked for: the K = 256 kernels fill every CU (one 512-VGPR wave per
+        # SIMD, 256 workgroups), so a concurrent RCCL kernel can only run by displacing compute workgroups -- whether the overlap
+        # wins has to be measured on an xGMI node first; NMFX_W_CHUNKS / n_chunks turn it on.
+        self.n_chunks = int(n_chunks) if n_chunks is not None else int(os.environ.get("NMFX_W_CHUNKS", "1"))
+        if self.path_kind != 1 or self.m % (128 * max(self.n_chunks, 1)) != 0:
+            self.n_chunks = 1
         self.has_halos = bool(self.hL or self.hR)
         if self.has_halos:   # V_hat / cost are refreshed only after the neighbours' new H columns have arrived
             _lib.check(self.lib.nmfx_engine_defer_hstep_finish(self.h, 1))
