@@ -168,8 +168,9 @@ def _dist_worker(rank, world, port, q):
     V, W0, H0 = synth(m, n, K)
     lo, hi = shard_columns(n, world, rank)
     dev = "cuda:0"
-    e = Engine(colmajor_to_torch(V[:, lo:hi], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo:hi], dev), divergence="kl")
-    assert e.dist is not None and e.rank == rank
+    e = Engine(colmajor_to_torch(V[:, lo:hi], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo:hi], dev), divergence="kl",
+               n_chunks=2)                          # also exercises the row-chunked, async all-reduce form of the W step
+    assert e.dist is not None and e.rank == rank and e.n_chunks == 2
     e.init()
     cost = torch.zeros(10, dtype=torch.float64, device=dev)
     e.iterate(10, cost)
