@@ -78,3 +78,17 @@ def test_nmfsc_c5_full_size_properties(gpu_lib):
     assert np.allclose(c, cg, rtol=2e-6) and np.all(np.diff(c) <= 0)  # the line search never increases the objective (nmfsc.m:164)
     sp = (np.sqrt(n) - np.abs(H).sum(1) / np.sqrt((H ** 2).sum(1))) / (np.sqrt(n) - 1)
     assert np.allclose(sp, 0.5, atol=2e-5) and H.min() >= 0          # Hoyer sparseness of every row is exactly the target
+
+
+@pytest.mark.parametrize("div,m,n,K", [("kl", 4097, 20001, 256), ("euclidean", 2049, 50001, 96)])
+def test_nmf_large_ragged_paths_agree(gpu_lib, div, m, n, K):
+    """Spectrogram-shaped (odd m, arbitrary n) at scale: the masked-edge fused kernels against the pipelined-GEMM path."""
+    import torch
+    V, W0, H0 = _rand(torch, (n, m), 1000), _rand(torch, (K, m), 1), _rand(torch, (n, K), 2)
+    fused, cf = _run(torch, V, W0, H0, 3, divergence=div, path=2)
+    assert fused.cost_lags
+    gen, cg = _run(torch, V, W0, H0, 3, divergence=div, path=1)
+    assert _rel(fused.W, gen.W) < 1e-5 and _rel(fused.H, gen.H) < 1e-5 and np.allclose(cf, cg, rtol=2e-6)
+    assert np.all(np.diff(cf) < 0)
+    nrm = (fused.W.double() ** 2).sum(dim=1).sqrt()
+    assert float((nrm - 1).abs().max()) < 1e-5
