@@ -6,7 +6,10 @@
  * logic before calling in here.
  *
  *   [W, H, cost, info] = nmfx_mex(algo, V, W_init, H_init, K_s, T, opts)
- *     algo   : 'nmf' | 'cnmf' | 'nmfsc' | 'cnmfsc'
+ *     algo   : 'nmf' | 'cnmf' | 'nmfsc' | 'cnmfsc' | 'lnmf'
+ *              (constrainednmf, SortDictionary, projfunc and ReconstructFromDecomposition take other argument lists: their
+ *               gateways are the same dozen lines around nmfx_constrainednmf / nmfx_sort_dictionary / nmfx_projfunc /
+ *               nmfx_reconstruct)
  *     V      : m x n double          W_init : m x K x T double        H_init : K x n double
  *     K_s    : 1 x S int32 (basis elements per source, sum = K)
  *     opts   : struct with fields divergence (int32 nmfx_divergence), alpha, beta, W_sparsity, H_sparsity (1 x S double),
@@ -74,6 +77,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     else if (!strcmp(algo, "cnmf")) st = nmfx_cnmf(&p, &r);
     else if (!strcmp(algo, "nmfsc")) st = nmfx_nmfsc(&p, &r);
     else if (!strcmp(algo, "cnmfsc")) st = nmfx_cnmfsc(&p, &r);
+    else if (!strcmp(algo, "lnmf")) st = nmfx_lnmf(&p, &r);
     else { mexErrMsgIdAndTxt("nmfx:algo", "unknown algorithm %s", algo); return; }
     if (st != NMFX_OK) mexErrMsgIdAndTxt("nmfx:error", "%s", nmfx_last_error());   /* same text the reference's error() uses */
     mxSetM(plhs[2], (mwSize)r.cost_len);                                         /* cost = cost(1:iter) trim (nmf.m:222) */
