@@ -463,8 +463,7 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
 nmfx_status refresh_w_derived(nmfx_engine *e) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
     TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
     if (e->div == NMFX_DIV_KL) {
-        TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->colsum));
-        TRY(sum_over_t(e->st, e->colsum, e->K, 1, e->Gpvec));
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->Gpvec));   // T == 1: colsum(W) is the H-step denominator as is
     }
     return NMFX_OK;
 }
@@ -672,8 +671,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
         if (e->div == NMFX_DIV_KL) {
             Scope s(e, TAG_SMALL);
-            TRY(f2d(e->st, e->packed + mK, e->Pvec, e->K));
-            p.Pvec = e->Pvec;
+            p.Pvecf = e->packed + mK;   // the all-reduced rowsum(H), still fp32 as it travelled
         } else {
             Scope s(e, TAG_GRAM);   // P = W * (H*H')
             TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
@@ -759,8 +757,11 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
             }
             Scope s(e, TAG_SMALL);
-            if (e->isplit_h > 1) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
-            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
+            if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f,
+                                       e->isplit_h, f.slab_stride));
+            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
             else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
         }
         e->cost_valid = false;

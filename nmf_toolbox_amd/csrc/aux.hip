@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     const long cr = p.m / nch;
     const long KT = (long)p.K * p.T;
     const float *pp = p.P ? p.P + p.m * c : nullptr;
-    const float pv = p.Pvec ? (float)p.Pvec[c] : 0.0f;
+    const float pv = p.Pvec ? (float)p.Pvec[c] : (p.Pvecf ? p.Pvecf[c] : 0.0f);
     double dn = 0.0, dp = 0.0;
     const float lam = p.lamW ? p.lamW[k] : 0.0f;
     const bool vec = (cr & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(p.N) | reinterpret_cast<uintptr_t>(pp)) & 15) == 0;
@@ -297,23 +297,26 @@ nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s)
 
 // H <- H .* (Gn.^e ./ max(Gp.^e + lambda, eps))     nmf.m:199 / cnmf.m:231
 __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long count,
-                                const float *lamH, const uint8_t *fixH, float inv_exp) {
+                                const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     const int k = (int)(idx % K);
     if (fixH && fixH[k]) return;
     float neg = Gn[idx];
+    for (int sl = 1; sl < n_slabs; ++sl) neg += Gn[idx + sl * slab_stride];   // split partial sums, fixed order (deterministic)
+    const float gsum = neg;
     float pos = Gp ? Gp[idx] : (float)Gpvec[k];
     if (inv_exp != 1.0f) { neg = powf(neg, inv_exp); pos = powf(pos, inv_exp); }
     const float lam = lamH ? lamH[k] : 0.0f;
-    if (inv_exp == -2.0f) { H[idx] = sqrtf(H[idx] * Gn[idx]); return; }   // lnmf.m:76  H = sqrt(H .* (W'*(V./V_hat)))
+    if (inv_exp == -2.0f) { H[idx] = sqrtf(H[idx] * gsum); return; }   // lnmf.m:76  H = sqrt(H .* (W'*(V./V_hat)))
     H[idx] = H[idx] * (neg / fmaxf(pos + lam, NMFX_EPS_F));
 }
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
-                     const float *lamH, const uint8_t *fixH, float inv_exp) {
+                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride) {
     long count = (long)K * n;
     if (count <= 0) return NMFX_OK;
-    hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H, Gn, Gp, Gpvec, K, count, lamH, fixH, inv_exp);
+    hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H, Gn, Gp, Gpvec, K, count, lamH, fixH, inv_exp,
+                       n_slabs, slab_stride);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

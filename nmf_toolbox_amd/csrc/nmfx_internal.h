@@ -137,6 +137,7 @@ struct WUpdateParams {
     const float *N;      // m x (K*T) numerator GEMM result
     const float *P;      // m x (K*T) denominator GEMM result, or nullptr when Pvec is used
     const double *Pvec;  // [K*T] broadcast denominator (KL: rowsum of (shifted) H), or nullptr
+    const float *Pvecf;  // the same as fp32 (the all-reduced tail of `packed`), used when Pvec is nullptr
     const float *lamW;   // [K] device or nullptr
     const uint8_t *fixW; // [K] device or nullptr
     long m;
@@ -153,7 +154,7 @@ nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, in
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
-                     const float *lamH, const uint8_t *fixH, float inv_exp);
+                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs = 1, long slab_stride = 0);   // n_slabs > 1: Gn = sum of slabs
 nmfx_status z_update(hipStream_t st, float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long nz, const long *seg,
                      const float *lamZ, const uint8_t *fixZ, float inv_exp, int gather_only);
 nmfx_status center_of_gravity(hipStream_t st, const void *W, int is_f64, long m, int K, int *cog);
