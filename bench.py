@@ -171,6 +171,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
+    comm_total_ms, comm_calls = eng.comm_ms()
     eng.profile(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1 or force_dist:
@@ -222,6 +223,9 @@ def main():
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,
         }
+        if comm_calls:   # N > 1: how long the compute stream waited for the packed all-reduce (rank 0), per step
+            out["allreduce_ms_per_step"] = round(comm_total_ms / args.steps, 4)
+            out["allreduce_bytes"] = int(eng.packed.numel() * 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(alg, div, m, n, K, T)

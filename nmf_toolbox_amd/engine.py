@@ -76,7 +76,14 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
             backend.wstep_partial()
             if lag and it > 0 and cost_out is not None:
                 emit(it - 1)
+            ev = getattr(backend, "comm_events", None)        # measurement hook: how long the compute stream stalls on the exchange
+            if ev is not None:
+                a, b = backend.torch.cuda.Event(enable_timing=True), backend.torch.cuda.Event(enable_timing=True)
+                a.record()
             dist.all_reduce(backend.packed, group=group)      # the ONE exchange step of an iteration
+            if ev is not None:
+                b.record()
+                ev.append((a, b))
         backend.wstep_finish()
         backend.hstep()
         if getattr(backend, "has_halos", False):
@@ -240,6 +247,12 @@ class Engine:
     # ---- measurement hooks -------------------------------------------------------------------
     def profile(self, enable=True):
         _lib.check(self.lib.nmfx_engine_profile(self.h, 1 if enable else 0))
+        self.comm_events = [] if (enable and self.dist is not None and self.V.is_cuda) else None
+
+    def comm_ms(self):
+        """after torch.cuda.synchronize(): total ms the compute stream spent in the packed all-reduce while profiling was on"""
+        ev = getattr(self, "comm_events", None) or []
+        return sum(a.elapsed_time(b) for a, b in ev), len(ev)
 
     def profile_read(self):
         """after torch.cuda.synchronize(): {tag_name: dict(ms_total, launches, flops, bytes)}"""
