@@ -446,3 +446,47 @@ def test_nmfsc_fused_ragged(gpu_lib, sW, sH):
     got = gpu_lib.nmfsc(V, 32, dict(cfg, nmfx_path=2), info=i1)
     assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
     _check(got, ref, tol=2e-5, cost_tol=2e-6)
+
+
+def test_nmf_random_shapes_fuzz(gpu_lib):
+    """40 seeded random (m, n, K, divergence, sparsity, fixed) problems between 64 and 400 rows / columns: whichever kernels the
+    engine picks (masked-edge fused with padded K, or the pipelined GEMM path when forced) must match the oracle."""
+    from oracle import nmf_oracle as O
+    rs = np.random.RandomState(2024)
+    worst = 0.0
+    for trial in range(40):
+        m, n = int(rs.randint(64, 400)), int(rs.randint(64, 400))
+        K = int(rs.choice([1, 2, 3, 5, 8, 13, 20, 32, 33, 50, 64, 70]))
+        div = str(rs.choice(["kl", "euclidean"]))
+        V, W0, H0 = synth(m, n, K)
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=int(rs.randint(2, 9)), tolerance=1e-300)   # no early stop: converged
+        if rs.rand() < 0.5:                                                                                  # rank-1 cases sit at fp32 noise
+            cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.1), float(rs.rand() * 0.1)
+        if rs.rand() < 0.2:
+            cfg["W_fixed"] = True
+        elif rs.rand() < 0.2:
+            cfg["H_fixed"] = True
+        path = int(rs.choice([0, 1, 2]))
+        ref = O.nmf(V, K, cfg)
+        got = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=path))
+        assert len(got[2]) == len(ref[2]), (trial, m, n, K, div, path)
+        e = max(rel_fro(got[0], ref[0]), rel_fro(got[1], ref[1]))
+        worst = max(worst, e)
+        assert e <= 3e-5 and rel_fro(got[2], ref[2]) <= 3e-6, (trial, m, n, K, div, path, e, rel_fro(got[2], ref[2]))
+    assert worst <= 3e-5
+
+
+def test_cnmf_random_shapes_fuzz(gpu_lib):
+    from oracle import nmf_oracle as O
+    rs = np.random.RandomState(77)
+    for trial in range(20):
+        m, n = int(rs.randint(20, 300)), int(rs.randint(40, 300))
+        K, T = int(rs.choice([1, 3, 4, 6, 10, 16, 25, 32])), int(rs.randint(1, 7))
+        div = str(rs.choice(["kl", "euclidean", "is"]))
+        V, W0, H0 = synth(m, n, K, T=T)
+        cfg = dict(divergence=div, W_init=W0 if T > 1 else W0[:, :, 0], H_init=H0, maxiter=int(rs.randint(2, 6)), tolerance=1e-300,
+                   W_sparsity=float(rs.rand() * 0.05), H_sparsity=float(rs.rand() * 0.05))
+        ref = O.cnmf(V, K, T, cfg)
+        got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=int(rs.choice([0, 1]))))
+        assert len(got[2]) == len(ref[2]), (trial, m, n, K, T, div)
+        assert rel_fro(got[0], ref[0]) <= 3e-5 and rel_fro(got[1], ref[1]) <= 3e-5 and rel_fro(got[2], ref[2]) <= 1e-5, (trial, m, n, K, T, div)
