@@ -490,3 +490,23 @@ def test_cnmf_random_shapes_fuzz(gpu_lib):
         got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=int(rs.choice([0, 1]))))
         assert len(got[2]) == len(ref[2]), (trial, m, n, K, T, div)
         assert rel_fro(got[0], ref[0]) <= 3e-5 and rel_fro(got[1], ref[1]) <= 3e-5 and rel_fro(got[2], ref[2]) <= 1e-5, (trial, m, n, K, T, div)
+
+
+def test_nmfsc_random_shapes_fuzz(gpu_lib):
+    from oracle import nmf_oracle as O
+    rs = np.random.RandomState(5)
+    for trial in range(10):
+        m, n = int(rs.randint(64, 300)), int(rs.randint(64, 300))
+        K = int(rs.choice([4, 9, 32, 64]))
+        sW, sH = float(rs.choice([0.0, 0.3, 0.6])), float(rs.choice([0.0, 0.4, 0.7]))
+        V, W0, H0 = synth(m, n, K)
+        cfg = dict(W_init=W0, H_init=H0, maxiter=int(rs.randint(3, 8)), tolerance=1e-300)
+        if sW:
+            cfg["W_sparsity"] = sW
+        if sH:
+            cfg["H_sparsity"] = sH
+        i0, i1 = {}, {}
+        ref = O.nmfsc(V, K, cfg, info=i0)
+        got = gpu_lib.nmfsc(V, K, cfg, info=i1)
+        assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"], (trial, m, n, K, sW, sH, i0, i1)
+        assert rel_fro(got[0], ref[0]) <= 3e-5 and rel_fro(got[1], ref[1]) <= 3e-5 and rel_fro(got[2], ref[2]) <= 3e-6, (trial, m, n, K, sW, sH)
