@@ -1191,6 +1191,15 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         if (comm.active()) return projfunc_cols_dist(st, HxT, n, K, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>());
         return projfunc_cols(st, HxT, n, K, L1s, 1.0, 1, nullptr);
     };
+    // out = projection of (base + mu*dir), rows of H as the columns of the n x K transposed copies   (nmfsc.m:154-157)
+    auto step_project_H = [&](const float *baseT, const float *dirT, float mu, float *outT) -> nmfx_status {
+        if (comm.active()) {
+            TRY(axpy_f32(st, (long)Kn, mu, dirT, baseT, outT));
+            return project_H(outT);
+        }
+        NMFX_HIP(hipMemcpyAsync(outT, baseT, Kn * 4, hipMemcpyDeviceToDevice, st));
+        return projfunc_cols(st, outT, n, K, L1s, 1.0, 1, nullptr, dirT, mu);   // the step is applied while loading
+    };
     TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
     if (sW > 0) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
     if (sH > 0) TRY(project_H(HTd));                                        // nmfsc.m:107-109
@@ -1319,8 +1328,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
-                        TRY(project_H(HnewT));                                                      // nmfsc.m:155-157
+                        TRY(step_project_H(HTd, G1.as<float>(), (float)(-stepH), HnewT));           // nmfsc.m:154-157
                         TRY(transpose_f32(st, HnewT, n, K, Hcand));
                         TRY(fast_obj(Wd, Hcand, &newobj));                                          // nmfsc.m:160-161
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
@@ -1737,14 +1745,19 @@ nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s
                           int32_t *usediters, int32_t device) {
     if (N <= 0 || count <= 0 || !s || !v) { set_error("nmfx_projfunc: bad arguments"); return NMFX_ERR_INVALID; }
     TRY(check_device(device));
+    if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("nmfx_projfunc: dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
     const size_t tot = (size_t)N * count;
-    DevBuf X, it, stage;
-    TRY(X.alloc(tot * 4)); TRY(it.alloc(sizeof(int) * count)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    DevBuf X, it;
+    TRY(X.alloc(tot * dsize(dtype))); TRY(it.alloc(sizeof(int) * count));
     hipStream_t st = nullptr;
-    TRY(upload(st, s, dtype, X.as<float>(), tot, 1.0, stage, STAGE_ELEMS));
-    TRY(projfunc_cols(st, X.as<float>(), N, count, k1, k2, nn, it.as<int>()));
-    if (usediters) NMFX_HIP(hipMemcpy(usediters, it.p, sizeof(int) * count, hipMemcpyDeviceToHost));
-    return download(st, X.as<float>(), dtype, v, tot, stage, STAGE_ELEMS);
+    // the vectors stay in the caller's precision: float64 input is projected in float64 end to end (projfunc.m computes in double)
+    NMFX_HIP(hipMemcpyAsync(X.p, s, tot * dsize(dtype), hipMemcpyHostToDevice, st));
+    if (dtype == NMFX_F64) TRY(projfunc_cols_f64(st, X.as<double>(), N, count, k1, k2, nn, it.as<int>()));
+    else TRY(projfunc_cols(st, X.as<float>(), N, count, k1, k2, nn, it.as<int>()));
+    if (usediters) NMFX_HIP(hipMemcpyAsync(usediters, it.p, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipMemcpyAsync(v, X.p, tot * dsize(dtype), hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipStreamSynchronize(st));
+    return NMFX_OK;
 }
 
 }  // extern "C"

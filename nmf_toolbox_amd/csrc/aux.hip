@@ -523,7 +523,8 @@ nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const dou
 __global__ __launch_bounds__(256) void transpose_kernel(const float *in, long rows, long cols, float *out) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+    const long rtiles = (rows + 31) / 32;   // 1-D grid over the tiles: neither extent is bound by the 65535 limit of grid.y
+    const long r0 = ((long)blockIdx.x % rtiles) * 32, c0 = ((long)blockIdx.x / rtiles) * 32;
     for (int y = ty; y < 32; y += 8)
         if (r0 + tx < rows && c0 + y < cols) tile[y][tx] = in[(r0 + tx) + rows * (c0 + y)];
     __syncthreads();
@@ -532,7 +533,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *in, long ro
 }
 nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out) {
     if (rows <= 0 || cols <= 0) return NMFX_OK;
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, st, in, rows, cols, out);
+    const long tiles = ((rows + 31) / 32) * ((cols + 31) / 32);
+    if (tiles > 0x7fffffffL) { set_error("transpose_f32: %ld x %ld is too large", rows, cols); return NMFX_ERR_INVALID; }
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tiles), dim3(256), 0, st, in, rows, cols, out);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -1,6 +1,6 @@
 // Hoyer's L1/L2 projection (projfunc.m:13-65) for `count` vectors stored as the columns of X
 // (len x count, column-major), in place.  One 1024-thread workgroup per vector; the vector lives in
-// registers as fp64 for the whole iteration (len <= 1024*EPT), every reduction (sum, w'w, w'v, v'v,
+// registers (+ LDS beyond 16 elements per thread) as fp64 for the whole iteration (len <= 32768), every reduction (sum, w'w, w'v, v'v,
 // |Z|, all(v>=0)) is a wave-shuffle + LDS tree in fp64 so the discrete branches (v<=0 sets,
 // nmfsc.m:164 objective test downstream) follow the float64 reference.  Bandwidth-class: the only
 // HBM traffic is one read and one write of the vector.
@@ -34,14 +34,25 @@ __device__ __forceinline__ Red4 block_red4(Red4 v, double *red) {
     return r;
 }
 
-template <int EPT>
-__global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len, double k1, double k2, int nn, int *usediters) {
+// Working vector: element e of thread tid is x[tid + e*1024].  The first ER elements per thread live in registers (fp64, 2 VGPRs
+// each), the next EL in LDS (fp64, [e][tid]: conflict-free b64 accesses) -- 16 + 16 covers len <= 32768 (a row of H at BASELINE
+// config 5) with 128 KiB of LDS and no scratch spills (the all-register variant needed 64 + temporaries > 128 VGPRs at 1024 threads
+// and spilled 212 of them).  TIO = float (engine buffers) or double (nmfx_projfunc on float64 input: no fp32 rounding anywhere).
+// dir != nullptr fuses the line-search step into the load: s = x + mu*dir (fp32, as the separate axpy kernel computed it; nmfsc.m:154).
+template <int ER, int EL, typename TIO>
+__global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, float mu) {
     __shared__ double red[PF_WAVES * 4];
-    float *x = X + len * blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double vl[];   // [EL][PF_THREADS]
+    constexpr int EPT = ER + EL;
+    static_assert(EPT <= 64, "one mask bit per element");
+    TIO *x = X + len * blockIdx.x;
+    const float *dx = dir ? dir + len * blockIdx.x : nullptr;
     const int tid = threadIdx.x;
     const double N = (double)len;
-    double v[EPT];
+    double vr[ER > 0 ? ER : 1];
     unsigned long long zmask = 0ull, negmask = 0ull;
+    auto get = [&](int e) -> double { return e < ER ? vr[e < ER ? e : 0] : vl[(e - ER) * PF_THREADS + tid]; };
+    auto put = [&](int e, double val) { if (e < ER) vr[e < ER ? e : 0] = val; else vl[(e - ER) * PF_THREADS + tid] = val; };
 
     Red4 r = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -49,16 +60,17 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
         const long i = tid + (long)e * PF_THREADS;
         double s = 0.0;
         if (i < len) {
-            s = (double)x[i];
+            if (sizeof(TIO) == 4 && dx) s = (double)((float)x[i] + mu * dx[i]);
+            else s = (double)x[i];
             if (!nn) { if (s < 0) negmask |= 1ull << e; s = fabs(s); }   // projfunc.m:16-19
         }
-        v[e] = s;
+        put(e, s);
         r.a += s;
     }
     r = block_red4(r, red);
     const double shift0 = (k1 - r.a) / N;                                  // projfunc.m:22
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) v[e] += shift0;
+    for (int e = 0; e < EPT; ++e) put(e, get(e) + shift0);
 
     double nz = 0.0;
     int j = 0;
@@ -69,10 +81,11 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
         for (int e = 0; e < EPT; ++e) {
             const long i = tid + (long)e * PF_THREADS;
             if (i < len) {
-                const double w = v[e] - (((zmask >> e) & 1ull) ? 0.0 : mid); // projfunc.m:33
+                const double ve = get(e);
+                const double w = ve - (((zmask >> e) & 1ull) ? 0.0 : mid); // projfunc.m:33
                 r.a += w * w;                                              // projfunc.m:34
-                r.b += w * v[e];                                           // projfunc.m:35
-                r.c += v[e] * v[e];                                        // projfunc.m:36
+                r.b += w * ve;                                             // projfunc.m:35
+                r.c += ve * ve;                                            // projfunc.m:36
             }
         }
         r = block_red4(r, red);
@@ -84,9 +97,11 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
         for (int e = 0; e < EPT; ++e) {
             const long i = tid + (long)e * PF_THREADS;
             if (i < len) {
-                const double w = v[e] - (((zmask >> e) & 1ull) ? 0.0 : mid);
-                v[e] = alphap * w + v[e];                                  // projfunc.m:38
-                if (!(v[e] >= 0.0)) r.a += 1.0;                            // projfunc.m:40 all(v>=0)
+                const double ve = get(e);
+                const double w = ve - (((zmask >> e) & 1ull) ? 0.0 : mid);
+                const double vn = alphap * w + ve;                         // projfunc.m:38
+                put(e, vn);
+                if (!(vn >= 0.0)) r.a += 1.0;                              // projfunc.m:40 all(v>=0)
             }
         }
         r = block_red4(r, red);
@@ -98,8 +113,9 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
         for (int e = 0; e < EPT; ++e) {
             const long i = tid + (long)e * PF_THREADS;
             if (i < len) {
-                if (v[e] <= 0.0) { zmask |= 1ull << e; v[e] = 0.0; r.b += 1.0; }   // projfunc.m:49-50
-                r.a += v[e];                                                       // projfunc.m:51
+                double ve = get(e);
+                if (ve <= 0.0) { zmask |= 1ull << e; ve = 0.0; put(e, 0.0); r.b += 1.0; }   // projfunc.m:49-50
+                r.a += ve;                                                              // projfunc.m:51
             }
         }
         r = block_red4(r, red);
@@ -107,29 +123,44 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(float *X, long len
         const double shift = (k1 - r.a) / (N - nz);                        // projfunc.m:52
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
-            if (!((zmask >> e) & 1ull)) v[e] += shift;                     // projfunc.m:52-53
+            if (!((zmask >> e) & 1ull)) put(e, get(e) + shift);            // projfunc.m:52-53
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const long i = tid + (long)e * PF_THREADS;
-        if (i < len) x[i] = (float)(((negmask >> e) & 1ull) ? -v[e] : v[e]);       // projfunc.m:58-60
+        if (i < len) x[i] = (TIO)(((negmask >> e) & 1ull) ? -get(e) : get(e));         // projfunc.m:58-60
     }
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
 }
 
+template <int ER, int EL, typename TIO>
+static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, float mu) {
+    auto kern = projfunc_kernel<ER, EL, TIO>;
+    const size_t ldsb = sizeof(double) * EL * PF_THREADS;
+    static bool attr_done = false;
+    if (ldsb > 48 * 1024 && !attr_done) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(count), dim3(PF_THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
 
 // Any length: the working vector lives in a global fp64 scratch row (L2-resident for realistic sizes) instead of registers.
-__global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(float *X, long len, double k1, double k2, int nn, int *usediters, double *scratch,
-                                                                  unsigned char *flags) {
+template <typename TIO>
+__global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, double *scratch,
+                                                                  unsigned char *flags, const float *dir, float mu) {
     __shared__ double red[PF_WAVES * 4];
-    float *x = X + len * blockIdx.x;
+    TIO *x = X + len * blockIdx.x;
+    const float *dx = dir ? dir + len * blockIdx.x : nullptr;
     double *v = scratch + len * blockIdx.x;
     unsigned char *fl = flags + len * blockIdx.x;   // bit0: in Z, bit1: was negative
     const int tid = threadIdx.x;
     const double N = (double)len;
     Red4 r = {0.0, 0.0, 0.0, 0.0};
     for (long i = tid; i < len; i += PF_THREADS) {
-        double s = (double)x[i];
+        double s = (sizeof(TIO) == 4 && dx) ? (double)((float)x[i] + mu * dx[i]) : (double)x[i];
         unsigned char f = 0;
         if (!nn) { if (s < 0) f = 2; s = fabs(s); }
         v[i] = s; fl[i] = f; r.a += s;
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(float *X, lon
         for (long i = tid; i < len; i += PF_THREADS)
             if (!(fl[i] & 1)) v[i] += shift;
     }
-    for (long i = tid; i < len; i += PF_THREADS) x[i] = (float)((fl[i] & 2) ? -v[i] : v[i]);
+    for (long i = tid; i < len; i += PF_THREADS) x[i] = (TIO)((fl[i] & 2) ? -v[i] : v[i]);
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
 }
 
@@ -282,12 +313,15 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
     const double N = (double)N_total;
     std::vector<double> host(4 * (size_t)count);
     hipLaunchKernelGGL(pfd_init_kernel, g, b, 0, st, X, len, nn, v_scratch, flags, red, state);
+    NMFX_HIP(hipGetLastError());
     nmfx_status rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM);
     if (rc != NMFX_OK) return rc;
     for (int j = 0; j <= PF_MAX_ITERS; ++j) {
         hipLaunchKernelGGL(pfd_shift_sums_kernel, g, b, 0, st, v_scratch, flags, len, N, k1, red, state);
+        NMFX_HIP(hipGetLastError());
         if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
         hipLaunchKernelGGL(pfd_step_kernel, g, b, 0, st, v_scratch, flags, len, N, k1, k2, red, state);
+        NMFX_HIP(hipGetLastError());
         if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
         NMFX_HIP(hipMemcpyAsync(host.data(), red, sizeof(double) * host.size(), hipMemcpyDeviceToHost, st));
         NMFX_HIP(hipStreamSynchronize(st));
@@ -295,6 +329,7 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
         for (int k = 0; k < count; ++k) all_done &= host[4 * (size_t)k] == 0.0;
         if (all_done) break;
         hipLaunchKernelGGL(pfd_zero_kernel, g, b, 0, st, v_scratch, flags, len, red, state);
+        NMFX_HIP(hipGetLastError());
         if ((rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM)) != NMFX_OK) return rc;
     }
     hipLaunchKernelGGL(pfd_store_kernel, g, b, 0, st, X, v_scratch, flags, len);
@@ -302,26 +337,34 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
     return NMFX_OK;
 }
 
-nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
+template <typename TIO>
+static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu) {
     if (count <= 0 || len <= 0) return NMFX_OK;
-    dim3 g(count), b(PF_THREADS);
-    if (len <= 4L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<4>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
-    else if (len <= 16L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<16>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
-    else if (len <= 32L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<32>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
-    else if (len <= 64L * PF_THREADS) hipLaunchKernelGGL(projfunc_kernel<64>, g, b, 0, st, X, len, k1, k2, nn, usediters_dev);
-    else {   // longer than the register-resident limit: global fp64 working rows (allocated per call; this is the rare path)
-        double *scratch = nullptr;
-        unsigned char *flags = nullptr;
-        NMFX_HIP(hipMalloc(&scratch, sizeof(double) * (size_t)len * count));
-        hipError_t e2 = hipMalloc(&flags, (size_t)len * count);
-        if (e2 != hipSuccess) { (void)hipFree(scratch); set_error("projfunc: hipMalloc failed: %s", hipGetErrorString(e2)); return NMFX_ERR_NOMEM; }
-        hipLaunchKernelGGL(projfunc_long_kernel, g, b, 0, st, X, len, k1, k2, nn, usediters_dev, scratch, flags);
-        hipError_t e3 = hipStreamSynchronize(st);
-        (void)hipFree(scratch); (void)hipFree(flags);
-        if (e3 != hipSuccess) { set_error("projfunc_long: %s", hipGetErrorString(e3)); return NMFX_ERR_HIP; }
-    }
-    NMFX_HIP(hipGetLastError());
+    // elements per thread: registers first (<= 16 doubles: no spills under the 128-VGPR budget of a 1024-thread block), then LDS
+    if (len <= 4L * PF_THREADS) return launch_pf<4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    if (len <= 8L * PF_THREADS) return launch_pf<8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    if (len <= 16L * PF_THREADS) return launch_pf<16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    if (len <= 24L * PF_THREADS) return launch_pf<16, 8, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    if (len <= 32L * PF_THREADS) return launch_pf<16, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    // longer than registers + LDS hold: global fp64 working rows (allocated per call; this is the rare path)
+    double *scratch = nullptr;
+    unsigned char *flags = nullptr;
+    NMFX_HIP(hipMalloc(&scratch, sizeof(double) * (size_t)len * count));
+    hipError_t e2 = hipMalloc(&flags, (size_t)len * count);
+    if (e2 != hipSuccess) { (void)hipFree(scratch); set_error("projfunc: hipMalloc failed: %s", hipGetErrorString(e2)); return NMFX_ERR_NOMEM; }
+    hipLaunchKernelGGL(projfunc_long_kernel<TIO>, dim3(count), dim3(PF_THREADS), 0, st, X, len, k1, k2, nn, usediters_dev, scratch, flags, dir, mu);
+    hipError_t e3 = hipGetLastError();
+    if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
+    (void)hipFree(scratch); (void)hipFree(flags);
+    if (e3 != hipSuccess) { set_error("projfunc_long: %s", hipGetErrorString(e3)); return NMFX_ERR_HIP; }
     return NMFX_OK;
+}
+
+nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu) {
+    return projfunc_cols_t<float>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+}
+nmfx_status projfunc_cols_f64(hipStream_t st, double *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
+    return projfunc_cols_t<double>(st, X, len, count, k1, k2, nn, usediters_dev, nullptr, 0.0f);
 }
 
 }  // namespace nmfx

@@ -40,7 +40,7 @@ def reconstruct_from_decomposition(W, H):
     V_hat = np.zeros((m, n))
     for t in range(1, T + 1):
         Hs = np.concatenate([np.zeros((K, t - 1)), H[:, : n - t + 1]], axis=1)
-        V_hat = V_hat + W[:, :, t - 1] @ Hs
+        V_hat = V_hat + np.ascontiguousarray(W[:, :, t - 1]) @ Hs   # contiguous copy (what MATLAB's W(:,:,t) is): a strided slice would bypass BLAS
     return V_hat
 
 
@@ -386,7 +386,7 @@ def cnmf(V, num_basis_elems, context_len, config=None, rng=None):
                 lam = cfg["W_sparsity"][s]
                 for t in range(1, T + 1):
                     Hsh = _rshift(H[s], t, n)             # cnmf.m:181/188
-                    Wt = W[s][:, :, t - 1]
+                    Wt = np.ascontiguousarray(W[s][:, :, t - 1])   # MATLAB's W(:,:,t) is a contiguous copy; a strided view bypasses BLAS
                     if use_dual:                          # cnmf.m:180-185
                         Vn = _pw(V, alpha - 1) * _pw(V_hat, beta)
                         Vp = _pw(V, alpha + beta - 1)
@@ -419,7 +419,7 @@ def cnmf(V, num_basis_elems, context_len, config=None, rng=None):
                 for t in range(1, T + 1):                 # cnmf.m:217-226
                     Vn_sh = _lshift(V_neg, t, n)
                     Vp_sh = V_pos if is_kl else _lshift(V_pos, t, n)   # cnmf.m:220-224 (KL: unshifted)
-                    Wt = W[s][:, :, t - 1]
+                    Wt = np.ascontiguousarray(W[s][:, :, t - 1])   # MATLAB's W(:,:,t) is a contiguous copy; a strided view bypasses BLAS
                     gneg = gneg + Wt.T @ Vn_sh
                     gpos = gpos + Wt.T @ Vp_sh
                 ex = (1.0 / beta) if use_dual else (1.0 / alpha)       # cnmf.m:227-231
@@ -637,8 +637,8 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
             neg = np.zeros((K, n))
             pos = np.zeros((K, n))
             for t in range(1, T + 1):                     # cnmfsc.m:160-165
-                neg = neg + W0[:, :, t - 1].T @ _lshift(V, t, n)
-                pos = pos + W0[:, :, t - 1].T @ _lshift(V_hat, t, n)
+                neg = neg + np.ascontiguousarray(W0[:, :, t - 1]).T @ _lshift(V, t, n)
+                pos = pos + np.ascontiguousarray(W0[:, :, t - 1]).T @ _lshift(V_hat, t, n)
             if sH > 0:
                 dH = pos - neg                            # cnmfsc.m:168
                 begobj = cost[it - 1]
@@ -699,7 +699,7 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
                     pos = V_hat @ Hsh.T
                     with np.errstate(divide="ignore", invalid="ignore"):
                         W[:, :, t - 1] = W0[:, :, t - 1] * (neg / np.fmax(pos, EPS))
-                    V_hat = np.fmax(V_hat + (W[:, :, t - 1] - W0[:, :, t - 1]) @ Hsh, 0.0)
+                    V_hat = np.fmax(V_hat + np.ascontiguousarray(W[:, :, t - 1] - W0[:, :, t - 1]) @ Hsh, 0.0)
         W0 = W.copy()                                     # cnmfsc.m:266 (value semantics)
         V_hat = rfd3(W0, H)                               # cnmfsc.m:269
         cost[it] = 0.5 * np.sum((V - V_hat) ** 2)

@@ -15,6 +15,47 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- worst relative errors per test, written to gpurun_out/parity_errors.json at the end of a -m gpu session -----------------
+_ERRORS = {}
+_CURRENT = [None]
+
+
+@pytest.fixture(autouse=True)
+def _track_current_test(request):
+    _CURRENT[0] = request.node.nodeid
+    yield
+    _CURRENT[0] = None
+
+
+def record_err(**vals):
+    """remember max(value) per key for the running test (keys: W, H, WH, cost, ...); also returned for printing"""
+    d = _ERRORS.setdefault(_CURRENT[0] or "?", {})
+    for k, v in vals.items():
+        v = float(v)
+        if not (d.get(k, -1.0) >= v):      # NaN sticks
+            d[k] = v
+    return vals
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _ERRORS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        worst = {}
+        for t, d in _ERRORS.items():
+            for k, v in d.items():
+                if k not in worst or not (worst[k][0] >= v):
+                    worst[k] = (v, t)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(dict(contract=dict(W=1e-5, H=1e-5, WH=1e-5, cost=1e-6), worst={k: dict(value=v, test=t) for k, (v, t) in worst.items()},
+                           tests=_ERRORS), f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def rel_fro(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

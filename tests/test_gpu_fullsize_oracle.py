@@ -1,0 +1,112 @@
+"""-m gpu: the HIP path against the float64 oracle AT BASELINE.json's geometry and at the reference's default iteration count.
+The oracle runs on the GPU box's host cores (minutes in total); every test prints and records its worst relative errors
+(gpurun_out/parity_errors.json).  Contract: <= 1e-5 relative Frobenius on W, H and W*H, cost <= 1e-6 relative, identical
+cost-vector length / line-search try counts.  Inputs are SURVEY 8(d)'s synthetic V, W_init, H_init (conftest.synth)."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import record_err, rel_fro, synth
+
+pytestmark = pytest.mark.gpu
+TOL, CTOL = 1e-5, 1e-6
+
+
+def _report(name, got, ref, t_gpu, t_cpu, wh=True):
+    (W, H, c), (Wr, Hr, cr) = got, ref
+    assert len(c) == len(cr), (len(c), len(cr))
+    e = dict(W=rel_fro(W, Wr), H=rel_fro(H, Hr), cost=rel_fro(c, cr))
+    if wh:
+        if W.ndim == 2:
+            e["WH"] = rel_fro(W @ H, Wr @ Hr)
+        else:
+            from oracle import nmf_oracle as O
+            e["WH"] = rel_fro(O.reconstruct_from_decomposition(W, H), O.reconstruct_from_decomposition(Wr, Hr))
+    record_err(**e)
+    print("\n[%s] rel errors vs float64 oracle: %s   (HIP incl. transfers %.1f s, oracle %.1f s, %d iterations)"
+          % (name, "  ".join("%s %.2e" % kv for kv in sorted(e.items())), t_gpu, t_cpu, len(cr)))
+    assert e["W"] <= TOL and e["H"] <= TOL and e.get("WH", 0.0) <= TOL and e["cost"] <= CTOL, e
+    return e
+
+
+def _both(fn_gpu, fn_ref):
+    t0 = time.time(); got = fn_gpu(); t1 = time.time(); ref = fn_ref(); t2 = time.time()
+    return got, ref, t1 - t0, t2 - t1
+
+
+def test_c2_full_euclidean(gpu_lib):
+    """BASELINE config 2: nmf euclidean, V = 8192 x 32768, K = 128 (fused W step + pipelined GEMM H step, Gram denominators)."""
+    from oracle import nmf_oracle as O
+    m, n, K = 8192, 32768, 128
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
+    _report("C2 8192x32768 K=128 euclidean", got, ref, tg, tc)
+
+
+def test_c3_shard_kl(gpu_lib):
+    """BASELINE config 3, one rank's shard of the 8-GPU run: nmf KL, V = 16384 x 8192, K = 256 (the fused KL kernels)."""
+    from oracle import nmf_oracle as O
+    m, n, K = 16384, 8192, 256
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
+    _report("C3 shard 16384x8192 K=256 kl", got, ref, tg, tc)
+
+
+def test_c3_full_kl(gpu_lib):
+    """BASELINE config 3 in full on one GPU: nmf KL, V = 16384 x 65536, K = 256 -- the bench workload.  The float64 oracle
+    needs ~100 GB of host memory for its m x n temporaries (the GPU box has 3 TB); 2 iterations."""
+    from oracle import nmf_oracle as O
+    m, n, K = 16384, 65536, 256
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
+    _report("C3 16384x65536 K=256 kl", got, ref, tg, tc, wh=False)
+    # W*H on a 2048-column sample (the full product would be another 8 GiB pair)
+    j = np.arange(0, n, 32)
+    e = rel_fro(got[0] @ got[1][:, j], ref[0] @ ref[1][:, j])
+    record_err(WH=e)
+    print("[C3 full] W*H on every 32nd column: %.2e" % e)
+    assert e <= TOL
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+def test_c4_full_cnmf(gpu_lib, div):
+    """BASELINE config 4: cnmf, V = 4096 x 16384, K = 64, T = 8."""
+    from oracle import nmf_oracle as O
+    m, n, K, T = 4096, 16384, 64, 8
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
+    got, ref, tg, tc = _both(lambda: gpu_lib.cnmf(V, K, T, cfg), lambda: O.cnmf(V, K, T, cfg))
+    _report("C4 4096x16384 K=64 T=8 " + div, got, ref, tg, tc)
+
+
+def test_c5_nmfsc(gpu_lib):
+    """BASELINE config 5 geometry at a quarter of the columns: nmfsc, V = 8192 x 8192, K = 128, H_sparsity 0.5; 3 outer iterations
+    (the first line search alone takes ~10 objective evaluations) with IDENTICAL try counts."""
+    from oracle import nmf_oracle as O
+    m, n, K = 8192, 8192, 128
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=3, tolerance=1e-300)
+    i0, i1 = {}, {}
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
+    print("\n[C5] line-search tries H: HIP %s oracle %s" % (i1["triesH"], i0["triesH"]))
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    _report("C5 8192x8192 K=128 nmfsc sH=0.5", got, ref, tg, tc)
+
+
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
+def test_default_100_iterations(gpu_lib, div):
+    """The reference's defaults (nmf.m:404-411): maxiter = 100, tolerance = 1e-3, stop rule active, at 2048 x 8192, K = 128.
+    The cost vectors must have the same length (the rule does not fire before 100 on this data in either implementation)."""
+    from oracle import nmf_oracle as O
+    m, n, K = 2048, 8192, 128
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0)          # no maxiter / tolerance: the defaults
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
+    assert len(ref[2]) == 100
+    _report("100 iterations 2048x8192 K=128 " + div, got, ref, tg, tc)
+    d = -np.diff(ref[2])
+    print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], ref[2][-1]))

@@ -4,7 +4,7 @@ seeded inputs.  Tolerance is the north-star contract: <= 1e-5 relative Frobenius
 import numpy as np
 import pytest
 
-from conftest import rel_fro, synth
+from conftest import record_err, rel_fro, synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -17,6 +17,9 @@ def _check(got, ref, tol=TOL, cost_tol=1e-6, cost_atol=0.0):
     W, W0, H, H0 = cat(W, 1), cat(W0, 1), cat(H, 0), cat(H0, 0)
     assert W.shape == W0.shape and H.shape == H0.shape
     assert len(c) == len(c0), (len(c), len(c0))
+    record_err(W=rel_fro(W, W0), H=rel_fro(H, H0))
+    if np.all(np.isfinite(c0)) and np.linalg.norm(c0) > 0 and cost_atol == 0:
+        record_err(cost=rel_fro(c, c0))
     assert rel_fro(W, W0) <= tol, rel_fro(W, W0)
     assert rel_fro(H, H0) <= tol, rel_fro(H, H0)
     if not np.all(np.isfinite(c0)):
