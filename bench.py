@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- NMF multiplicative-update iterations/s on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|tiny] [--overlap 0|2|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full multiplicative-update iteration (W step, H step, V_hat refresh, cost) on synthetic V
@@ -38,6 +38,7 @@ WORKLOADS = {
     "c3": ("nmf", "kl", 16384, 65536, 256, 1, 8.0),
     "c2": ("nmf", "euclidean", 8192, 32768, 128, 1, 12.0),
     "c4": ("cnmf", "euclidean", 4096, 16384, 64, 8, 12.0),
+    "c5": ("nmfsc", "euclidean", 8192, 32768, 128, 1, 12.0),   # H_sparsity 0.5; F_alg = (5 + tries)*2mnK = 12 mnK at one try per line search
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
     "c3_shard8": ("nmf", "kl", 16384, 8192, 256, 1, 8.0),     # what ONE of 8 ranks holds at c3 (dev aid for the small-kernel overheads)
     "c3_shard4": ("nmf", "kl", 16384, 16384, 256, 1, 8.0),
@@ -80,6 +81,113 @@ def cpu_baseline(alg, div, m, n, K, T, budget_s=40.0):
                        "scaled by %d/%d (cost is linear in n)" % (alg, div, m, ns, ns, n, K, (", T=%d" % T) if T > 1 else "", per_iter, ns, n))
 
 
+def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
+    """BASELINE config 5: nmfsc.m with Hoyer projection on H.  A step = one outer iteration (H line search + W update + cost,
+    nmfsc.m:141-245) on device-resident data; warm-up iterations run first and the timed call RESUMES from their state
+    (same W, H, step sizes), so the timed region is exactly `steps` steady-state outer iterations."""
+    from nmf_toolbox_amd import _lib
+    from nmf_toolbox_amd.engine import nmfsc_sharded, shard_columns
+    import ctypes as C
+    alg, div, m, n, K, T, fmul = WORKLOADS[args.workload]
+    lo, hi = shard_columns(n, world, rank)
+    nl = hi - lo
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    V = torch.rand((nl, m), generator=g, device=dev, dtype=torch.float32)
+    g.manual_seed(1)
+    W = torch.rand((K, m), generator=g, device=dev, dtype=torch.float32)
+    g.manual_seed(2 + rank)
+    H = torch.rand((nl, K), generator=g, device=dev, dtype=torch.float32)
+    lib = _lib.load()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1 or force_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kw = dict(H_sparsity=args.h_sparsity, tolerance=-1.0, path=args.path)
+    c0, info = nmfsc_sharded(V, W, H, maxiter=max(args.warmup, 1), **kw)
+    sync()
+    _lib.check(lib.nmfx_nmfsc_profile(1))
+    t0 = time.perf_counter()
+    c1, info1 = nmfsc_sharded(V, W, H, maxiter=args.steps, resume=info, **kw)
+    sync()
+    dt = time.perf_counter() - t0
+    nt = lib.nmfx_nmfsc_profile_ntags()
+    ms, cnt = (C.c_double * nt)(), (C.c_int32 * nt)()
+    _lib.check(lib.nmfx_nmfsc_profile_read(ms, cnt))
+    names = [lib.nmfx_nmfsc_profile_tag_name(t).decode() for t in range(nt)]
+    _lib.check(lib.nmfx_nmfsc_profile(0))
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1 or force_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        its = args.steps / dt
+        tries = info1["triesH"]
+        f_mnk = 2.0 * m * nl * K
+        work = {names[0]: (f_mnk, 4.0 * (m * nl + m * K + K * nl)),                       # objective pass: S = W*H only
+                names[2]: (f_mnk + 2.0 * K * K * (m + nl), 4.0 * (m * nl + m * K + 3 * K * nl)),
+                names[3]: (f_mnk + 2.0 * K * K * (m + nl), 4.0 * (m * nl + 3 * m * K + K * nl))}
+        phases = {names[t]: round(ms[t] / args.steps, 4) for t in range(nt) if cnt[t] > 0}
+        tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in work}
+        roof = None
+        if tags:
+            name = max(tags, key=lambda k: tags[k][0])
+            avg_ms = tags[name][0] / tags[name][1]
+            ach = work[name][0] / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=name, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        traffic=None, avg_launch_ms=round(avg_ms, 4), launches=int(tags[name][1]), flops_per_launch=work[name][0],
+                        algorithmic_bytes_per_launch=work[name][1], phases_ms_per_step=phases)
+        pj = None
+        if cnt[1] > 0:   # projfunc: HBM-class -- one read of H' and of the step direction, one write, per call (nmfsc.m:154-157)
+            pms = ms[1] / cnt[1]
+            pbytes = 4.0 * 3 * nl * K
+            pj = dict(calls=int(cnt[1]), ms_per_call=round(pms, 4), algorithmic_bytes_per_call=pbytes, achieved_GBps=round(pbytes / (pms * 1e-3) / 1e9, 1),
+                      frac_of_hbm_peak=round(pbytes / (pms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                      note="latency-bound: ~3 dependent block reductions per inner iteration of projfunc.m:28-55, one 1024-thread workgroup per row of H")
+        out = {
+            "metric": "NMF multiplicative-update iterations/s", "value": round(its, 4), "unit": "iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nmfsc.m (Hoyer projection on H, H_sparsity=%g) outer iterations, V=%dx%d K=%d fp32 on %d GPU(s)" % (args.h_sparsity, m, n, K, world),
+                       "name": args.workload, "m": m, "n": n, "K": K, "T": 1, "divergence": "euclidean", "H_sparsity": args.h_sparsity,
+                       "line_search_tries_H": tries, "path": "fused kernels (objective = fused cost pass, Gram-form gradients)"},
+            "effective_tflops": round((5.0 + float(np.mean(tries))) * f_mnk * world * its / 1e12, 3),
+            "cost_first_last": [float(c1[0]), float(c1[-1])], "cost_monotone": bool(np.all(np.diff(c1) <= 0)),
+            "roofline": roof, "projfunc": pj,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_nmfsc(m, n, K, args.h_sparsity)
+            except Exception as ex:
+                out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out), flush=True)
+    if world > 1 or force_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_nmfsc(m, n, K, sH, ns=2048):
+    """float64 restatement of nmfsc.m on the first `ns` columns, outer iterations 3-5 (after the long first line searches), scaled by ns/n"""
+    from oracle import nmf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rs = np.random.RandomState
+    V, W0, H0 = rs(1000).rand(m, ns), rs(1).rand(m, K), rs(2).rand(K, ns)
+    cfg = dict(W_init=W0, H_init=H0, H_sparsity=sH, tolerance=1e-300)
+    t0 = time.perf_counter(); O.nmfsc(V, K, dict(cfg, maxiter=2)); t2 = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.nmfsc(V, K, dict(cfg, maxiter=5)); t5 = time.perf_counter() - t0
+    per = max((t5 - t2) / 3.0, 1e-9)
+    return dict(value=(1.0 / per) * ns / n, unit="iterations/s", cores=int(threads), kind="port",
+                sample="float64 NumPy restatement of nmfsc.m (H_sparsity=%g), V=%dx%d (first %d of %d columns), K=%d: %.3f s per outer iteration (iterations 3-5) "
+                       "on the sample, scaled by %d/%d" % (sH, m, ns, ns, n, K, per, ns, n))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +196,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 generic (materialised V_hat), 2 fused")
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("NMFX_W_CHUNKS", "0") or 0), choices=[0, 1, 2, 4, 8],
+                    help="N > 1: row chunks of the W-step partial whose all-reduces overlap the next chunk's compute (0/1 = one blocking all-reduce)")
+    ap.add_argument("--h-sparsity", type=float, default=0.5, help="c5: Hoyer sparseness target of the rows of H (nmfsc.m:102-110)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +232,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     alg, div, m, n, K, T, fmul = WORKLOADS[args.workload]
+    if alg == "nmfsc":
+        return bench_nmfsc(args, torch, dist, dev, world, rank, force_dist)
     lo, hi = shard_columns(n, world, rank)
     nl = hi - lo
     # synthetic inputs generated in HBM: V = max(U(0,1), eps) per shard (seed 1000+rank), W seed 1, H seed 2+rank
@@ -153,7 +266,8 @@ def main():
             req.wait()
         torch.cuda.synchronize()
         V, H, halo = Vx, Hx, (hL, hR)
-    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo, use_dist=True if force_dist else None)
+    eng = Engine(V, W, H, divergence=div, T=T, algorithm=alg, path=args.path, halo=halo, use_dist=True if force_dist else None,
+                 n_chunks=max(args.overlap, 1))
     eng.init()
     costs = torch.zeros(args.steps + args.warmup + 1, dtype=torch.float64, device=dev)
 
@@ -173,12 +287,40 @@ def main():
     prof = eng.profile_read()
     comm_total_ms, comm_calls = eng.comm_ms()
     eng.profile(False)
+    path_kind, n_chunks_used, packed_bytes = eng.path_kind, eng.n_chunks, int(eng.packed.numel() * 4)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     c = costs[: args.warmup + args.steps].cpu().numpy()
 
+    # N > 1: rank 0 also times the WHOLE problem on its own GPU (no collective) right after the timed region, so the line carries
+    # its own strong-scaling reference; the driver computes efficiency itself from the per-N lines, this is a cross-check
+    single_its = None
+    if world > 1 and rank == 0 and alg == "nmf" and (m * n * 4 + 3 * m * K * 4 * 4 + 3 * n * K * 4) < 40e9:
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            g.manual_seed(1000)
+            Vf = torch.rand((n, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
+            g.manual_seed(1)
+            Wf = torch.rand((K, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
+            g.manual_seed(2)
+            Hf = torch.rand((n, K), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
+            e1 = Engine(Vf, Wf, Hf, divergence=div, path=args.path, use_dist=False)
+            e1.init()
+            cs = torch.zeros(8, dtype=torch.float64, device=dev)
+            e1.iterate(1, cs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e1.iterate(5, cs)
+            torch.cuda.synchronize()
+            single_its = 5.0 / (time.perf_counter() - t1)
+            e1.close()
+            del e1, Vf, Wf, Hf
+            eng = None
+        except Exception:
+            single_its = None
     # RCCL prints its version banner through C stdio, which is flushed only at exit: push every rank's buffered output out
     # now so that rank 0's JSON line is the last thing on stdout
     try:
@@ -208,7 +350,9 @@ def main():
                 except Exception:
                     traffic = None
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=traffic, avg_launch_ms=round(avg_ms, 4), launches=d["launches"], flops_per_launch=d["flops"],
+                        traffic=traffic, traffic_source=("profiles/pmc_traffic.json: HBM bytes per launch from a separate rocprofv3 --pmc pass of the same command "
+                                                         "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run") if traffic is not None else None,
+                        avg_launch_ms=round(avg_ms, 4), launches=d["launches"], flops_per_launch=d["flops"],
                         algorithmic_bytes_per_launch=d["bytes"],
                         phases_ms_per_step={k: round(v["ms_total"] / args.steps, 4) for k, v in prof.items() if v["launches"] > 0})
         out = {
@@ -218,14 +362,27 @@ def main():
             "config": {"workload": "%s.m %s MU, V=%dx%d K=%d%s fp32, V column-sharded over %d GPU(s)" % (alg, div, m, n, K, (" T=%d" % T) if T > 1 else "", world),
                        "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
                        "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
-                                0: "generic GEMM (materialised V_hat)"}[eng.path_kind]},
+                                0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,
         }
+        out["world_size_seen"] = int(dist.get_world_size()) if (world > 1 or force_dist) else 1
+        out["overlap_chunks"] = int(n_chunks_used)
         if comm_calls:   # N > 1: how long the compute stream waited for the packed all-reduce (rank 0), per step
-            out["allreduce_ms_per_step"] = round(comm_total_ms / args.steps, 4)
-            out["allreduce_bytes"] = int(eng.packed.numel() * 4)
+            ar_ms = comm_total_ms / args.steps
+            S = packed_bytes
+            out["allreduce_ms_per_step"] = round(ar_ms, 4)
+            out["allreduce_bytes"] = S
+            p_ = max(world, 1)
+            if ar_ms > 0 and p_ > 1:   # bus bandwidth 2(p-1)/p * S / t against one xGMI link (ring bound) and all seven
+                busbw = 2.0 * (p_ - 1) / p_ * S / (ar_ms * 1e-3) / 1e9
+                out["allreduce_busbw_GBps"] = round(busbw, 2)
+                out["allreduce_busbw_vs_link_153GBps"] = round(busbw / 153.0, 3)
+                out["allreduce_busbw_vs_7links_1071GBps"] = round(busbw / 1071.0, 3)
+        if single_its is not None:
+            out["single_gpu_its_same_run"] = round(single_its, 4)
+            out["strong_scaling_eff"] = round(its / (world * single_its), 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(alg, div, m, n, K, T)

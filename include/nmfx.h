@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NMFX_VERSION 100
+#define NMFX_VERSION 200
 
 typedef enum {
     NMFX_OK = 0,
@@ -80,6 +80,13 @@ typedef struct {
     /* nmfsc only (nmfsc.m:87-110): Hoyer sparseness targets in [0,1]; <= 0 selects the MU branch */
     double sc_W_sparsity, sc_H_sparsity;
     int32_t path;             /* NMFX extension: 0 = auto, 1 = generic kernels only, 2 = require the fused kernels */
+    /* NMFX extensions; all-zero = the reference's behaviour on p->device */
+    double sc_stepsize_H0, sc_stepsize_W0; /* nmfsc / nmfsc_dev: initial line-search step sizes; <= 0 = 1 (nmfsc.m:133-134).  With
+                                              result.stepsize_H / stepsize_W of a previous call this resumes a run exactly */
+    int32_t sc_resume;        /* nmfx_nmfsc_dev only: W / H are the state a previous call left (skip the initial projections, nmfsc.m:94-110) */
+    int32_t n_gpus;           /* nmfx_nmf / nmfx_lnmf: 0 or 1 = one GPU (p->device); N > 1 = V and H column-sharded over N GPUs of this
+                                 process, W replicated, ONE all-reduce of the packed W-step sums per iteration */
+    const int32_t *device_ids;/* [n_gpus] HIP ordinals, or NULL = 0 .. n_gpus-1 */
 } nmfx_problem;
 
 typedef struct {
@@ -131,6 +138,12 @@ typedef enum { NMFX_REDUCE_SUM = 0, NMFX_REDUCE_MAX = 1 } nmfx_reduce_op;
 typedef int32_t (*nmfx_allreduce_fn)(void *ctx, void *dev_ptr, int64_t count, int32_t dtype, int32_t op, void *stream);
 nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,
                            nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r);
+/* Measurement hooks for nmfx_nmfsc / nmfx_nmfsc_dev on the calling thread (bench.py --workload c5): hipEvent pairs around every
+ * launch group on the stream the kernels run on; read total ms / launch count per tag after the call returned. */
+nmfx_status nmfx_nmfsc_profile(int32_t enable);
+int32_t nmfx_nmfsc_profile_ntags(void);
+const char *nmfx_nmfsc_profile_tag_name(int32_t tag);
+nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag);
 /* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
                              const void *H, void *V_hat, int32_t device);
@@ -141,6 +154,11 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
 /* [v,usediters] = projfunc(s, k1, k2, nn) applied to `count` vectors of length N (stride N) -- replaces projfunc.m:1 */
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2,
                           int32_t nn, void *v, int32_t *usediters, int32_t device);
+
+/* the same projection on DEVICE buffers (fp32), asynchronous on `stream`: X (N x count, column-major) receives the projection of
+ * src + mu*dir (src NULL = X itself, dir NULL = no step: the line-search candidates of nmfsc.m:154-157 in one kernel) */
+nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
+                              const float *dir_dev, float mu, int32_t *usediters_dev);
 
 const char *nmfx_last_error(void);
 int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */
@@ -221,6 +239,9 @@ nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev);
 nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0);
 /* algorithm 3 only, before nmfx_engine_init: host segments[0..nz] (see nmfx_constrainednmf) and the DEVICE cluster matrix Z (K x nz) */
 nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *segments_host, int64_t nz, float *Z_dev);
+/* column shards without halos: everything between two all-reduces of `packed` in one call -- wstep_finish, hstep and, unless
+ * `last`, the next iteration's wstep_partial (one host call per iteration next to the collective) */
+nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last);
 /* convenience for one GPU: `iters` full iterations, costs written to the DEVICE array dev_cost_out[iters] (may be NULL) */
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out);
 

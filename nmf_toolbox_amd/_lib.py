@@ -24,6 +24,7 @@ EXPORTS = [
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
+    "nmfx_engine_between_allreduces", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read",
 ]
 
 
@@ -42,6 +43,7 @@ class Problem(C.Structure):
         ("W_fixed", C.c_void_p), ("H_fixed", C.c_void_p),
         ("maxiter", C.c_int32), ("tolerance", C.c_double), ("device", C.c_int32),
         ("sc_W_sparsity", C.c_double), ("sc_H_sparsity", C.c_double), ("path", C.c_int32),
+        ("sc_stepsize_H0", C.c_double), ("sc_stepsize_W0", C.c_double), ("sc_resume", C.c_int32), ("n_gpus", C.c_int32), ("device_ids", C.c_void_p),
     ]
 
 
@@ -86,6 +88,10 @@ def load():
     lib.nmfx_last_error.restype = C.c_char_p
     lib.nmfx_engine_profile_tag_name.restype = C.c_char_p
     lib.nmfx_engine_profile_tag_name.argtypes = [C.c_int32]
+    lib.nmfx_nmfsc_profile_tag_name.restype = C.c_char_p
+    lib.nmfx_nmfsc_profile_tag_name.argtypes = [C.c_int32]
+    lib.nmfx_nmfsc_profile.argtypes = [C.c_int32]
+    lib.nmfx_nmfsc_profile_read.argtypes = [C.c_void_p, C.c_void_p]
     lib.nmfx_engine_destroy.restype = None
     lib.nmfx_engine_destroy.argtypes = [C.c_void_p]
     for name in ("nmfx_nmf", "nmfx_cnmf", "nmfx_lnmf", "nmfx_nmfsc", "nmfx_cnmfsc"):
@@ -96,6 +102,7 @@ def load():
     lib.nmfx_nmfsc_dev.argtypes = [C.POINTER(Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.POINTER(Result)]
     lib.nmfx_reconstruct.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.nmfx_projfunc.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nmfx_projfunc_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.nmfx_engine_workspace_bytes.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_packed_count.argtypes = [C.POINTER(EngineDesc), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_create.argtypes = [C.POINTER(EngineDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -104,6 +111,7 @@ def load():
     lib.nmfx_engine_hstep_finish.argtypes = [C.c_void_p]
     for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass"):
         getattr(lib, name).argtypes = [C.c_void_p]
+    lib.nmfx_engine_between_allreduces.argtypes = [C.c_void_p, C.c_int32]
     lib.nmfx_engine_wstep_partial_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.nmfx_engine_packed_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

@@ -62,6 +62,48 @@ struct ProfEvent {
     int tag;
     hipEvent_t a, b;
 };
+// hipEvent pairs around launch groups, on the stream the kernels run on (bench.py's per-kernel durations)
+struct Profiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    void enable(bool e) { on = e; events.clear(); pool_used = 0; }
+    void release() { for (hipEvent_t ev : pool) (void)hipEventDestroy(ev); pool.clear(); events.clear(); pool_used = 0; }
+    nmfx_status read(int ntags, double *ms_per_tag, int32_t *count_per_tag) const {
+        for (int t = 0; t < ntags; ++t) { ms_per_tag[t] = 0.0; count_per_tag[t] = 0; }
+        for (const ProfEvent &pe : events) {
+            float ms = 0.f;
+            NMFX_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+            if (pe.tag >= 0 && pe.tag < ntags) { ms_per_tag[pe.tag] += ms; count_per_tag[pe.tag] += 1; }
+        }
+        return NMFX_OK;
+    }
+};
+struct PScope {
+    Profiler *p;
+    int idx;
+    PScope(Profiler *p_, int tag) : p(p_), idx(-1) {
+        if (!p || !p->on) return;
+        auto get = [&]() {
+            if (p->pool_used == p->pool.size()) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return (hipEvent_t) nullptr;
+                p->pool.push_back(ev);
+            }
+            return p->pool[p->pool_used++];
+        };
+        ProfEvent pe{tag, get(), get()};
+        if (!pe.a || !pe.b) return;
+        (void)hipEventRecord(pe.a, p->st);
+        p->events.push_back(pe);
+        idx = (int)p->events.size() - 1;
+    }
+    ~PScope() {
+        if (idx >= 0) (void)hipEventRecord(p->events[idx].b, p->st);
+    }
+};
 
 struct nmfx_engine {
     long m, n;                // n = local columns owned by this shard
@@ -100,11 +142,7 @@ struct nmfx_engine {
     float *Z;
     long nz;
     long *seg_dev;            // owned (hipMalloc) -- the only allocation the engine makes itself
-    // profiling
-    bool prof;
-    std::vector<ProfEvent> events;
-    std::vector<hipEvent_t> pool;
-    size_t pool_used;
+    Profiler prof;
 };
 
 enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6,
@@ -116,28 +154,8 @@ static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'"
 
 namespace {
 
-struct Scope {
-    nmfx_engine *e;
-    int idx;
-    Scope(nmfx_engine *e_, int tag) : e(e_), idx(-1) {
-        if (!e->prof) return;
-        auto get = [&]() {
-            if (e->pool_used == e->pool.size()) {
-                hipEvent_t ev;
-                if (hipEventCreate(&ev) != hipSuccess) return (hipEvent_t) nullptr;
-                e->pool.push_back(ev);
-            }
-            return e->pool[e->pool_used++];
-        };
-        ProfEvent pe{tag, get(), get()};
-        if (!pe.a || !pe.b) return;
-        (void)hipEventRecord(pe.a, e->st);
-        e->events.push_back(pe);
-        idx = (int)e->events.size() - 1;
-    }
-    ~Scope() {
-        if (idx >= 0) (void)hipEventRecord(e->events[idx].b, e->st);
-    }
+struct Scope : PScope {
+    Scope(nmfx_engine *e, int tag) : PScope(&e->prof, tag) {}
 };
 
 struct Layout {
@@ -257,6 +275,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->div = d->divergence;
     e->device = d->device;
     e->st = static_cast<hipStream_t>(d->stream);
+    e->prof.st = e->st;
     e->rank0 = 1;
     e->algo = d->algorithm;
     e->alpha = d->divergence == NMFX_DIV_AB ? d->alpha : 1.0;
@@ -533,7 +552,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
 void nmfx_engine_destroy(nmfx_engine *e) {
     if (!e) return;
     if (e->seg_dev) (void)hipFree(e->seg_dev);
-    for (hipEvent_t ev : e->pool) (void)hipEventDestroy(ev);
+    e->prof.release();
     delete e;
 }
 
@@ -845,6 +864,16 @@ nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
     return NMFX_OK;
 }
 
+// the whole stretch between two all-reduces of a column-sharded run as ONE call: replicated W update, local H step, and (unless
+// `last`) the next iteration's W-step partial.  Not for cnmf shards, whose H step is split around the halo exchange.
+nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
+    if (e->hL || e->hR) { set_error("nmfx_engine_between_allreduces: not for shards with halos"); return NMFX_ERR_UNSUPPORTED; }
+    TRY(nmfx_engine_wstep_finish(e));
+    TRY(nmfx_engine_hstep(e));
+    if (!last) TRY(nmfx_engine_wstep_partial(e));
+    return NMFX_OK;
+}
+
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
     for (int it = 0; it < iters; ++it) {
         TRY(nmfx_engine_wstep_partial(e));
@@ -864,23 +893,14 @@ nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_
 
 // ---- profiling: hipEvent pairs around every launch group, on the engine's stream -----------------
 nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable) {
-    e->prof = enable != 0;
-    e->events.clear();
-    e->pool_used = 0;
+    e->prof.enable(enable != 0);
     return NMFX_OK;
 }
 int32_t nmfx_engine_profile_ntags(void) { return TAG_COUNT; }
 const char *nmfx_engine_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < TAG_COUNT) ? kTagNames[tag] : ""; }
 // after the stream is synchronised: total ms and launch count per tag
 nmfx_status nmfx_engine_profile_read(nmfx_engine *e, double *ms_per_tag, int32_t *count_per_tag) {
-    for (int t = 0; t < TAG_COUNT; ++t) { ms_per_tag[t] = 0.0; count_per_tag[t] = 0; }
-    for (const ProfEvent &pe : e->events) {
-        float ms = 0.f;
-        NMFX_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
-        ms_per_tag[pe.tag] += ms;
-        count_per_tag[pe.tag] += 1;
-    }
-    return NMFX_OK;
+    return e->prof.read(TAG_COUNT, ms_per_tag, count_per_tag);
 }
 // algorithmic flops of ONE launch of the GEMM behind `tag` (2*M*N*Kc by formula) and its algorithmic HBM bytes
 nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, double *bytes) {
@@ -1122,6 +1142,12 @@ nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *
     return NMFX_OK;
 }
 
+// nmfsc launch groups (bench.py --workload c5)
+enum ScTag { SC_OBJ = 0, SC_PROJ = 1, SC_HTERMS = 2, SC_WTERMS = 3, SC_SMALL = 4, SC_COUNT = 5 };
+static const char *const kScTagNames[SC_COUNT] = {"fused:objective pass (S=W*H -> 0.5||V-S||^2)", "projfunc (Hoyer projection of the rows of H)",
+                                                  "H-step terms (W'*V, (W'*W)*H)", "W-step terms (V*H', W*(H*H'))", "small kernels (transposes, updates)"};
+static thread_local Profiler g_sc_prof;
+
 // device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
 struct ScDev {
     const float *V;      // m x n_local, already divided by the GLOBAL max (nmfsc.m:62)
@@ -1147,6 +1173,9 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
     TRY(check_device(p->device));
     hipStream_t st = dev ? dev->st : nullptr;
+    g_sc_prof.st = st;
+    if (g_sc_prof.on) { g_sc_prof.events.clear(); g_sc_prof.pool_used = 0; }
+    Profiler *pf = &g_sc_prof;
     const long n_total = dev ? dev->n_total : n;
     double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity;
     double L1a = 0, L1s = 0;
@@ -1197,12 +1226,13 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             TRY(axpy_f32(st, (long)Kn, mu, dirT, baseT, outT));
             return project_H(outT);
         }
-        NMFX_HIP(hipMemcpyAsync(outT, baseT, Kn * 4, hipMemcpyDeviceToDevice, st));
-        return projfunc_cols(st, outT, n, K, L1s, 1.0, 1, nullptr, dirT, mu);   // the step is applied while loading
+        PScope ps(pf, SC_PROJ);
+        return projfunc_cols(st, outT, n, K, L1s, 1.0, 1, nullptr, dirT, mu, baseT);   // the step is applied while loading
     };
     TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
-    if (sW > 0) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
-    if (sH > 0) TRY(project_H(HTd));                                        // nmfsc.m:107-109
+    const bool resume = dev && p->sc_resume;   // W / H are the state a previous call left: already projected, nothing to initialise
+    if (sW > 0 && !resume) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
+    if (sH > 0 && !resume) TRY(project_H(HTd));                                        // nmfsc.m:107-109
 
     // V_hat = Wx * Hx (Hx given transposed, n x K) with the residual objective; returns 0.5*||V - V_hat||^2
     auto recon_obj = [&](const float *Wx, const float *HxT, double *obj) -> nmfx_status {
@@ -1257,7 +1287,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         memset(&f, 0, sizeof(f));
         f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
         f.cost_partials = fparts.as<double>();
-        TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
+        {
+            PScope ps(pf, SC_OBJ);
+            TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
+        }
         return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
     };
     auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
@@ -1268,6 +1301,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
     auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
+        PScope ps(pf, SC_HTERMS);
         static const bool sc_fused_env = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
         const bool sc_fused_terms = sc_fused_env || K % 64 != 0;   // the GEMM is only pipelined for tile-aligned outputs
         if (sc_fused_terms) {
@@ -1288,6 +1322,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx'); N_ has room for K*K more floats: [N | Hx*Hx'] is what column shards sum
     auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
+        PScope ps(pf, SC_WTERMS);
         float *KK = N_ + mK;
         // V*H' (N = K wide): the register-stationary kernel (R = V, two workgroups per CU at K <= 128) beats the split-K GEMM here
         static const bool sc_fused_terms = getenv("NMFX_SC_GEMM_WTERMS") == nullptr;   // dev switch: A/B
@@ -1306,7 +1341,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                        OpView{KK, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
     };
-    double stepH = 1.0, stepW = 1.0;   // nmfsc.m:133-134
+    double stepH = p->sc_stepsize_H0 > 0 ? p->sc_stepsize_H0 : 1.0, stepW = p->sc_stepsize_W0 > 0 ? p->sc_stepsize_W0 : 1.0;   // nmfsc.m:133-134
     if (fast) {
         DevBuf Hcb;
         TRY(Hcb.alloc(Kn * 4));
@@ -1321,15 +1356,21 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             if (!fixH) {
                 TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
                 if (sH > 0) {
-                    TRY(axpy_f32(st, (long)Kn, -1.0f, Gb.as<float>(), Denb.as<float>(), Denb.as<float>()));   // dH = pos - neg   nmfsc.m:148
-                    TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));             // dH' (n x K): rows of H are contiguous there
+                    {
+                        PScope ps(pf, SC_SMALL);
+                        TRY(axpy_f32(st, (long)Kn, -1.0f, Gb.as<float>(), Denb.as<float>(), Denb.as<float>()));   // dH = pos - neg   nmfsc.m:148
+                        TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));         // dH' (n x K): rows of H are contiguous there
+                    }
                     const double begobj = cur_obj;                                              // nmfsc.m:149
                     int tries = 0;
                     double newobj = 0;
                     for (;;) {
                         ++tries;
                         TRY(step_project_H(HTd, G1.as<float>(), (float)(-stepH), HnewT));           // nmfsc.m:154-157
-                        TRY(transpose_f32(st, HnewT, n, K, Hcand));
+                        {
+                            PScope ps(pf, SC_SMALL);
+                            TRY(transpose_f32(st, HnewT, n, K, Hcand));
+                        }
                         TRY(fast_obj(Wd, Hcand, &newobj));                                          // nmfsc.m:160-161
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
                         stepH /= 2;                                                                 // nmfsc.m:169
@@ -1362,8 +1403,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(axpy_f32(st, (long)mK, (float)(-stepW), G2.as<float>(), Wd, Wnew));     // nmfsc.m:205
-                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
+                        {
+                            PScope ps(pf, SC_PROJ);
+                            TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, G2.as<float>(), (float)(-stepW), Wd));   // nmfsc.m:205-208
+                        }
                         TRY(fast_obj(Wnew, Hcur, &newobj));                                         // nmfsc.m:211-212
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
                         stepW /= 2;
@@ -1376,6 +1419,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     std::swap(Wd, Wnew);                                                            // nmfsc.m:229
                     cur_obj = newobj;
                 } else {
+                    PScope ps(pf, SC_SMALL);
                     TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
                     cur_obj = NAN;
                 }
@@ -1740,6 +1784,21 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
     if (order_out) for (int k = 0; k < K; ++k) order_out[k] = order[k];
     return NMFX_OK;
 }
+
+nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
+                              const float *dir_dev, float mu, int32_t *usediters_dev) {
+    if (N <= 0 || count <= 0 || !X_dev) { set_error("nmfx_projfunc_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    return projfunc_cols(static_cast<hipStream_t>(stream), X_dev, N, count, k1, k2, nn, usediters_dev, dir_dev, mu, src_dev);
+}
+
+nmfx_status nmfx_nmfsc_profile(int32_t enable) {
+    g_sc_prof.enable(enable != 0);
+    if (!enable) g_sc_prof.release();
+    return NMFX_OK;
+}
+int32_t nmfx_nmfsc_profile_ntags(void) { return SC_COUNT; }
+const char *nmfx_nmfsc_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < SC_COUNT) ? kScTagNames[tag] : ""; }
+nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag) { return g_sc_prof.read(SC_COUNT, ms_per_tag, count_per_tag); }
 
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,
                           int32_t *usediters, int32_t device) {

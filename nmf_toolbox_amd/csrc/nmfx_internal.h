@@ -177,9 +177,10 @@ nmfx_status cvt_to_f32(hipStream_t st, const void *in, int dtype, float *out, lo
 nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count);
 
 // ---- Hoyer projection (projfunc.hip): vectors are the COLUMNS of X (len x count), in place ----
-// dir != nullptr: the vectors projected are X + mu*dir (the line-search step of nmfsc.m:154 / 205 fused into the load); X receives the result
+// dir != nullptr: the vectors projected are src + mu*dir (the line-search step of nmfsc.m:154 / 205 fused into the load); src == nullptr
+// means X itself.  X receives the result.
 nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev,
-                          const float *dir = nullptr, float mu = 0.0f);
+                          const float *dir = nullptr, float mu = 0.0f, const float *src = nullptr);
 nmfx_status projfunc_cols_f64(hipStream_t st, double *X, long len, int count, double k1, double k2, int nn, int *usediters_dev);
 // the same projection when every vector is split over the ranks of `comm` (len = local part, N_total = whole length);
 // v_scratch: len*count doubles, flags: len*count bytes, red: 6*count doubles

@@ -12,7 +12,10 @@ namespace nmfx {
 
 constexpr int PF_THREADS = 1024;
 constexpr int PF_WAVES = PF_THREADS / 64;
-constexpr int PF_MAX_ITERS = 100000;  // safety cap: the reference loops forever on NaN input
+constexpr int PF_MAX_ITERS = 100000;
+#ifndef PF_GROUP
+#define PF_GROUP 4
+#endif  // safety cap: the reference loops forever on NaN input
 
 struct Red4 { double a, b, c, d; };
 
@@ -34,44 +37,116 @@ __device__ __forceinline__ Red4 block_red4(Red4 v, double *red) {
     return r;
 }
 
-// Working vector: element e of thread tid is x[tid + e*1024].  The first ER elements per thread live in registers (fp64, 2 VGPRs
-// each), the next EL in LDS (fp64, [e][tid]: conflict-free b64 accesses) -- 16 + 16 covers len <= 32768 (a row of H at BASELINE
-// config 5) with 128 KiB of LDS and no scratch spills (the all-register variant needed 64 + temporaries > 128 VGPRs at 1024 threads
-// and spilled 212 of them).  TIO = float (engine buffers) or double (nmfx_projfunc on float64 input: no fp32 rounding anywhere).
+// ---- block reduction of four fp64 sums without LDS shuffles -----------------------------------------------------------------
+// A projection needs two or three dependent block reductions per inner iteration (projfunc.m:34-36, 40, 51), so their latency, not
+// HBM, bounds the kernel.  The round-1 version (ds_bpermute butterflies + every thread re-reading all WAVES*4 partials from LDS)
+// cost ~3.7 us per reduction with 16 waves; this one keeps the intra-wave part in the VALU (DPP row operations on the two halves
+// of each double) and reads one partial per lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {   // lanes without a source lane, and rows outside ROW_MASK, receive 0
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {   // sum over the 64 lanes, returned wave-uniform
+    v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]      -> every lane: sum of its quad
+    v += dpp_f64<0x141, 0xf>(v);   // row_half_mirror          -> sum of its 8 lanes
+    v += dpp_f64<0x140, 0xf>(v);   // row_mirror               -> sum of its row of 16
+    v += dpp_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3: rows 0+1 | rows 2+3
+    v += dpp_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3: row 3 holds the wave total
+    return readlane_f64(v, 63);
+}
+
+template <int WAVES>
+__device__ __forceinline__ Red4 block_red4_w(Red4 v, double *red) {
+    static_assert(WAVES * 4 <= 64 && (WAVES & (WAVES - 1)) == 0, "one partial per lane");
+    const double a = wave_sum_f64(v.a), b = wave_sum_f64(v.b), c = wave_sum_f64(v.c), d = wave_sum_f64(v.d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                            // the previous reduction's readers are done with red[]
+    if (lane == 0) { red[wave * 4 + 0] = a; red[wave * 4 + 1] = b; red[wave * 4 + 2] = c; red[wave * 4 + 3] = d; }
+    __syncthreads();
+    // lane l holds partial (wave l/4, sum l%4); add the lanes that share l%4: strides 4, 8 inside a row, then rows
+    double t = lane < WAVES * 4 ? red[lane] : 0.0;
+    t += dpp_f64<0x114, 0xf>(t);   // row_shr:4
+    t += dpp_f64<0x118, 0xf>(t);   // row_shr:8               -> lanes 12..15 of a row: the row's four sums
+    if (WAVES > 4) t += __shfl_xor(t, 16);                      // rows pair up (plain permutes: one value, two steps at most)
+    if (WAVES > 8) t += __shfl_xor(t, 32);
+    Red4 r;
+    r.a = readlane_f64(t, 12); r.b = readlane_f64(t, 13); r.c = readlane_f64(t, 14); r.d = readlane_f64(t, 15);
+    return r;
+}
+
+// Working vector: element e of thread tid is x[tid + e*THREADS].  The first ER elements per thread live in registers (fp64, 2 VGPRs
+// each), the next EL in LDS (fp64, [e][tid]: conflict-free b64 accesses).  <1024, 16, 0> covers len <= 16384 inside the 128-VGPR budget
+// of a 1024-thread block; <512, 64, 0> covers len <= 32768 (a row of H at BASELINE config 5) inside the 256-VGPR budget of a
+// 512-thread block -- the round-1 <1024 threads, 32 elements> variant spilled 212 VGPRs to scratch there.
+// TIO = float (engine buffers) or double (nmfx_projfunc on float64 input: no fp32 rounding anywhere).
 // dir != nullptr fuses the line-search step into the load: s = x + mu*dir (fp32, as the separate axpy kernel computed it; nmfsc.m:154).
-template <int ER, int EL, typename TIO>
-__global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, float mu) {
-    __shared__ double red[PF_WAVES * 4];
-    extern __shared__ __attribute__((aligned(16))) double vl[];   // [EL][PF_THREADS]
+// Two block reductions per inner iteration instead of the three a literal transcription needs: the pass that applies
+// v = alpha*w + v (projfunc.m:38) also gathers what lines 49-51 would need if the loop goes on -- |{v <= 0}| and the sum of the
+// entries that survive the zeroing (the zeros add exactly 0.0) -- and the zeroing + redistribution of lines 50-53 is applied
+// element-wise at the top of the next sweep.
+template <int THREADS, int ER, int EL, typename TIO>
+__global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, float mu, const TIO *src) {
+    constexpr int WAVES = THREADS / 64;
+    __shared__ double red[WAVES * 4];
+    extern __shared__ __attribute__((aligned(16))) double vl[];   // [EL][THREADS]
     constexpr int EPT = ER + EL;
-    static_assert(EPT <= 64, "one mask bit per element");
-    TIO *x = X + len * blockIdx.x;
-    const float *dx = dir ? dir + len * blockIdx.x : nullptr;
+    // raw buffer accesses: one 32-bit lane offset + an immediate per element (no 64-bit address pair per element and pointer, which
+    // is what pushed the unrolled loads over the register budget), and the hardware bounds check stands in for the tail predicate:
+    // loads past the end of the vector return 0, stores there are dropped
+    const unsigned vbytes = (unsigned)(len * (long)sizeof(TIO));
+    const __amdgpu_buffer_rsrc_t xo_srd = __builtin_amdgcn_make_buffer_rsrc((void *)(X + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xi_srd = __builtin_amdgcn_make_buffer_rsrc((void *)((src ? src : X) + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_srd = __builtin_amdgcn_make_buffer_rsrc((void *)(dir ? dir + len * blockIdx.x : (const float *)X), 0, dir ? (int)(unsigned)(len * 4) : 0, 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t srd, int e) -> double {
+        const int voff = (int)(threadIdx.x * sizeof(TIO)), ioff = e * THREADS * (int)sizeof(TIO);
+        if (sizeof(TIO) == 4) return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, ioff, 0));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(srd, voff, ioff, 0));
+    };
     const int tid = threadIdx.x;
     const double N = (double)len;
+    // element e of this thread exists iff e < nfull, or e == nfull and tid < rem (wave-uniform tests except the last)
+    const int nfull = (int)(len / THREADS), rem = (int)(len - (long)nfull * THREADS);
+    auto valid = [&](int e) -> bool { return e < nfull || (e == nfull && tid < rem); };
     double vr[ER > 0 ? ER : 1];
-    unsigned long long zmask = 0ull, negmask = 0ull;
-    auto get = [&](int e) -> double { return e < ER ? vr[e < ER ? e : 0] : vl[(e - ER) * PF_THREADS + tid]; };
-    auto put = [&](int e, double val) { if (e < ER) vr[e < ER ? e : 0] = val; else vl[(e - ER) * PF_THREADS + tid] = val; };
+    unsigned zm[(EPT + 31) / 32], ngm[(EPT + 31) / 32];           // Z membership / original sign, one bit per element
+#pragma unroll
+    for (int q = 0; q < (EPT + 31) / 32; ++q) zm[q] = ngm[q] = 0u;
+    auto get = [&](int e) -> double { return e < ER ? vr[e < ER ? e : 0] : vl[(e - ER) * THREADS + tid]; };
+    auto put = [&](int e, double val) { if (e < ER) vr[e < ER ? e : 0] = val; else vl[(e - ER) * THREADS + tid] = val; };
 
+    // Everything below is branch-free per element (selects, not ifs): with divergent control flow around each element hipcc emits
+    // one exec-masked block per element and the 64 dependent chains of a thread run one after the other (measured: 280 cycles per
+    // element and sweep); as straight-line code they interleave.  Slots past the end of the vector are permanent members of Z with
+    // value 0: they add exact zeros to every sum and are taken out of the |Z| count (n_pad).
+    const double n_pad = (double)((long)THREADS * EPT - len);
     Red4 r = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const long i = tid + (long)e * PF_THREADS;
-        double s = 0.0;
-        if (i < len) {
-            if (sizeof(TIO) == 4 && dx) s = (double)((float)x[i] + mu * dx[i]);
-            else s = (double)x[i];
-            if (!nn) { if (s < 0) negmask |= 1ull << e; s = fabs(s); }   // projfunc.m:16-19
+        const bool ok = valid(e);
+        double s = ld(xi_srd, e);
+        if (sizeof(TIO) == 4 && dir) {                                     // uniform branch
+            const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dx_srd, (int)(threadIdx.x * 4), e * THREADS * 4, 0));
+            s = (double)((float)s + mu * d);
         }
+        const bool neg = !nn && s < 0;                                     // projfunc.m:16-19
+        ngm[e >> 5] |= neg ? (1u << (e & 31)) : 0u;
+        zm[e >> 5] |= ok ? 0u : (1u << (e & 31));
+        s = nn ? s : fabs(s);
         put(e, s);
         r.a += s;
+        if ((e & (PF_GROUP - 1)) == PF_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
-    r = block_red4(r, red);
-    const double shift0 = (k1 - r.a) / N;                                  // projfunc.m:22
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) put(e, get(e) + shift0);
-
+    r = block_red4_w<WAVES>(r, red);
+    double shift = (k1 - r.a) / N;                                         // projfunc.m:22
+    bool zero_first = false;                                               // the pending element-wise step: v += shift off Z (first: everywhere)
     double nz = 0.0;
     int j = 0;
     for (;;) {
@@ -79,70 +154,64 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_kernel(TIO *X, long len, 
         r.a = r.b = r.c = r.d = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const long i = tid + (long)e * PF_THREADS;
-            if (i < len) {
-                const double ve = get(e);
-                const double w = ve - (((zmask >> e) & 1ull) ? 0.0 : mid); // projfunc.m:33
-                r.a += w * w;                                              // projfunc.m:34
-                r.b += w * ve;                                             // projfunc.m:35
-                r.c += ve * ve;                                            // projfunc.m:36
-            }
+            const unsigned bit = 1u << (e & 31);
+            double ve = get(e);
+            const bool z = zero_first ? (ve <= 0.0) : ((zm[e >> 5] & bit) != 0u);   // projfunc.m:49 (first sweep: only the padding)
+            ve = z ? 0.0 : ve + shift;                                     // projfunc.m:50, 53 | 22, 52   (padding and old zeros are 0 already)
+            zm[e >> 5] = (zm[e >> 5] & ~bit) | (z ? bit : 0u);
+            put(e, ve);
+            const double w = ve - (z ? 0.0 : mid);                         // projfunc.m:33
+            r.a += w * w;                                                  // projfunc.m:34
+            r.b += w * ve;                                                 // projfunc.m:35
+            r.c += ve * ve;                                                // projfunc.m:36
+            if ((e & (PF_GROUP - 1)) == PF_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // interleave PF_GROUP chains, not all EPT: bounds the live ranges
         }
-        r = block_red4(r, red);
+        r = block_red4_w<WAVES>(r, red);
         const double a = r.a, b = 2.0 * r.b, c = r.c - k2;
         const double disc = b * b - 4.0 * a * c;
         const double alphap = (-b + (disc > 0.0 ? sqrt(disc) : 0.0)) / (2.0 * a);   // projfunc.m:37 real(sqrt(.))
         r.a = r.b = r.c = r.d = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const long i = tid + (long)e * PF_THREADS;
-            if (i < len) {
-                const double ve = get(e);
-                const double w = ve - (((zmask >> e) & 1ull) ? 0.0 : mid);
-                const double vn = alphap * w + ve;                         // projfunc.m:38
-                put(e, vn);
-                if (!(vn >= 0.0)) r.a += 1.0;                              // projfunc.m:40 all(v>=0)
-            }
+            const double ve = get(e);
+            const double w = ve - ((zm[e >> 5] & (1u << (e & 31))) ? 0.0 : mid);
+            const double vn = alphap * w + ve;                             // projfunc.m:38
+            put(e, vn);
+            r.a += (vn >= 0.0) ? 0.0 : 1.0;                                // projfunc.m:40 all(v>=0)  (NaN counts as a failure)
+            r.b += (vn <= 0.0) ? 1.0 : 0.0;                                // |Z| of projfunc.m:49, should the loop go on
+            r.c += (vn <= 0.0) ? 0.0 : vn;                                 // sum(v) after v(Z) = 0, projfunc.m:51
+            if ((e & (PF_GROUP - 1)) == PF_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
-        r = block_red4(r, red);
+        r = block_red4_w<WAVES>(r, red);
         if (r.a == 0.0 || j >= PF_MAX_ITERS) break;                        // projfunc.m:40-44
         ++j;                                                               // projfunc.m:46
-        zmask = 0ull;
-        r.a = r.b = r.c = r.d = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const long i = tid + (long)e * PF_THREADS;
-            if (i < len) {
-                double ve = get(e);
-                if (ve <= 0.0) { zmask |= 1ull << e; ve = 0.0; put(e, 0.0); r.b += 1.0; }   // projfunc.m:49-50
-                r.a += ve;                                                              // projfunc.m:51
-            }
-        }
-        r = block_red4(r, red);
-        nz = r.b;
-        const double shift = (k1 - r.a) / (N - nz);                        // projfunc.m:52
-#pragma unroll
-        for (int e = 0; e < EPT; ++e)
-            if (!((zmask >> e) & 1ull)) put(e, get(e) + shift);            // projfunc.m:52-53
+        nz = r.b - n_pad;
+        shift = (k1 - r.c) / (N - nz);                                     // projfunc.m:52
+        zero_first = true;
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const long i = tid + (long)e * PF_THREADS;
-        if (i < len) x[i] = (TIO)(((negmask >> e) & 1ull) ? -get(e) : get(e));         // projfunc.m:58-60
+        const double o = (ngm[e >> 5] & (1u << (e & 31))) ? -get(e) : get(e);             // projfunc.m:58-60
+        const int voff = (int)(threadIdx.x * sizeof(TIO)), ioff = e * THREADS * (int)sizeof(TIO);
+        if (sizeof(TIO) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)o), xo_srd, voff, ioff, 0);
+        else {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), xo_srd, voff, ioff, 0);
+        }
     }
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
 }
 
-template <int ER, int EL, typename TIO>
-static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, float mu) {
-    auto kern = projfunc_kernel<ER, EL, TIO>;
-    const size_t ldsb = sizeof(double) * EL * PF_THREADS;
+template <int THREADS, int ER, int EL, typename TIO>
+static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, float mu, const TIO *src) {
+    auto kern = projfunc_kernel<THREADS, ER, EL, TIO>;
+    const size_t ldsb = sizeof(double) * EL * THREADS;
     static bool attr_done = false;
     if (ldsb > 48 * 1024 && !attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(count), dim3(PF_THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu, src);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -338,15 +407,19 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
 }
 
 template <typename TIO>
-static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu) {
+static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu,
+                                   const TIO *src) {
     if (count <= 0 || len <= 0) return NMFX_OK;
-    // elements per thread: registers first (<= 16 doubles: no spills under the 128-VGPR budget of a 1024-thread block), then LDS
-    if (len <= 4L * PF_THREADS) return launch_pf<4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
-    if (len <= 8L * PF_THREADS) return launch_pf<8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
-    if (len <= 16L * PF_THREADS) return launch_pf<16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
-    if (len <= 24L * PF_THREADS) return launch_pf<16, 8, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
-    if (len <= 32L * PF_THREADS) return launch_pf<16, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+    // elements per thread: registers first, then LDS (see projfunc_kernel)
+    if (len <= 1024L) return launch_pf<256, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 4096L) return launch_pf<1024, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 8192L) return launch_pf<1024, 8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 16384L) return launch_pf<1024, 16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 24576L) return launch_pf<512, 48, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 32768L) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 40960L) return launch_pf<512, 48, 32, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
     // longer than registers + LDS hold: global fp64 working rows (allocated per call; this is the rare path)
+    if (src && src != X) NMFX_HIP(hipMemcpyAsync(X, src, sizeof(TIO) * (size_t)len * count, hipMemcpyDeviceToDevice, st));
     double *scratch = nullptr;
     unsigned char *flags = nullptr;
     NMFX_HIP(hipMalloc(&scratch, sizeof(double) * (size_t)len * count));
@@ -360,11 +433,12 @@ static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, 
     return NMFX_OK;
 }
 
-nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu) {
-    return projfunc_cols_t<float>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu);
+nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu,
+                          const float *src) {
+    return projfunc_cols_t<float>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
 }
 nmfx_status projfunc_cols_f64(hipStream_t st, double *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
-    return projfunc_cols_t<double>(st, X, len, count, k1, k2, nn, usediters_dev, nullptr, 0.0f);
+    return projfunc_cols_t<double>(st, X, len, count, k1, k2, nn, usediters_dev, nullptr, 0.0f, nullptr);
 }
 
 }  // namespace nmfx

@@ -60,7 +60,26 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
         backend._copy_cost(cost_out[idx:idx + 1])
 
     nch = int(getattr(backend, "n_chunks", 1))
+    merged = nch == 1 and hasattr(backend, "between_allreduces") and not getattr(backend, "has_halos", False)
     for it in range(iters):
+        if merged:
+            # one host call per iteration next to the collective: [wstep_finish, hstep, next wstep_partial] is a single C entry point
+            if it == 0:
+                backend.wstep_partial()
+            if lag and it > 0 and cost_out is not None:
+                emit(it - 1)
+            ev = getattr(backend, "comm_events", None)
+            if ev is not None:
+                a, b = backend.torch.cuda.Event(enable_timing=True), backend.torch.cuda.Event(enable_timing=True)
+                a.record()
+            dist.all_reduce(backend.packed, group=group)      # the ONE exchange step of an iteration
+            if ev is not None:
+                b.record()
+                ev.append((a, b))
+            backend.between_allreduces(it == iters - 1)
+            if not lag and cost_out is not None:
+                emit(it)
+            continue
         if nch > 1:
             # row-chunked W step: the all-reduce of chunk c (async, on the collective's own stream) overlaps the compute of
             # chunk c+1; the lagged cost is complete after the last chunk
@@ -194,6 +213,9 @@ class Engine:
     def hstep_finish(self):
         _lib.check(self.lib.nmfx_engine_hstep_finish(self.h))
 
+    def between_allreduces(self, last):
+        _lib.check(self.lib.nmfx_engine_between_allreduces(self.h, 1 if last else 0))
+
     def cost_pass(self):
         _lib.check(self.lib.nmfx_engine_cost_pass(self.h))
 
@@ -277,14 +299,16 @@ class _DevPtr:
 
 
 def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed=False, H_fixed=False, maxiter=100, tolerance=1e-3,
-                  group=None, path=0, allreduce=None):
+                  group=None, path=0, allreduce=None, resume=None):
     """nmfsc.m:57-245 with V / H column-sharded over the ranks of `group` and W replicated.
 
     V: (n_local, m) fp32 CUDA tensor (= column-major m x n_local), W: (K, m), H: (n_local, K); W and H are updated in place
     (W ends identical on every rank).  Every cross-rank sum is requested by libnmfx through a callback and served here by
     torch.distributed (RCCL with the nccl backend): one [V*H' | H*H'] all-reduce per outer iteration, 8 bytes per objective
     evaluation, 4*K doubles per projfunc reduction.  `allreduce(tensor, op)` replaces torch.distributed (tests).
-    Returns (cost ndarray, info dict).  tolerance < 0 disables the stop rule."""
+    Returns (cost ndarray, info dict).  tolerance < 0 disables the stop rule.
+    resume = the info dict of a previous call on the same buffers: V is taken as already rescaled (info["Vs"]), W / H as that
+    call's final state and the line searches continue from its step sizes -- two calls of a + b iterations equal one of a + b."""
     import torch
     dist = torch.distributed
     lib = _lib.load()
@@ -301,14 +325,17 @@ def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed
 
         def allreduce(t, op):
             dist.all_reduce(t, op=ops[op], group=group)
-    # nmfsc.m:57-62: data must be non-negative; V = V / max(V(:)) with the GLOBAL max
-    mm = torch.stack([V.max(), -V.min()]).double()
-    if allreduce is not None:
-        allreduce(mm, _lib.REDUCE_MAX)
-    vmax, vmin = float(mm[0]), -float(mm[1])
-    if vmin < 0:
-        raise ValueError("Negative values in data!")
-    Vs = V / vmax
+    if resume is not None:
+        Vs, vmax = resume["Vs"], resume["vmax"]
+    else:
+        # nmfsc.m:57-62: data must be non-negative; V = V / max(V(:)) with the GLOBAL max
+        mm = torch.stack([V.max(), -V.min()]).double()
+        if allreduce is not None:
+            allreduce(mm, _lib.REDUCE_MAX)
+        vmax, vmin = float(mm[0]), -float(mm[1])
+        if vmin < 0:
+            raise ValueError("Negative values in data!")
+        Vs = V / vmax
     nt = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
     if allreduce is not None:
         allreduce(nt, _lib.REDUCE_SUM)
@@ -338,6 +365,8 @@ def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed
     p.maxiter, p.tolerance = int(maxiter), float(tolerance)
     p.device = dev.index or 0
     p.sc_W_sparsity, p.sc_H_sparsity, p.path = float(W_sparsity), float(H_sparsity), int(path)
+    if resume is not None:
+        p.sc_resume, p.sc_stepsize_H0, p.sc_stepsize_W0 = 1, float(resume["stepsizeH"]), float(resume["stepsizeW"])
     r = _lib.Result()
     r.cost, r.tries_H, r.tries_W = cost.ctypes.data_as(C.c_void_p), tH.ctypes.data_as(C.c_void_p), tW.ctypes.data_as(C.c_void_p)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -346,5 +375,5 @@ def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed
         raise errors[0]
     _lib.check(rc)
     info = dict(triesH=[int(t) for t in tH if t > 0], triesW=[int(t) for t in tW if t > 0], stepsizeH=r.stepsize_H, stepsizeW=r.stepsize_W,
-                converged_early=bool(r.converged_early), vmax=vmax)
+                converged_early=bool(r.converged_early), vmax=vmax, Vs=Vs)
     return cost[: r.cost_len].copy(), info

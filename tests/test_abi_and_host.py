@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(set(L.EXPORTS)) == declared          # the Python binding list tracks the header
-    assert lib.nmfx_version() == 100
+    assert lib.nmfx_version() == 200
 
 
 def test_struct_layouts_match_header():

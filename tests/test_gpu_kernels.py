@@ -75,29 +75,37 @@ def test_gemm_prologue_and_accumulate(gpu_lib, pro):
     assert rel_fro(got, A @ g) < 2e-6
 
 
-@pytest.mark.parametrize("N,count,sparse", [(200, 3, 0.6), (1024, 8, 0.5), (4096, 4, 0.8), (5000, 2, 0.3), (32768, 2, 0.5), (40000, 1, 0.5), (70000, 2, 0.7), (200001, 1, 0.4)])
-def test_projfunc(gpu_lib, N, count, sparse):
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N,count,sparse", [(200, 3, 0.6), (1024, 8, 0.5), (1025, 2, 0.5), (4096, 4, 0.8), (5000, 2, 0.3), (16384, 3, 0.5), (16385, 2, 0.6),
+                                            (24576, 2, 0.4), (32768, 2, 0.5), (32769, 1, 0.5), (40000, 1, 0.5), (70000, 2, 0.7), (200001, 1, 0.4)])
+def test_projfunc(gpu_lib, N, count, sparse, dtype):
+    """every storage variant of the kernel (registers / registers + LDS / global scratch) against the float64 oracle: identical
+    iteration counts and zero sets; float64 input is projected in float64 end to end, float32 input is its exact widening"""
     from oracle import nmf_oracle as O
     import ctypes as C
     from nmf_toolbox_amd import _lib
     lib = _lib.load()
     rs = np.random.RandomState(N + count)
     S = np.abs(rs.randn(count, N))
+    if dtype == "f32":
+        S = S.astype(np.float32)
     k1 = np.sqrt(N) - (np.sqrt(N) - 1) * sparse
     out = np.zeros_like(S)
     its = np.zeros(count, dtype=np.int32)
-    _lib.check(lib.nmfx_projfunc(N, count, _lib.F64, S.ctypes.data_as(C.c_void_p), k1, 1.0, 1, out.ctypes.data_as(C.c_void_p), its.ctypes.data_as(C.c_void_p), 0))
+    _lib.check(lib.nmfx_projfunc(N, count, _lib.F64 if dtype == "f64" else _lib.F32, S.ctypes.data_as(C.c_void_p), k1, 1.0, 1,
+                                 out.ctypes.data_as(C.c_void_p), its.ctypes.data_as(C.c_void_p), 0))
+    tol = 1e-12 if dtype == "f64" else 1e-6
     for c in range(count):
-        v, it = O.projfunc(S[c].astype(np.float32).astype(np.float64), k1, 1.0, True)
+        v, it = O.projfunc(S[c].astype(np.float64), k1, 1.0, True)
         assert it == its[c]
-        assert rel_fro(out[c], v) < 1e-6
-        assert abs(out[c].sum() - k1) < 1e-4 * k1 and abs((out[c] ** 2).sum() - 1.0) < 1e-5 and out[c].min() >= 0
+        assert rel_fro(out[c], v) < tol
+        assert abs(out[c].sum(dtype=np.float64) - k1) < 1e-4 * k1 and abs((out[c].astype(np.float64) ** 2).sum() - 1.0) < 1e-5 and out[c].min() >= 0
         assert np.array_equal(out[c] == 0, v == 0)   # identical zero set (discrete branch)
 
 
 def test_projfunc_signed(gpu_lib):
     from oracle import nmf_oracle as O
-    v, it = gpu_lib.projfunc(np.random.RandomState(5).randn(300), 6.0, 1.0, False)
-    s = np.random.RandomState(5).randn(300).astype(np.float32).astype(np.float64)
+    s = np.random.RandomState(5).randn(300)
+    v, it = gpu_lib.projfunc(s, 6.0, 1.0, False)
     v0, it0 = O.projfunc(s, 6.0, 1.0, False)
-    assert it == it0 and rel_fro(v, v0) < 1e-6
+    assert it == it0 and rel_fro(v, v0) < 1e-12
