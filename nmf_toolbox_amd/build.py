@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libnmfx.so")
-SOURCES = ["gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
+SOURCES = ["fused_cnmf_a.hip", "fused_cnmf_b.hip", "fused_cnmf_c.hip", "gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "api.hip"]
 ARCH = "gfx950"
 
 
@@ -54,6 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer([src] + hdrs, obj):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed",
                    "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            if os.path.basename(src).startswith("fused_cnmf"):
+                # K = Kh*T = 512 bodies hold 512 MFMAs per tile: past clang's default budget for `#pragma unroll`, and a partially
+                # unrolled loop indexes the accumulator arrays dynamically (scratch)
+                cmd[3:3] = ["-mllvm", "-pragma-unroll-threshold=1000000"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -132,6 +132,13 @@ struct nmfx_engine {
     bool fused, cost_valid, defer_hfinish;
     bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
     float *CC;                // KT x KT Gram of the stacked W (gram path)
+    // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
+    // H-step numerator as ONE (KT x n x m) GEMM Q = W_flat' * V followed by the shift-sum over t
+    bool fusedT, hpad_valid;
+    bool qgemm;               // cnmf, T > 1: H-step numerator sum_t W_t' * lshift_t(A) as ONE (KT x n x m) GEMM Q = W_flat' * A + a shift-sum over t
+    float *Hpad, *Qbuf, *slabsT;
+    int nsplit_T;
+    long cps_T;
     int nsplit_w, isplit_h;
     long cps_w, cps_h;        // streamed extent per split (multiples of 64; the last split may be shorter)
     int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
@@ -176,8 +183,10 @@ Layout layout(nmfx_engine *e, void *ws) {
     size_t gs = gemm_scratch_bytes(e->m, e->KT, e->n);
     size_t gs2 = gemm_scratch_bytes(e->K, e->n, (long)e->T * e->m);
     size_t gs3 = gemm_scratch_bytes(e->m, e->n + e->hR, e->KT);
+    size_t gs4 = e->qgemm ? gemm_scratch_bytes(e->KT, e->n + e->hR, e->m) : 0;
     if (gs2 > gs) gs = gs2;
     if (gs3 > gs) gs = gs3;
+    if (gs4 > gs) gs = gs4;
     e->gemm_scratch_bytes = gs;
     e->gemm_scratch = gs ? c.take<float>(gs / sizeof(float)) : nullptr;
     e->lamW = c.take<float>(e->K);
@@ -232,7 +241,14 @@ Layout layout(nmfx_engine *e, void *ws) {
         size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
         size_t gg = std::max(std::max(g4, g5), sizeof(float) * Kn * e->T);   // + T slabs of the z-batched H-step denominator
         if (gg > e->gemm_scratch_bytes) { e->gemm_scratch_bytes = gg; e->gemm_scratch = c.take<float>(gg / sizeof(float)); }
+        if (e->fusedT) {
+            e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+            e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
+            const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+            if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        }
     }
+    if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
     L.total = c.off;
     L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
     return L;
@@ -304,6 +320,15 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     e->fused = eligible && d->path != 1;
     e->gram = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
+    static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
+    e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
+    if (d->path == 2 && e->algo == 1 && !e->fusedT) {
+        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean, T > 1, an instantiated (K, T) pair)");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (e->fusedT) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
+    e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
         e->nsplit_w = fused_split((e->m + 127) / 128, e->n, e->K, &e->cps_w);
@@ -479,6 +504,39 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
     return fused_wpass_finish(e);
 }
 
+// cnmf fused passes (fused_kernel TT > 1) over the local columns: do_g2 -> N_all = V * H_stack' into `out` (m x KT), else the residual cost
+// partials of the CURRENT (W, H).  H's T-1 columns to the left of the shard are its halo, or zeros (Hpad) on the first / only shard.
+nmfx_status fusedT_pass(nmfx_engine *e, bool do_g2, float *out) {
+    const float *Hy = e->H;
+    if (e->hL < e->T - 1) {
+        if (!e->hpad_valid) {   // H changed since the last pass (init, H step)
+            Scope s(e, TAG_SMALL);
+            TRY(pad_left(e->st, e->H, e->K, e->n, e->T - 1, e->Hpad));
+            e->hpad_valid = true;
+        }
+        Hy = e->Hpad + (size_t)e->K * (e->T - 1);
+    }
+    FusedParams f;
+    memset(&f, 0, sizeof(f));
+    f.X = e->W; f.xs_r = 1; f.xs_k = e->m; f.xs_t = e->m * (long)e->K; f.T = e->T;
+    f.Y = Hy; f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->KT;
+    f.c_per_split = e->cps_T;
+    const long mKT = e->m * (long)e->KT;
+    f.out = e->nsplit_T == 1 ? out : e->slabsT;
+    f.slab_stride = mKT; f.os_r = 1; f.os_k = e->m; f.os_t = e->m * (long)e->K;
+    f.cost_partials = do_g2 ? nullptr : e->cost_partials;
+    {
+        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        TRY(launch_fused(e->st, f, e->nsplit_T, true, do_g2 ? 0 : 1, do_g2, 0));
+    }
+    if (do_g2 && e->nsplit_T > 1) {
+        Scope s(e, TAG_SMALL);
+        TRY(reduce_slabs(e->st, e->slabsT, e->nsplit_T, mKT, mKT, out, 0));
+    }
+    if (!do_g2) e->n_cost_used = (int)((e->m + 127) / 128) * e->nsplit_T;
+    return NMFX_OK;
+}
+
 nmfx_status refresh_w_derived(nmfx_engine *e) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
     TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
     if (e->div == NMFX_DIV_KL) {
@@ -579,6 +637,7 @@ nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 =
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
 nmfx_status nmfx_engine_init(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
+    e->hpad_valid = false;
     if (e->algo == 3) {
         if (!e->Z) { set_error("nmfx_engine_init: constrainednmf needs nmfx_engine_set_constraint first"); return NMFX_ERR_INVALID; }
         TRY(z_update(e->st, e->Z, e->H, nullptr, nullptr, nullptr, e->K, e->nz, e->seg_dev, nullptr, nullptr, 1.0f, 1));   // H = Z*A, constrainednmf.m:177
@@ -661,7 +720,8 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
-    TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
+    if (e->fusedT) TRY(fusedT_pass(e, true, e->packed));   // all T numerators in one pass over V, the shifted H tile in LDS
+    else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
     if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
         Scope s(e, TAG_GRAM);
         OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
@@ -789,7 +849,24 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     if (!e->all_fixH) {
         OpView a{}, b{};
         num_view(e, a);
-        TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
+        e->hpad_valid = false;
+        if (e->qgemm) {
+            // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
+            // (K x n) GEMM with contraction T*m whose 64-row output starves the tiles
+            {
+                Scope s(e, TAG_HNUM);
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->KT; g.N = e->nvalid; g.Kc = e->m;
+                g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                a.ld = e->m; a.mode = VIEW_KC; a.blk = 0; a.tstride = 0; a.lim = 0;   // the numerator operand (V, V./V_hat, ...) un-shifted
+                g.B = a;
+                g.C = e->Qbuf; g.ldc = e->KT; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
+            }
+            Scope s(e, TAG_SMALL);
+            TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gn));
+        } else TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
         if (e->gram) {
             // sum_t W_t' * lshift_t(V_hat) = sum_t D_t * lshift_t(Hs),  D = W_flat' * W_flat  (cnmf.m:217-226 without V_hat)
             Scope s(e, TAG_GRAM);
@@ -839,7 +916,8 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
+    if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, false, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
+    else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
     else TRY(recon(e, !nocost));
     Scope s(e, TAG_SMALL);
     e->cost_valid = true;
@@ -918,6 +996,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
+        if (e->fusedT) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
     case TAG_FUSED_H: *flops = (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;

@@ -56,6 +56,39 @@ nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long sla
     return NMFX_OK;
 }
 
+// ---- cnmf H-step numerator from Q = W_flat' * X (KT x ncols):  Gn(k, j) = sum_t Q((t,k), j + t), j + t < nvalid   (cnmf.m:217-226) ----
+__global__ void shift_sum_kernel(const float *Q, int K, int T, long n, long nvalid, float *Gn) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)K * n) return;
+    const long j = idx / K;
+    const int k = (int)(idx - j * K);
+    const long KT = (long)K * T;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t)
+        if (j + t < nvalid) s += Q[(long)t * K + k + KT * (j + t)];
+    Gn[idx] = s;
+}
+nmfx_status shift_sum(hipStream_t st, const float *Q, int K, int T, long n, long nvalid, float *Gn) {
+    const long count = (long)K * n;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(shift_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, Q, K, T, n, nvalid, Gn);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// dst = [zeros(K, pad) | src (K x n)]: the zero left halo the cnmf fused passes read for columns j - t < 0
+__global__ void pad_left_kernel(const float *src, long count, long padcount, float *dst) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < padcount) dst[idx] = 0.0f;
+    if (idx < count) dst[padcount + idx] = src[idx];
+}
+nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst) {
+    const long count = (long)K * n, padcount = (long)K * pad;
+    const long tot = count > padcount ? count : padcount;
+    hipLaunchKernelGGL(pad_left_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, count, padcount, dst);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // ---- column reductions (one workgroup per column) ----------------------------------------------
 __device__ __forceinline__ double red_f(int mode, float x) {
     return mode == 1 ? (double)x * (double)x : (mode == 2 ? (double)fabsf(x) : (double)x);

@@ -26,12 +26,21 @@
 namespace nmfx {
 
 bool fused_supported(int K) { return K >= 32 && K <= 256 && K % 32 == 0; }
+// (Kh, T) pairs instantiated in fused_cnmf_*.hip: Kh*T <= 512 (the register-stationary operand / the accumulators take Kh*T/2 VGPRs)
+bool fused_supported_T(int Kh, int T) {
+    static const int ok[][2] = {{64, 8}, {64, 4}, {32, 8}, {32, 16}, {64, 2}, {32, 4}, {128, 2}, {128, 4}};
+    for (const auto &c : ok) if (c[0] == Kh && c[1] == T) return true;
+    return false;
+}
 
 // one translation unit per K group and per extent kind (fused_k*.hip, fused_rag_k*.hip): the instantiations compile in parallel
 #define NMFX_DECL(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi)
 NMFX_DECL(launch_fused_k32_96); NMFX_DECL(launch_fused_k128_192); NMFX_DECL(launch_fused_k224_256);
 NMFX_DECL(launch_fused_rag_k32_96); NMFX_DECL(launch_fused_rag_k128_192); NMFX_DECL(launch_fused_rag_k224_256);
 #undef NMFX_DECL
+#define NMFX_DECL_T(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2)
+NMFX_DECL_T(launch_fused_cnmf_a); NMFX_DECL_T(launch_fused_cnmf_b); NMFX_DECL_T(launch_fused_cnmf_c);
+#undef NMFX_DECL_T
 
 // nsplit: number of contraction ranges (grid.y); c_per_split must be a multiple of 64.  R (stationary rows) and Cn (streamed extent)
 // that are not multiples of 128 / 64 select the RAG instantiations (masked edges).
@@ -40,6 +49,16 @@ nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool 
     if (p.R <= 0 || p.Cn <= 0 || p.c_per_split % FT_C || p.c_per_split <= 0 || nsplit < 1 || (long)(nsplit - 1) * p.c_per_split >= p.Cn) {
         set_error("launch_fused: bad split (R=%ld Cn=%ld c_per_split=%ld nsplit=%d)", p.R, p.Cn, p.c_per_split, nsplit);
         return NMFX_ERR_INVALID;
+    }
+    if (p.T > 1) {   // cnmf: W-step form only
+        if (!d_rc || epi != 0 || p.K % p.T != 0 || !fused_supported_T(p.K / p.T, p.T)) {
+            set_error("launch_fused: cnmf pass with (K = %d, T = %d) is not instantiated", p.K, p.T);
+            return NMFX_ERR_UNSUPPORTED;
+        }
+        const int kh = p.K / p.T;
+        if ((kh == 64 && (p.T == 8 || p.T == 4))) return launch_fused_cnmf_a(st, p, nsplit, func, do_g2);
+        if (kh == 32 && (p.T == 8 || p.T == 16)) return launch_fused_cnmf_b(st, p, nsplit, func, do_g2);
+        return launch_fused_cnmf_c(st, p, nsplit, func, do_g2);
     }
     if (!fused_supported(p.K)) { set_error("launch_fused: K=%d not supported (multiples of 32 up to 256)", p.K); return NMFX_ERR_UNSUPPORTED; }
     const bool rag = p.R % FT_ROWS != 0 || p.Cn % FT_C != 0;

@@ -28,15 +28,25 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
 // elements and cost terms are masked to zero, so they add nothing to the second product.  Two extra VALU ops per element.
-template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool RAG = false>
+// TT > 1 (cnmf, W-step form only): the contraction index k' = (p, k), p = 0..TT-1, k = 0..K/TT-1, addresses H(k, j - t) with
+// t = TT-1-p (cnmf.m:188 / RFD.m:36-38: V_hat = sum_t W_t * rshift_t(H)), i.e. streamed row j is the K floats that start at column
+// j-(TT-1) of H -- consecutive rows OVERLAP in memory.  The LDS tile therefore holds FT_C + TT-1 columns of H (row stride KH + 4) and
+// row c of the tile starts at LDS row c; nothing is replicated.  p.Y must be preceded by TT-1 readable columns (zeros, or the left
+// halo of a column shard).  X / out slice t = TT-1-p lives at xs_t / os_t.
+template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool RAG = false, int TT = 1>
 __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LDY = K + 4;
+    static_assert(TT == 1 || (D_RC && EPI == 0 && (K / TT) % 32 == 0 && K % TT == 0), "TT > 1: W-step form, K/TT a multiple of 32");
+    constexpr int KH = K / TT;             // floats per column of H
+    constexpr int LDY = KH + 4;            // LDS row stride (one column of H per row)
     constexpr int NKB = K / 32;
-    constexpr int BUF = FT_C * LDY;
+    constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
+    constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
-    constexpr int ROWS_PER_WAVE = FT_C / 4;  // streamed rows each wave moves per tile
+    constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
+    // LDS float offset of contraction index kq (a multiple of 4 or of 32, never straddling a block of KH) relative to the row of streamed index c
+    auto kofs = [](int kq) constexpr -> int { return (kq / KH) * LDY + (kq % KH); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -54,7 +64,10 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
     float xreg[NEED_S ? K / 2 : 1];
     if (NEED_S) {
 #pragma unroll
-        for (int s = 0; s < K / 2; ++s) xreg[s] = row_ok ? p.X[r * p.xs_r + (long)(8 * (s >> 2) + 4 * h + (s & 3)) * p.xs_k] : 0.0f;
+        for (int s = 0; s < K / 2; ++s) {
+            const int kq = 8 * (s >> 2) + (s & 3);                     // + 4*h: stays inside a block of KH
+            xreg[s] = row_ok ? p.X[r * p.xs_r + (long)(kq % KH + 4 * h) * p.xs_k + (long)(TT - 1 - kq / KH) * p.xs_t] : 0.0f;
+        }
     }
 
     f32x16 acc[DO_G2 ? NKB : 1];
@@ -68,14 +81,16 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
     // Streamed tile: LDS-DMA (buffer_load_dwordx4 ... lds), one 1-KiB row of K floats per wave-instruction, wave w moves rows
     // w, w+4, ...  Issued as inline asm so hipcc does not see an LDS write (with the builtin it drains vmcnt(0) before the next
     // ds_read and serialises the DMA latency into every tile); completion = s_waitcnt vmcnt(0) + barrier at the tile top.
+    const int ystride = p.y_stride > 0 ? (int)p.y_stride : K;   // floats between streamed rows in memory (> K: a K-wide column block of wider rows)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned y_voff = (unsigned)lane * 16u;
     auto dma_row = [&](const i32x4 ysrd, int b, int c) {   // c-th row of this wave: tile row w + 4c
         const int row = w + 4 * c;
+        if (TROWS % 4 != 0 && row >= TROWS) return;            // wave-uniform
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((b * BUF + row * LDY) * 4));
-        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(row * K * 4));
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(row * (TT > 1 ? KH : ystride) * 4));
         unsigned keep;
-        if (lane < K / 4)
+        if (lane < KH / 4)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(y_voff), "s"(ysrd), "s"(dst), "s"(soff) : "memory");
     };
@@ -85,7 +100,10 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
         const long left = cend - (cbeg + (long)t * FT_C);
         return left >= FT_C ? FT_C : (left > 0 ? (int)left : 0);
     };
-    auto y_srd = [&](int t) { return make_srd(p.Y + (cbeg + (long)t * FT_C) * K, (unsigned)(tile_rows(t) * K * 4)); };
+    auto y_srd = [&](int t) {
+        if (TT > 1) return make_srd(p.Y + (cbeg + (long)t * FT_C - (TT - 1)) * KH, (unsigned)((tile_rows(t) + TT - 1) * KH * 4));
+        return make_srd(p.Y + (cbeg + (long)t * FT_C) * ystride, (unsigned)(tile_rows(t) > 0 ? ((tile_rows(t) - 1) * ystride + K) * 4 : 0));
+    };
 
     // V tile of step t: d[jb*16 + reg] = V(r, c = c0 + 32*jb + rowmap(reg, h))
     float d[32];
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
 #pragma unroll
             for (int q = q0; q < q1; ++q) emap_u(jb, q >> 2, q & 3);
         };
-        auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + 8 * g + 4 * h); };
+        auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + kofs(8 * g) + 4 * h); };
         if (NEED_S) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             auto g2_read = [&](int jb, int reg, float (&y)[NKB]) {
                 const float *yrow = Yt + (32 * jb + rowmap(reg, h)) * LDY + l31;
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) y[kb] = yrow[32 * kb];
+                for (int kb = 0; kb < NKB; ++kb) y[kb] = yrow[kofs(32 * kb)];
             };
             float y_cur[NKB], y_nxt[NKB];
             g2_read(0, 0, y_cur);
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    if (row_ok) out[r * p.os_r + (long)(32 * kb + rowmap(reg, h)) * p.os_k] = acc[kb][reg];
+                    if (row_ok) out[r * p.os_r + (long)((32 * kb) % KH + rowmap(reg, h)) * p.os_k + (long)(TT - 1 - (32 * kb) / KH) * p.os_t] = acc[kb][reg];
         } else {
             // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
 #pragma unroll

@@ -19,6 +19,30 @@ static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) 
     return NMFX_OK;
 }
 
+// cnmf (TT > 1), W-step form: numerator pass (FUNC 0: N_t = V * rshift_t(H)', all t at once) and cost-only pass (FUNC 1).  The masked-edge
+// (RAG) instantiation serves every shape: its two extra VALU ops per element are nothing next to K = Kh*TT MFMAs per streamed column.
+template <int K, int FUNC, bool DO_G2, int TT>
+static nmfx_status launch_one_T(hipStream_t st, const FusedParams &p, int nsplit) {
+    const size_t ldsb = sizeof(float) * 2 * (FT_C + TT - 1) * (K / TT + 4);
+    auto kern = fused_kernel<K, true, FUNC, DO_G2, 0, 0, true, TT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((p.R + FT_ROWS - 1) / FT_ROWS), (unsigned)nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+template <int KH, int TT>
+static nmfx_status launch_T(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2) {
+    if (func == 0 && do_g2) return launch_one_T<KH * TT, 0, true, TT>(st, p, nsplit);
+    if (func == 1 && !do_g2) return launch_one_T<KH * TT, 1, false, TT>(st, p, nsplit);
+    set_error("launch_fused_T: unsupported pass (func %d, do_g2 %d)", func, (int)do_g2);
+    return NMFX_ERR_UNSUPPORTED;
+}
+
 template <int K, bool D_RC, bool DO_G2, int EPI, bool RAG>
 static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, int func) {
     switch (func) {

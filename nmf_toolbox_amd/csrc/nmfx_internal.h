@@ -101,7 +101,10 @@ size_t gemm_scratch_bytes(long M, long N, long Kc);
 struct FusedParams {
     const float *X;       // stationary factor: X(r, k) = X[r*xs_r + k*xs_k]   (W step: W; H step: H^T i.e. H with xs_r = K, xs_k = 1)
     long xs_r, xs_k;
-    const float *Y;       // streamed factor: row c = K contiguous floats at Y + c*K  (W step: columns of H; H step: rows of W = W^T copy)
+    int T;                // cnmf (W-step form only): K = Kh*T contraction indices (t, k); X / out slice t at xs_t / os_t; Y = H (Kh x n),
+    long xs_t, os_t;      //   preceded by T-1 readable columns (zeros or a shard's left halo).  0 or 1: plain nmf
+    const float *Y;       // streamed factor: row c = K contiguous floats at Y + c*y_stride  (W step: columns of H; H step: rows of W = W^T copy)
+    long y_stride;        // 0 = K.  > K: the K floats are a column block of longer rows (H-step numerator of a wide factor in blocks of <= 256)
     const float *D;       // V (m x n, ld = ldd); W step reads V(r, c) = D[r + ldd*c], H step V(c, r) = D[c + ldd*r]
     long ldd;
     long R, Cn;           // stationary rows (multiple of 128), streamed rows (multiple of 64)
@@ -120,6 +123,7 @@ struct FusedParams {
     int sqrt_rule;        // EPI 1: H <- sqrt(H .* G)   (lnmf.m:76) instead of the ratio update
 };
 bool fused_supported(int K);
+bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
 // func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost;  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
@@ -150,6 +154,8 @@ struct WUpdateParams {
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
                         double *f_out, int kvalid = 0);
+nmfx_status shift_sum(hipStream_t st, const float *Q, int K, int T, long n, long nvalid, float *Gn);
+nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst);
 nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);

@@ -107,7 +107,6 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     auto ld = [&](const __amdgpu_buffer_rsrc_t srd, int e) -> double {
         const int voff = (int)(threadIdx.x * sizeof(TIO)), ioff = e * THREADS * (int)sizeof(TIO);
         if (sizeof(TIO) == 4) return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, ioff, 0));
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(srd, voff, ioff, 0));
     };
     const int tid = threadIdx.x;

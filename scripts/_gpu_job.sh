@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -m gpu -x -q -k "projfunc or nmfsc" 2>&1 | tail -3
-python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -c 900
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r2_c5 -o c5 -- python bench.py --workload c5 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_r2_c5.log 2>&1
-ls gpurun_out/prof_r2_c5 | head
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_pins.py tests/test_gpu_sharded.py tests/test_gpu_fullsize.py -m gpu -x -q -k "cnmf" 2>&1 | tail -3
+python bench.py --workload c4 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['roofline']['phases_ms_per_step'])"
+python bench.py --workload c4kl --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['roofline']['phases_ms_per_step'])"
+NMFX_CNMF_NO_QGEMM=1 python bench.py --workload c4kl --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['roofline']['phases_ms_per_step'])"
