@@ -1212,6 +1212,208 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     return s;
 }
 
+// ---- nmfx_problem.n_gpus > 1: one process, one host thread, one stream + engine per device (what a MEX caller of nmf() needs) -------
+// V and H are column-sharded over the devices, W is replicated.  Per iteration ONE exchange of the packed W-step sums
+// (SURVEY 8(e)), done here without a collective library: every device reduces its own 1/N slice of `packed` straight out of its
+// peers' HBM over xGMI (all links in parallel, fixed summation order), then copies the other N-1 reduced slices from their owners.
+// Each slice has exactly one owner, so all replicas of W stay bit-identical.  device_ids may name one device several times
+// (N shards on one GPU): that is how the 1-GPU test box exercises this path.
+struct MultiDev {
+    int ndev = 0;
+    int dev[NMFX_MAX_GPUS];
+    hipStream_t st[NMFX_MAX_GPUS] = {};
+    hipEvent_t evP[NMFX_MAX_GPUS] = {}, evR[NMFX_MAX_GPUS] = {}, evG[NMFX_MAX_GPUS] = {};
+    nmfx_engine *eng[NMFX_MAX_GPUS] = {};
+    DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
+    long lo[NMFX_MAX_GPUS + 1];
+    ~MultiDev() {
+        for (int g = 0; g < ndev; ++g) {
+            (void)hipSetDevice(dev[g]);
+            if (eng[g]) nmfx_engine_destroy(eng[g]);
+            if (evP[g]) (void)hipEventDestroy(evP[g]);
+            if (evR[g]) (void)hipEventDestroy(evR[g]);
+            if (evG[g]) (void)hipEventDestroy(evG[g]);
+            if (st[g]) (void)hipStreamDestroy(st[g]);
+        }
+    }
+};
+
+nmfx_status multi_allreduce(MultiDev &M, size_t count) {
+    const int N = M.ndev;
+    PeerPtrs ptrs{};
+    for (int g = 0; g < N; ++g) ptrs.p[g] = M.packed[g].as<float>();
+    const long per = (long)(((count + N - 1) / N + 3) & ~(size_t)3);   // slice length, a multiple of 4 floats
+    auto slice = [&](int g, long *off, long *cnt) { *off = std::min((long)count, per * g); *cnt = std::min((long)count, per * (g + 1)) - *off; };
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipEventRecord(M.evP[g], M.st[g])); }
+    for (int g = 0; g < N; ++g) {   // reduce-scatter: device g owns slice g
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) if (h != g) NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evP[h], 0));
+        long off, cnt;
+        slice(g, &off, &cnt);
+        TRY(peer_reduce(M.st[g], ptrs, N, g, off, cnt));
+        NMFX_HIP(hipEventRecord(M.evR[g], M.st[g]));
+    }
+    for (int g = 0; g < N; ++g) {   // all-gather: fetch the slices the others reduced
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) {
+            if (h == g) continue;
+            long off, cnt;
+            slice(h, &off, &cnt);
+            NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evR[h], 0));
+            if (cnt > 0) NMFX_HIP(hipMemcpyPeerAsync(ptrs.p[g] + off, M.dev[g], ptrs.p[h] + off, M.dev[h], (size_t)cnt * 4, M.st[g]));
+        }
+        NMFX_HIP(hipEventRecord(M.evG[g], M.st[g]));
+    }
+    for (int g = 0; g < N; ++g) {   // nobody refills its `packed` (next W-step partial) before every peer has copied out of it
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) if (h != g) NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evG[h], 0));
+    }
+    return NMFX_OK;
+}
+
+nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
+    TRY(validate_problem(p, r, false, true));
+    if (algorithm != 0 && algorithm != 2) { set_error("n_gpus > 1 is implemented for nmf and lnmf (cnmf / nmfsc shard through the device-level API)"); return NMFX_ERR_UNSUPPORTED; }
+    if (p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
+    const int N = p->n_gpus;
+    if (N > NMFX_MAX_GPUS || N > p->n) { set_error("n_gpus = %d: at most %d devices and one column per device", N, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
+    MultiDev M;
+    for (int g = 0; g < N; ++g) {
+        M.dev[g] = p->device_ids ? p->device_ids[g] : g;
+        TRY(check_device(M.dev[g]));
+    }
+    for (int g = 0; g < N; ++g)      // peer mappings: the reduce kernel reads the other devices' `packed` in place
+        for (int h = 0; h < N; ++h) {
+            if (M.dev[g] == M.dev[h]) continue;
+            int can = 0;
+            NMFX_HIP(hipDeviceCanAccessPeer(&can, M.dev[g], M.dev[h]));
+            if (!can) { set_error("device %d cannot access device %d as a peer", M.dev[g], M.dev[h]); return NMFX_ERR_UNSUPPORTED; }
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            hipError_t pe = hipDeviceEnablePeerAccess(M.dev[h], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { set_error("hipDeviceEnablePeerAccess(%d -> %d): %s", M.dev[g], M.dev[h], hipGetErrorString(pe)); return NMFX_ERR_HIP; }
+            (void)hipGetLastError();
+        }
+    const int Kt = p->K_total, S = p->num_sources, dv = p->divergence;
+    const long m = p->m, n = p->n;
+    M.lo[0] = 0;
+    for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
+    long nmin = n;
+    for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
+    const bool pad = Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN);
+    const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
+    std::vector<float> lw(K, 0.f), lh(K, 0.f);
+    std::vector<uint8_t> fw(K, 0), fh(K, 0);
+    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
+    for (int s = 0, k0 = 0; s < S; ++s) {
+        const int Ks = p->K_s ? p->K_s[s] : Kt;
+        for (int k = k0; k < k0 + Ks; ++k) {
+            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
+            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
+            if (p->W_fixed) fw[k] = p->W_fixed[s];
+            if (p->H_fixed) fh[k] = p->H_fixed[s];
+        }
+        k0 += Ks;
+    }
+    const size_t mK = (size_t)m * K, mKt = (size_t)m * Kt;
+    size_t packed_count = 0;
+    int kind = -1;
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        M.ndev = g + 1;
+        NMFX_HIP(hipStreamCreateWithFlags(&M.st[g], hipStreamNonBlocking));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evP[g], hipEventDisableTiming));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evR[g], hipEventDisableTiming));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evG[g], hipEventDisableTiming));
+        const long nl = M.lo[g + 1] - M.lo[g];
+        nmfx_engine_desc d{};
+        d.m = m; d.n_local = nl; d.K_total = K; d.T = 1; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
+        d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
+        d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = p->path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
+        size_t wsb = 0, pc = 0;
+        TRY(nmfx_engine_workspace_bytes(&d, &wsb));
+        TRY(nmfx_engine_packed_count(&d, &pc));
+        if (g == 0) packed_count = pc;
+        else if (pc != packed_count) { set_error("n_gpus: shards disagree on the packed layout"); return NMFX_ERR_INVALID; }
+        DevBuf stage, tmp;
+        TRY(M.V[g].alloc((size_t)m * nl * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nl * 4)); TRY(M.ws[g].alloc(wsb));
+        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64)); TRY(stage.alloc(STAGE_ELEMS * 8));
+        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
+        const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
+        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * nl, 1.0, stage, STAGE_ELEMS));
+        TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0, stage, STAGE_ELEMS));
+        if (pad) {
+            NMFX_HIP(hipMemsetAsync(M.W[g].as<float>() + mKt, 0, (mK - mKt) * 4, M.st[g]));
+            TRY(tmp.alloc((size_t)Kt * nl * 4));
+            TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(M.st[g], tmp.as<float>(), Kt, M.H[g].as<float>(), K, nl));
+            NMFX_HIP(hipStreamSynchronize(M.st[g]));
+        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nl, 1.0, stage, STAGE_ELEMS));
+        TRY(nmfx_engine_create(&d, M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb, M.packed[g].as<float>(), &M.eng[g]));
+        TRY(nmfx_engine_set_rank0(M.eng[g], g == 0));
+        const int kd = nmfx_engine_is_fused(M.eng[g]);
+        if (kind < 0) kind = kd;
+        else if (kd != kind) { set_error("n_gpus: shards picked different kernel paths; pass path = 1"); return NMFX_ERR_UNSUPPORTED; }
+        TRY(nmfx_engine_init(M.eng[g]));
+    }
+    const bool lag = kind == 1;
+    std::vector<double> hc(N);
+    auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
+        for (int g = 0; g < N; ++g) {
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            NMFX_HIP(hipMemcpyAsync(&hc[g], M.eng[g]->cost, sizeof(double), hipMemcpyDeviceToHost, M.st[g]));
+        }
+        double c = 0.0;
+        for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); c += hc[g]; }
+        r->cost[idx] = c;
+        r->iters_run = idx + 1;
+        return NMFX_OK;
+    };
+    auto stop = [&](int idx) {
+        if (p->tolerance < 0 || idx == 0) return false;
+        if (algorithm == 2) return r->cost[idx] <= r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] <= p->tolerance;   // lnmf.m:84
+        return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;                         // nmf.m:221
+    };
+    r->iters_run = 0;
+    bool stopped = false;
+    for (int it = 0; it < p->maxiter; ++it) {
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_wstep_partial(M.eng[g]));
+        if (lag && it > 0) {
+            TRY(read_cost(it - 1));
+            if (stop(it - 1)) { stopped = true; break; }
+        }
+        TRY(multi_allreduce(M, packed_count));
+        for (int g = 0; g < N; ++g) { TRY(nmfx_engine_wstep_finish(M.eng[g])); TRY(nmfx_engine_hstep(M.eng[g])); }
+        if (!lag) {
+            TRY(read_cost(it));
+            if (stop(it)) { stopped = true; break; }
+        }
+    }
+    if (lag && !stopped) {
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_cost_pass(M.eng[g]));
+        TRY(read_cost(p->maxiter - 1));
+    }
+    r->cost_len = r->iters_run;
+    if (algorithm == 2) {
+        for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
+        r->cost_len = p->maxiter;
+    }
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        const long nl = M.lo[g + 1] - M.lo[g];
+        DevBuf stage, tmp;
+        TRY(stage.alloc(STAGE_ELEMS * 8));
+        if (g == 0) TRY(download(M.st[g], M.W[g].as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS));
+        char *Hh = static_cast<char *>(r->H) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
+        if (pad) {
+            TRY(tmp.alloc((size_t)Kt * nl * 4));
+            TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, tmp.as<float>(), Kt, nl));
+            TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl, stage, STAGE_ELEMS));
+        } else TRY(download(M.st[g], M.H[g].as<float>(), p->dtype, Hh, (size_t)K * nl, stage, STAGE_ELEMS));
+    }
+    return NMFX_OK;
+}
+
 // 0.5*||V - V_hat||^2 from the per-block partials of an EPI_COST GEMM (host double)
 nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out, Comm *comm = nullptr) {
     TRY(finish_cost(st, partials, count, 0.5, nullptr, 0, nullptr, nullptr, 0, nullptr, cost_dev));
@@ -1793,9 +1995,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
 
 extern "C" {
 
-nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 0); }
-nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 1); }
-nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return run_mu(p, r, 2); }
+nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 0) : run_mu(p, r, 0); }
+nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 1) : run_mu(p, r, 1); }
+nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 2) : run_mu(p, r, 2); }
 nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, int64_t nz, const void *Z_init, nmfx_result *r, void *Z_out) {
     return run_mu(p, r, 3, segments, nz, Z_init, Z_out);
 }

@@ -89,6 +89,35 @@ nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, f
     return NMFX_OK;
 }
 
+// ---- single-process multi-GPU all-reduce, reduce-scatter half: this device sums slice [off, off + count) of every device's buffer
+// (peer-mapped over xGMI) in the fixed order 0 .. ndev-1 and writes it back into its own buffer; the all-gather half is plain peer copies.
+// One device owns each slice, so every device ends with bit-identical sums.
+__global__ void peer_reduce_kernel(PeerPtrs bufs, int ndev, int self, long off, long count) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= count) return;
+    if (i + 3 < count && ((off + i) & 3) == 0) {
+        float4 s = *reinterpret_cast<const float4 *>(bufs.p[0] + off + i);
+        for (int h = 1; h < ndev; ++h) {
+            const float4 t = *reinterpret_cast<const float4 *>(bufs.p[h] + off + i);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(bufs.p[self] + off + i) = s;
+    } else {
+        for (long e = i; e < i + 4 && e < count; ++e) {
+            float s = bufs.p[0][off + e];
+            for (int h = 1; h < ndev; ++h) s += bufs.p[h][off + e];
+            bufs.p[self][off + e] = s;
+        }
+    }
+}
+nmfx_status peer_reduce(hipStream_t st, const PeerPtrs &bufs, int ndev, int self, long off, long count) {
+    if (count <= 0) return NMFX_OK;
+    const long nthr = (count + 3) / 4;
+    hipLaunchKernelGGL(peer_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, bufs, ndev, self, off, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // ---- column reductions (one workgroup per column) ----------------------------------------------
 __device__ __forceinline__ double red_f(int mode, float x) {
     return mode == 1 ? (double)x * (double)x : (mode == 2 ? (double)fabsf(x) : (double)x);

@@ -154,6 +154,9 @@ struct WUpdateParams {
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
                         double *f_out, int kvalid = 0);
+constexpr int NMFX_MAX_GPUS = 16;
+struct PeerPtrs { float *p[NMFX_MAX_GPUS]; };
+nmfx_status peer_reduce(hipStream_t st, const PeerPtrs &bufs, int ndev, int self, long off, long count);
 nmfx_status shift_sum(hipStream_t st, const float *Q, int K, int T, long n, long nvalid, float *Gn);
 nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst);
 nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);

@@ -158,6 +158,11 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     p.tolerance = -1.0 if cfg.get("nmfx_disable_stop", False) else float(cfg["tolerance"])
     p.device = int(device)
     p.path = int(cfg.get("nmfx_path", 0))       # extension: 0 auto, 1 generic kernels only, 2 require the fused kernels
+    # extension: nmfx_gpus = N or a list of device ordinals -> V / H column-sharded over N GPUs of this process (nmf, lnmf)
+    gpus = cfg.get("nmfx_gpus", None)
+    if gpus is not None:
+        ids = np.asarray(list(range(int(gpus))) if np.isscalar(gpus) else list(gpus), dtype=np.int32)
+        p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
     r = _lib.Result()
     r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
     _lib.check(fn(C.byref(p), C.byref(r)))
