@@ -1,25 +1,26 @@
-function [W, H, cost] = nmfx_nmf(V, num_basis_elems, config)
-% nmfx_nmf  Drop-in for nmf(V, num_basis_elems, config) of the NMF Toolbox, computed on an AMD MI355X by libnmfx.
+function [W, H, cost] = nmfx_cnmf(V, num_basis_elems, context_len, config)
+% nmfx_cnmf  Drop-in for cnmf(V, num_basis_elems, context_len, config) of the NMF Toolbox, computed on an AMD MI355X by libnmfx.
 % SOURCE ONLY (never run: no MATLAB in the build image; the gateway underneath is exercised by tests/test_mex_gateway.py).
-% Rename to nmf.m (ahead of the toolbox on the path) to drop in.  config.nmfx_device_ids = int32([0 1 ... 7]) shards V over several GPUs.
-% Argument meaning, defaults, cell handling and error messages follow the toolbox's nmf and its local ValidateParameters.
-if nargin < 3, config = struct; end
+% Rename to cnmf.m (ahead of the toolbox on the path) to drop in.  Argument meaning, defaults, cell handling and error messages
+% follow the toolbox's cnmf and its local ValidateParameters; the library does the normalisation of the init and the iterations.
+if nargin < 4, config = struct; end
 if ~iscell(num_basis_elems), num_basis_elems = {num_basis_elems}; end
 S = numel(num_basis_elems);
+T = context_len;
 [m, n] = size(V);
 % --- defaults exactly as the toolbox's local ValidateParameters ---
 if ~isfield(config, 'divergence'), config.divergence = 'euclidean'; end
 is_ab = any(strcmp(config.divergence, {'ab_divergence', 'ab'}));
 if ~isfield(config, 'alpha') || ~is_ab, config.alpha = 1; end
 if ~isfield(config, 'beta') || ~is_ab, config.beta = 1; end
-switch config.divergence
-    case 'euclidean', dv = 0;
+if is_ab && config.alpha == 0 && config.beta == 0, error('alpha = 0 and beta = 0 is not supported at this time.'); end
+switch config.divergence                     % the toolbox's cnmf maps the name to (alpha, beta) and has NO otherwise branch:
+    case 'euclidean', dv = 0;                % any other string runs the euclidean updates with an all-zero cost vector
     case {'kl_divergence', 'kl'}, dv = 1;
     case {'is_divergence', 'is'}, dv = 2;
     case {'ab_divergence', 'ab'}, dv = 3;
-    otherwise, error(['No update equations defined for cost function with divergence type ', config.divergence]);
+    otherwise, dv = 4;                       % 'frobenius' and unknown names: NMFX_DIV_EUCLIDEAN_NOCOST
 end
-if is_ab && config.alpha == 0 && config.beta == 0, error('alpha = 0 and beta = 0 is not supported at this time.'); end
 if ~isfield(config, 'H_init') || isempty(config.H_init)
     is_H_cell = S > 1; config.H_init = cell(S, 1);
     for s = 1 : S, config.H_init{s} = max(rand(num_basis_elems{s}, n), eps); end
@@ -30,8 +31,11 @@ else, is_H_cell = true; config.H_init = config.H_init(:); end
 if ~isfield(config, 'W_init') || isempty(config.W_init)
     is_W_cell = S > 1; config.W_init = cell(1, S);
     for s = 1 : S
-        w = max(rand(m, num_basis_elems{s}), eps);
-        config.W_init{s} = w * diag(1 ./ sqrt(sum(w.^2, 1)));
+        w = rand(m, num_basis_elems{s}, T);
+        for k = 1 : num_basis_elems{s}
+            w(:, k, :) = w(:, k, :) / (norm(squeeze(w(:, k, :)), 'fro') / T);
+        end
+        config.W_init{s} = w;
     end
 elseif iscell(config.W_init) && numel(config.W_init) ~= S
     error(['Requested ', num2str(S), ' sources. Given ', num2str(numel(config.W_init)), ' initial basis matrices.']);
@@ -45,13 +49,13 @@ if ~isfield(config, 'maxiter') || config.maxiter <= 0, config.maxiter = 100; end
 if ~isfield(config, 'tolerance') || config.tolerance <= 0, config.tolerance = 1e-3; end
 opts.divergence = dv; opts.alpha = config.alpha; opts.beta = config.beta;
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
-if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end
 K_s = int32(cell2mat(num_basis_elems(:)'));
-[Wa, Ha, cost] = nmfx_mex('nmf', double(V), cell2mat(config.W_init), cell2mat(config.H_init), K_s, 1, opts);
+W_all = cat(2, config.W_init{:});            % cell2mat(1 x S) of m x K_s x T tensors: along dimension 2
+[Wa, Ha, cost] = nmfx_mex('cnmf', double(V), double(W_all), double(cell2mat(config.H_init)), K_s, T, opts);
 edges = [0, cumsum(double(K_s))];
 W = cell(1, S); H = cell(S, 1);
 for s = 1 : S
-    W{s} = Wa(:, edges(s)+1 : edges(s+1));
+    W{s} = Wa(:, edges(s)+1 : edges(s+1), :);
     H{s} = Ha(edges(s)+1 : edges(s+1), :);
 end
 if ~is_W_cell, W = W{1}; end
