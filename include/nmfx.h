@@ -133,7 +133,8 @@ nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r);
  *   p->V / W_init / H_init / dtype are ignored; result.W / result.H are ignored, cost / tries_* / stepsize_* are filled.
  * Per outer iteration: ONE large all-reduce of [V*H' | H*H'] (m*K + K*K floats), an 8-byte sum per objective evaluation
  * (nmfsc.m:161,212,238) and, when H is projected, 4*K doubles per reduction of projfunc.m:22-53.  Column shards need the
- * fused kernels: K a multiple of 32 up to 256 (NMFX_ERR_UNSUPPORTED otherwise). */
+ * fused kernels: any K <= 256 (padded internally to a multiple of 32 with zero components), m and n_local >= 64
+ * (NMFX_ERR_UNSUPPORTED otherwise). */
 typedef enum { NMFX_REDUCE_SUM = 0, NMFX_REDUCE_MAX = 1 } nmfx_reduce_op;
 typedef int32_t (*nmfx_allreduce_fn)(void *ctx, void *dev_ptr, int64_t count, int32_t dtype, int32_t op, void *stream);
 nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,

@@ -1443,8 +1443,13 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     if (!dev) TRY(validate_problem(p, r, true));
     if (p->T != 1) { set_error("nmfsc: T must be 1"); return NMFX_ERR_INVALID; }
     const long m = p->m, n = p->n;
-    const int K = p->K_total;
-    const size_t mn = (size_t)m * n, mK = (size_t)m * K, Kn = (size_t)K * n;
+    // any K <= 256 runs on the fused kernels: K is rounded up to a multiple of 32 with zero columns of W / zero rows of H.  They add exact
+    // zeros to W*H, to every gradient and to every Gram product, stay zero under both update rules, and are kept away from the only two
+    // places that would resurrect them: projfunc (a zero vector does NOT project to zero) and the row-norm rescale of nmfsc.m:185-187 (0/0)
+    const int Kv = p->K_total;
+    const bool padK = p->path != 1 && Kv % 32 != 0 && Kv <= 256 && ((m >= 64 && n >= 64) || p->path == 2);
+    const int K = padK ? (Kv + 31) / 32 * 32 : Kv;
+    const size_t mn = (size_t)m * n, mK = (size_t)m * K, Kn = (size_t)K * n, mKv = (size_t)m * Kv, Kvn = (size_t)Kv * n;
     Comm nocomm{};
     Comm &comm = dev ? dev->comm : nocomm;
     double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62
@@ -1468,7 +1473,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     const bool fast = p->path != 1 && fused_supported(K) && ((m >= 64 && n >= 64) || p->path == 2);   // ragged m / n: masked-edge kernels
     if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
     if (comm.active() && !fast) {
-        set_error("nmfsc on column shards runs on the fused kernels only: K a multiple of 32 up to 256");
+        set_error("nmfsc on column shards runs on the fused kernels only: K <= 256, m and n_local >= 64");
         return NMFX_ERR_UNSUPPORTED;
     }
     if (!dev) TRY(V.alloc(mn * 4));
@@ -1485,21 +1490,31 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     if (sb2 > sb) sb = sb2;
     if (sb3 > sb) sb = sb3;
     TRY(scratch.alloc(sb));
+    DevBuf hpk;   // Kv x n staging of the un-padded, row-interleaved H
+    if (padK) {
+        TRY(hpk.alloc(Kvn * 4));
+        NMFX_HIP(hipMemsetAsync(W.p, 0, mK * 4, st)); NMFX_HIP(hipMemsetAsync(Wn.p, 0, mK * 4, st));
+        NMFX_HIP(hipMemsetAsync(HT.p, 0, Kn * 4, st)); NMFX_HIP(hipMemsetAsync(HnT.p, 0, Kn * 4, st));   // the padding of every buffer that is only ever
+    }                                                                                                 // written through projfunc stays zero
     if (!dev) {
         TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
-        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mK, 1.0, stage, STAGE_ELEMS));
-        TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKv, 1.0, stage, STAGE_ELEMS));   // the first Kv columns of the m x K array
+        if (padK) {
+            TRY(upload(st, p->H_init, p->dtype, hpk.as<float>(), Kvn, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, hpk.as<float>(), Kv, Hk.as<float>(), K, n));
+        } else TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
     } else {
-        NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mK * 4, hipMemcpyDeviceToDevice, st));
-        NMFX_HIP(hipMemcpyAsync(Hk.p, dev->H, Kn * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mKv * 4, hipMemcpyDeviceToDevice, st));
+        if (padK) TRY(repack_rows(st, dev->H, Kv, Hk.as<float>(), K, n));
+        else NMFX_HIP(hipMemcpyAsync(Hk.p, dev->H, Kn * 4, hipMemcpyDeviceToDevice, st));
     }
     const float *Vp = dev ? dev->V : V.as<float>();
     float *Wd = W.as<float>(), *Wnew = Wn.as<float>(), *HTd = HT.as<float>(), *HnewT = HnT.as<float>();
     // rows of H (stored as the columns of an n_local x K transposed copy) through projfunc; on column shards every reduction of
     // projfunc.m:22-53 is a sum over ranks
     auto project_H = [&](float *HxT) -> nmfx_status {
-        if (comm.active()) return projfunc_cols_dist(st, HxT, n, K, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>());
-        return projfunc_cols(st, HxT, n, K, L1s, 1.0, 1, nullptr);
+        if (comm.active()) return projfunc_cols_dist(st, HxT, n, Kv, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>());
+        return projfunc_cols(st, HxT, n, Kv, L1s, 1.0, 1, nullptr);
     };
     // out = projection of (base + mu*dir), rows of H as the columns of the n x K transposed copies   (nmfsc.m:154-157)
     auto step_project_H = [&](const float *baseT, const float *dirT, float mu, float *outT) -> nmfx_status {
@@ -1508,11 +1523,11 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             return project_H(outT);
         }
         PScope ps(pf, SC_PROJ);
-        return projfunc_cols(st, outT, n, K, L1s, 1.0, 1, nullptr, dirT, mu, baseT);   // the step is applied while loading
+        return projfunc_cols(st, outT, n, Kv, L1s, 1.0, 1, nullptr, dirT, mu, baseT);   // the step is applied while loading
     };
     TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
     const bool resume = dev && p->sc_resume;   // W / H are the state a previous call left: already projected, nothing to initialise
-    if (sW > 0 && !resume) TRY(projfunc_cols(st, Wd, m, K, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
+    if (sW > 0 && !resume) TRY(projfunc_cols(st, Wd, m, Kv, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
     if (sH > 0 && !resume) TRY(project_H(HTd));                                        // nmfsc.m:107-109
 
     // V_hat = Wx * Hx (Hx given transposed, n x K) with the residual objective; returns 0.5*||V - V_hat||^2
@@ -1666,10 +1681,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 } else {
                     TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
                     TRY(transpose_f32(st, Hcur, K, n, HTd));
-                    TRY(col_reduce(st, HTd, n, n, K, 1, nrm2));                                     // nmfsc.m:185
-                    if (comm.active()) TRY(comm.allreduce(nrm2, K, NMFX_F64, NMFX_REDUCE_SUM));     // row norms of H span the shards
-                    TRY(scale_cols(st, HTd, n, K, nrm2, 1, 1));                                     // nmfsc.m:186
-                    TRY(scale_cols(st, Wd, m, K, nrm2, 1, 0));                                      // nmfsc.m:187
+                    TRY(col_reduce(st, HTd, n, n, Kv, 1, nrm2));                                    // nmfsc.m:185
+                    if (comm.active()) TRY(comm.allreduce(nrm2, Kv, NMFX_F64, NMFX_REDUCE_SUM));    // row norms of H span the shards
+                    TRY(scale_cols(st, HTd, n, Kv, nrm2, 1, 1));                                    // nmfsc.m:186
+                    TRY(scale_cols(st, Wd, m, Kv, nrm2, 1, 0));                                     // nmfsc.m:187
                     TRY(transpose_f32(st, HTd, n, K, Hcur));
                     cur_obj = NAN;
                 }
@@ -1686,7 +1701,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                         ++tries;
                         {
                             PScope ps(pf, SC_PROJ);
-                            TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, G2.as<float>(), (float)(-stepW), Wd));   // nmfsc.m:205-208
+                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, G2.as<float>(), (float)(-stepW), Wd));   // nmfsc.m:205-208
                         }
                         TRY(fast_obj(Wnew, Hcur, &newobj));                                         // nmfsc.m:211-212
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
@@ -1719,13 +1734,17 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
         if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
         if (dev) {
-            NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mK * 4, hipMemcpyDeviceToDevice, st));
-            NMFX_HIP(hipMemcpyAsync(dev->H, Hcur, Kn * 4, hipMemcpyDeviceToDevice, st));
+            NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mKv * 4, hipMemcpyDeviceToDevice, st));
+            if (padK) TRY(repack_rows(st, Hcur, K, dev->H, Kv, n));
+            else NMFX_HIP(hipMemcpyAsync(dev->H, Hcur, Kn * 4, hipMemcpyDeviceToDevice, st));
             NMFX_HIP(hipStreamSynchronize(st));
             return NMFX_OK;
         }
-        TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
-        TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+        TRY(download(st, Wd, p->dtype, r->W, mKv, stage, STAGE_ELEMS));
+        if (padK) {
+            TRY(repack_rows(st, Hcur, K, hpk.as<float>(), Kv, n));
+            TRY(download(st, hpk.as<float>(), p->dtype, r->H, Kvn, stage, STAGE_ELEMS));
+        } else TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
         return NMFX_OK;
     }
     TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
@@ -1741,7 +1760,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 for (;;) {
                     ++tries;
                     TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
-                    TRY(projfunc_cols(st, HnewT, n, K, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
+                    TRY(projfunc_cols(st, HnewT, n, Kv, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
                     double newobj;
                     TRY(recon_obj(Wd, HnewT, &newobj));                                         // nmfsc.m:160-161
                     if (newobj <= begobj) break;                                                // nmfsc.m:164
@@ -1772,7 +1791,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 for (;;) {
                     ++tries;
                     TRY(axpy_f32(st, (long)mK, (float)(-stepW), G1.as<float>(), Wd, Wnew));     // nmfsc.m:205
-                    TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
+                    TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
                     double newobj;
                     TRY(recon_obj(Wnew, HTd, &newobj));                                         // nmfsc.m:211-212
                     if (newobj <= begobj) break;                                                // nmfsc.m:215

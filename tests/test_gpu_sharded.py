@@ -390,10 +390,19 @@ def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world):
         assert np.allclose(Hs.sum(1), L1s, rtol=1e-5) and np.allclose((Hs ** 2).sum(1), 1.0, rtol=1e-5) and Hs.min() >= 0
 
 
-def test_nmfsc_sharded_refuses_unsupported_K_and_negative_data(gpu_lib):
-    V, W0, H0 = synth(256, 600, 20)                            # K = 20: no fused kernel, and the sharded nmfsc has no other path
+def test_nmfsc_sharded_any_K_and_negative_data(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 600, 20)                            # K = 20: padded to 32 inside the library, invisible outside
+    for sW, sH in ((0.0, 0.5), (0.3, 0.0), (0.4, 0.6)):
+        i0 = {}
+        cfg = dict(W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12, W_sparsity=sW, H_sparsity=sH)
+        W, H, cost = O.nmfsc(V, 20, cfg, info=i0)
+        res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=sW, H_sparsity=sH, maxiter=8, tolerance=1e-12)
+        Hs = np.concatenate([r[1] for r in res], axis=1)
+        assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
+        assert rel_fro(res[0][0], W) <= 1e-5 and rel_fro(Hs, H) <= 1e-5 and rel_fro(res[0][2], cost) <= 1e-6
     with pytest.raises(Exception, match="fused kernels only"):
-        _nmfsc_threads(V, W0, H0, 2, H_sparsity=0.5, maxiter=2)
+        _nmfsc_threads(*synth(256, 600, 300), 2, H_sparsity=0.5, maxiter=2)   # K > 256 has no sharded path
     Vn = synth(256, 512, 64)[0]
     Vn[3, 400] = -1.0                                          # only the second shard sees it: the check is global
     W0, H0 = synth(256, 512, 64)[1:]
