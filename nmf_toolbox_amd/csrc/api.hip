@@ -319,7 +319,9 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
-    e->gram = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
+    // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
+    // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
+    e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
     e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
     if (d->path == 2 && e->algo == 1 && !e->fusedT) {

@@ -536,3 +536,15 @@ def test_nmfsc_random_shapes_fuzz(gpu_lib):
         e = dict(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
         record_err(**e)
         assert e["W"] <= TOL and e["H"] <= TOL and e["cost"] <= 1e-6, (trial, m, n, K, sW, sH, e)
+
+
+# ---- K > 256 and other shapes outside the register-stationary kernels: euclidean still runs without V_hat in HBM (Gram form on the GEMM) ----
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+@pytest.mark.parametrize("m,n,K", [(512, 768, 320), (300, 1000, 257), (640, 512, 512)])
+def test_nmf_K_above_256(gpu_lib, div, m, n, K):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12, W_sparsity=0.01)
+    ref = O.nmf(V, K, cfg)
+    _check(gpu_lib.nmf(V, K, cfg), ref)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1)), ref)
