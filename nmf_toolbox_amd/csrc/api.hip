@@ -38,6 +38,13 @@ static nmfx_status check_device(int device) {
     return NMFX_OK;
 }
 
+// every entry point leaves the caller's current HIP device as it found it (torch and MATLAB hosts keep their own idea of "current")
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct Carver {
@@ -575,6 +582,7 @@ nmfx_status nmfx_engine_packed_count(const nmfx_engine_desc *d, size_t *count) {
 nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float *W, float *H, void *workspace, size_t workspace_bytes,
                                float *packed, nmfx_engine **out) {
     if (!out || !V || !W || !H || !workspace || !packed) { set_error("nmfx_engine_create: null pointer"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     TRY(check_device(d ? d->device : 0));
     nmfx_engine *e = new nmfx_engine{};
     nmfx_status s = fill_from_desc(e, d);
@@ -624,6 +632,7 @@ nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *seg_host, 
     if (seg_host[0] != 0 || seg_host[nz] != e->n) { set_error("nmfx_engine_set_constraint: segments must cover [0, n)"); return NMFX_ERR_INVALID; }
     for (int64_t c = 0; c < nz; ++c)
         if (seg_host[c + 1] <= seg_host[c]) { set_error("nmfx_engine_set_constraint: empty segment %ld", (long)c); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->seg_dev) { (void)hipFree(e->seg_dev); e->seg_dev = nullptr; }
     std::vector<long> sg(seg_host, seg_host + nz + 1);
@@ -638,6 +647,7 @@ nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 =
 
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
 nmfx_status nmfx_engine_init(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     e->hpad_valid = false;
     if (e->algo == 3) {
@@ -666,6 +676,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
 static nmfx_status fused_wstep_tail(nmfx_engine *e);
 static nmfx_status generic_wstep_partial(nmfx_engine *e);
 nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) {
         // one pass over V: N = (V./(W*H)) * H' (KL) or V*H' (euclidean), and the cost of the current (W, H) as a by-product
@@ -694,6 +705,7 @@ static nmfx_status fused_wstep_tail(nmfx_engine *e) {
 // computes rows [c*m/nchunks, (c+1)*m/nchunks) of N into the contiguous block packed + c*(m/nchunks)*K; after the last chunk the
 // tail ([rowsum(H)] or [H*H']) and the lagged cost are ready.  wstep_finish reads the chunked layout.
 nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (!e->fused) { set_error("nmfx_engine_wstep_partial_chunk: fused path only"); return NMFX_ERR_UNSUPPORTED; }
     if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % (128L * nchunks) != 0) { set_error("nmfx_engine_wstep_partial_chunk: m must split into nchunks multiples of 128 rows"); return NMFX_ERR_INVALID; }
@@ -742,6 +754,7 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
 
 // replicated part of the W step (after the all-reduce of packed): nmf.m:168-173 / cnmf.m:193-204
 nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) {
         if (e->all_fixW) return NMFX_OK;
@@ -792,6 +805,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
 nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e);
 // H step + V_hat refresh + local cost partial: nmf.m:176-218 / cnmf.m:207-251
 nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) {
         if (e->all_fixH) return NMFX_OK;
@@ -915,6 +929,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
 // second half of the H step on the generic paths: V_hat refresh (+ cost) with the NEW H -- on a column shard the halo
 // columns of H must have been refreshed from the neighbours before this runs (V_hat near the shard edges depends on them)
 nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
@@ -930,6 +945,7 @@ nmfx_status nmfx_engine_defer_hstep_finish(nmfx_engine *e, int32_t defer) { e->d
 // make e->cost hold the cost of the CURRENT (W, H): free on the generic path (hstep already did it), one S = W*H pass on the
 // fused path unless the last wstep_partial just produced it
 nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
+    DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     if (e->cost_valid) return NMFX_OK;
     if (e->fused) return fused_wpass(e, false);
@@ -1014,7 +1030,10 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
 nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t Kc, const float *A, const float *A2,
                           int64_t lda, int32_t proA, const float *B, const float *B2, int64_t ldb, int32_t proB, float *C, int64_t ldc,
                           int32_t accumulate, void *workspace, size_t workspace_bytes) {
-    TRY(check_device(0));
+    DeviceGuard dg_;
+    hipPointerAttribute_t attr;
+    if (!C || hipPointerGetAttributes(&attr, C) != hipSuccess) { (void)hipGetLastError(); set_error("nmfx_gemm_f32: C is not a device pointer"); return NMFX_ERR_INVALID; }
+    TRY(check_device(attr.device));      // the device the buffers live on, not device 0
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.Kc = Kc;
@@ -1105,6 +1124,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         if (p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("constrainednmf: unknown divergence (constrainednmf.m:204-205)"); return NMFX_ERR_INVALID; }
     }
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     TRY(check_device(p->device));
     const int Kt = p->K_total, S = p->num_sources;
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
@@ -1280,6 +1300,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     const int N = p->n_gpus;
     if (N > NMFX_MAX_GPUS || N > p->n) { set_error("n_gpus = %d: at most %d devices and one column per device", N, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     MultiDev M;
     for (int g = 0; g < N; ++g) {
         M.dev[g] = p->device_ids ? p->device_ids[g] : g;
@@ -1459,6 +1480,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     else if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    DeviceGuard dg_;
     TRY(check_device(p->device));
     hipStream_t st = dev ? dev->st : nullptr;
     g_sc_prof.st = st;
@@ -1847,6 +1869,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    DeviceGuard dg_;
     TRY(check_device(p->device));
     hipStream_t st = nullptr;
     double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity, L1a = 0, L1s = 0;
@@ -2027,6 +2050,7 @@ nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_d
                            nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r) {
     if (!p || !r || !V_dev || !W_dev || !H_dev || !r->cost) { set_error("nmfx_nmfsc_dev: null argument"); return NMFX_ERR_INVALID; }
     if (p->m <= 0 || p->n <= 0 || p->K_total <= 0 || p->maxiter <= 0 || n_total < p->n) { set_error("nmfx_nmfsc_dev: bad sizes"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     ScDev d{};
     d.V = V_dev; d.W = W_dev; d.H = H_dev; d.n_total = n_total; d.st = static_cast<hipStream_t>(stream);
     d.comm.fn = allreduce; d.comm.ctx = allreduce_ctx; d.comm.st = d.st;
@@ -2037,6 +2061,7 @@ nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmf
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W, const void *H, void *V_hat,
                              int32_t device) {
     if (m <= 0 || n <= 0 || K <= 0 || T <= 0 || !W || !H || !V_hat) { set_error("nmfx_reconstruct: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     TRY(check_device(device));
     const size_t mn = (size_t)m * n, mKT = (size_t)m * K * T, Kn = (size_t)K * n;
     DevBuf Wd, Hd, Vd, stage;
@@ -2061,6 +2086,7 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
                                  int32_t *order_out, int32_t device) {
     if (m <= 0 || K <= 0 || !W || !W_sorted || (H && (!H_sorted || n <= 0))) { set_error("nmfx_sort_dictionary: bad arguments"); return NMFX_ERR_INVALID; }
     if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     TRY(check_device(device));
     const size_t es = dsize(dtype), wb = (size_t)m * K * es, hb = H ? (size_t)K * n * es : 0;
     DevBuf Wd, Ws, Hd, Hs, cog, ord;
@@ -2105,6 +2131,7 @@ nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag) 
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,
                           int32_t *usediters, int32_t device) {
     if (N <= 0 || count <= 0 || !s || !v) { set_error("nmfx_projfunc: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
     TRY(check_device(device));
     if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("nmfx_projfunc: dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
     const size_t tot = (size_t)N * count;

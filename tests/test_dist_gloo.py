@@ -113,6 +113,20 @@ class NumpyShard:
         dst[0] = self.cost_local
 
 
+class NumpyShardMerged(NumpyShard):
+    """the same phases behind the one-call-per-iteration entry point (nmfx_engine_between_allreduces)"""
+
+    def between_allreduces(self, last):
+        self.wstep_finish()
+        self.hstep()
+        if not last:
+            if not self.cost_lags:
+                saved = self.cost_local          # the generic path's cost belongs to the H step just done, not to the next partial
+            self.wstep_partial()
+            if not self.cost_lags:
+                self.cost_local = saved
+
+
 def _worker(rank, world, port, div, layout, iters, q, n_chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -125,7 +139,9 @@ def _worker(rank, world, port, div, layout, iters, q, n_chunks=1):
     fixW = np.array([0, 0, 0, 0, 1, 1])
     fixH = np.array([1, 1, 0, 0, 0, 0])
     lo, hi = shard_columns(n, world, rank)
-    be = NumpyShard(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0, n_chunks)
+    cls = NumpyShardMerged if n_chunks == 0 else NumpyShard          # n_chunks == 0 selects the merged-call loop
+    n_chunks = max(n_chunks, 1)
+    be = cls(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0, n_chunks)
     cost = torch.zeros(iters, dtype=torch.float64)
     run_sharded_iterations(be, iters, dist, None, cost)
     q.put((rank, lo, hi, be.W, be.H, cost.numpy().copy()))
@@ -142,7 +158,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
-@pytest.mark.parametrize("layout,n_chunks", [("generic", 1), ("fused", 1), ("fused", 3)])
+@pytest.mark.parametrize("layout,n_chunks", [("generic", 1), ("fused", 1), ("fused", 3), ("generic", 0), ("fused", 0)])
 def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks):
     from oracle import nmf_oracle as O
     world, iters = 2, 12
