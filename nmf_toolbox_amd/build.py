@@ -44,7 +44,7 @@ def _newer(src_list, target):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INC, "nmfx.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INC, "nmfx.h"), os.path.abspath(__file__)]   # + this file: the flags live here
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -54,9 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer([src] + hdrs, obj):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed",
                    "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
-            if os.path.basename(src).startswith("fused_cnmf"):
-                # K = Kh*T = 512 bodies hold 512 MFMAs per tile: past clang's default budget for `#pragma unroll`, and a partially
-                # unrolled loop indexes the accumulator arrays dynamically (scratch)
+            if os.path.basename(src).startswith("fused_"):
+                # the biggest tile bodies (K = Kh*T = 512: 512 MFMAs; the dual-map kernels at K = 96 / 128) are past clang's default
+                # budget for `#pragma unroll`, and a partially unrolled loop indexes the accumulator arrays dynamically (wrong
+                # schedule at best; the K = 96 dual H-step kernel came out with 192 of its 288 MFMAs and wrong results)
                 cmd[3:3] = ["-mllvm", "-pragma-unroll-threshold=1000000"]
             if verbose:
                 print(" ".join(cmd), flush=True)

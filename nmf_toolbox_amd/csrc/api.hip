@@ -137,6 +137,9 @@ struct nmfx_engine {
     int n_cost_partials, n_cost_used;
     // fused path (fused.hip): V_hat is never materialised
     bool fused, cost_valid, defer_hfinish;
+    bool dual;                // fused IS / alpha-beta: packed = [N | P], both contractions of a pass come out of one kernel (func 4 / 5)
+    float *slabs2, *Valpha;   // dual: slabs of the second contraction; alpha-beta with alpha ~= 1: V.^alpha (the kernels' data operand)
+    double *sumVab;           // dual: the constant of the cost (IS: 0; alpha-beta: sum(V.^(alpha+beta)), nmf.m:214)
     bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
     float *CC;                // KT x KT Gram of the stacked W (gram path)
     // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
@@ -220,9 +223,11 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->WT = f.take<float>(mKT);
         // row-chunked W steps use more splits on fewer rows: rows*split per launch never exceeds max(nsplit_w, 2) * m / 2
         e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
+        e->slabs2 = e->dual ? f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn)) : nullptr;
+        e->Valpha = (e->dual && e->div == NMFX_DIV_AB && e->alpha != 1.0) ? f.take<float>((size_t)e->m * e->n) : nullptr;
         e->Gn = f.take<float>(Kn);
         const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
-        e->Gp = euc ? f.take<float>(Kn) : nullptr;
+        e->Gp = (euc || e->dual) ? f.take<float>(Kn) : nullptr;
         e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
         e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
         size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
@@ -237,9 +242,10 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->cost_partials = f.take<double>(e->n_cost_partials);
         e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
         e->sumV = f.take<double>(1);
+        e->sumVab = f.take<double>(1);
         e->colV = f.take<double>(e->n);
         L.total = f.off;
-        L.packed_count = euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT;
+        L.packed_count = e->dual ? 2 * mKT : (euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT);
         return L;
     }
     if (e->gram) {
@@ -319,13 +325,16 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_INVALID;
     }
     // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
-    const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN) && fused_supported(e->K) &&
+    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps and two accumulator sets per pass: K <= 128
+    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 128;
+    const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
                           e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
     if (d->path == 2 && !eligible) {
         set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf / lnmf / constrainednmf rules, kl or euclidean, K a multiple of 32 up to 256)");
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
+    if (!e->fused) e->dual = false;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
@@ -452,6 +461,19 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
     }
     double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
     if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
+    if (e->fused && e->dual) {
+        // fused IS: partials hold sum(V./V_hat - log(V./V_hat)); nmf.m:212 subtracts 1 per element.  Fused alpha-beta: partials hold
+        // sum(V.^a.*V_hat.^b - b/(a+b)*V_hat.^(a+b)); nmf.m:214 subtracts (a*sum(V.^(a+b)) + b*m*n) / (a+b) inside the scaled sum
+        const double cnt = (double)e->m * (double)e->n;
+        double pa = 0.0, pb = -cnt;
+        if (mdiv(e) == NMFX_DIV_AB) {
+            const double ab = e->alpha + e->beta;
+            if (ab != 0) { pa = -e->alpha / ab; pb = -e->beta * cnt / ab; }
+            else { pa = 0.0; pb = -((e->alpha + 2.0 * e->beta) * cnt) / ab; }   // nmf.m:214 divides by alpha + beta: +-Inf cost, like the reference
+        }
+        return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
+                           e->lamH, e->cost, nullptr, nullptr, 0, nullptr, mdiv(e) == NMFX_DIV_AB ? e->sumVab : nullptr, pa, pb);
+    }
     // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
                        e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV);
@@ -486,7 +508,16 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
     f.out = split == 1 ? out : e->slabs;
     f.slab_stride = rows * (long)e->K; f.os_r = 1; f.os_k = rows;
     f.cost_partials = e->cost_partials + e->chunk_parts;
-    const int func = e->div == NMFX_DIV_KL ? 3 : 1;
+    int func = e->div == NMFX_DIV_KL ? 3 : 1;
+    float *out2 = nullptr;
+    if (e->dual) {   // IS / alpha-beta: the denominators come out of the same pass, into the second half of `packed`
+        if (rows != e->m) { set_error("fused IS / alpha-beta W step: row chunks are not supported"); return NMFX_ERR_UNSUPPORTED; }
+        func = mdiv(e) == NMFX_DIV_IS ? 4 : 5;
+        out2 = out + (size_t)e->m * e->K;
+        f.out2 = split == 1 ? out2 : e->slabs2;
+        f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = 1.0f;
+        if (e->Valpha) f.D = e->Valpha + row0;
+    }
     {
         Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
         TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
@@ -495,6 +526,7 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
     if (do_g2 && split > 1) {
         Scope s(e, TAG_SMALL);
         TRY(reduce_slabs(e->st, e->slabs, split, f.slab_stride, f.slab_stride, out, 0));
+        if (e->dual) TRY(reduce_slabs(e->st, e->slabs2, split, f.slab_stride, f.slab_stride, out2, 0));
     }
     return NMFX_OK;
 }
@@ -665,6 +697,11 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
                 TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumV));
             }
+            if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
+                TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
+                TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
+                if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+            }
             return refresh_w_derived(e);
         }
     }
@@ -690,6 +727,7 @@ nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
 // what follows the last row chunk of a fused W-step partial: the small tail of `packed`
 static nmfx_status fused_wstep_tail(nmfx_engine *e) {
     const size_t mKT = (size_t)e->m * e->KT;
+    if (e->dual) return NMFX_OK;   // [N | P] is complete: both halves came out of the pass
     if (e->div == NMFX_DIV_KL) {
         Scope s(e, TAG_SMALL);
         TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
@@ -707,7 +745,7 @@ static nmfx_status fused_wstep_tail(nmfx_engine *e) {
 nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks) {
     DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
-    if (!e->fused) { set_error("nmfx_engine_wstep_partial_chunk: fused path only"); return NMFX_ERR_UNSUPPORTED; }
+    if (!e->fused || e->dual) { set_error("nmfx_engine_wstep_partial_chunk: fused kl / euclidean path only"); return NMFX_ERR_UNSUPPORTED; }
     if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % (128L * nchunks) != 0) { set_error("nmfx_engine_wstep_partial_chunk: m must split into nchunks multiples of 128 rows"); return NMFX_ERR_INVALID; }
     const long rows = e->m / nchunks;
     if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; }
@@ -721,7 +759,7 @@ nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchu
     if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % nchunks != 0) { set_error("nmfx_engine_packed_chunk: bad chunk"); return NMFX_ERR_INVALID; }
     const size_t per = (size_t)(e->m / nchunks) * e->KT, mKT = (size_t)e->m * e->KT;
     size_t tail = 0;
-    if (e->fused) tail = e->div == NMFX_DIV_EUCLIDEAN ? (size_t)e->K * e->K : (size_t)e->KT;
+    if (e->fused) tail = e->dual ? mKT : (e->div == NMFX_DIV_EUCLIDEAN ? (size_t)e->K * e->K : (size_t)e->KT);
     else if (nchunks != 1) { set_error("nmfx_engine_packed_chunk: only the fused path chunks its W step"); return NMFX_ERR_UNSUPPORTED; }
     else tail = e->gram ? (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? mKT : (size_t)e->KT);
     *offset = per * chunk;
@@ -763,7 +801,10 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = 1;
         p.n_chunks = e->w_chunks > 1 ? e->w_chunks : 1;   // row-chunked partial: N is stored as contiguous (m/chunks x K) blocks
         p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
-        if (e->div == NMFX_DIV_KL) {
+        if (e->dual) {
+            p.P = e->packed + mK;       // nmf.m:155-156,162-163: the all-reduced denominators
+            p.inv_exp = outer_exp(e);
+        } else if (e->div == NMFX_DIV_KL) {
             Scope s(e, TAG_SMALL);
             p.Pvecf = e->packed + mK;   // the all-reduced rowsum(H), still fp32 as it travelled
         } else {
@@ -821,8 +862,12 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         f.X = e->H; f.xs_r = e->K; f.xs_k = 1;
         f.Y = e->WT; f.D = e->V; f.ldd = e->m; f.R = e->n; f.Cn = e->m; f.K = e->K;
         f.c_per_split = e->cps_h;
-        const int func = e->div == NMFX_DIV_KL ? 2 : 0;
+        const int func = e->dual ? (mdiv(e) == NMFX_DIV_IS ? 4 : 5) : (e->div == NMFX_DIV_KL ? 2 : 0);
         const bool kl = e->div == NMFX_DIV_KL;
+        if (e->dual) {
+            f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = outer_exp(e);
+            if (e->Valpha) f.D = e->Valpha;
+        }
         static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
         if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
@@ -845,6 +890,20 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
             TRY(launch_fused(e->st, f, 1, false, func, true, 1));
+        } else if (e->dual) {   // split over the rows of W, or constrainednmf: numerator and denominator slabs, then the generic update
+            f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.out2 = e->isplit_h == 1 ? e->Gp : e->slabs2;
+            f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
+            {
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            if (e->isplit_h > 1) {
+                TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+                TRY(reduce_slabs(e->st, e->slabs2, e->isplit_h, f.slab_stride, f.slab_stride, e->Gp, 0));
+            }
+            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
         } else {
             f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
             {
@@ -1015,9 +1074,10 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
         if (e->fusedT) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
+        if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
-    case TAG_FUSED_H: *flops = (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_H: *flops = (e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
     case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
     }
@@ -1130,8 +1190,9 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
+    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;   // fused IS / alpha-beta: K <= 128
     const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 &&
-                     (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN);
+                     (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
     std::vector<float> lw(K, 0.f), lh(K, 0.f);
     std::vector<uint8_t> fw(K, 0), fh(K, 0);
@@ -1323,7 +1384,8 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
     long nmin = n;
     for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
-    const bool pad = Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN);
+    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;
+    const bool pad = Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
     std::vector<float> lw(K, 0.f), lh(K, 0.f);
     std::vector<uint8_t> fw(K, 0), fh(K, 0);

@@ -145,6 +145,33 @@ nmfx_status col_reduce(hipStream_t st, const float *X, long rows, long ld, int n
     return NMFX_OK;
 }
 
+// out[c] = sum_i X[i + ld*c].^e in fp64 (alpha-beta cost constant sum(V.^(alpha+beta)), nmf.m:214); MATLAB power semantics for e in {0, 1}
+__global__ __launch_bounds__(256) void col_reduce_pow_kernel(const float *X, long rows, long ld, float e, double *out) {
+    __shared__ double red[4];
+    const float *x = X + ld * blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < rows; i += 256) s += (double)(e == 0.0f ? 1.0f : (e == 1.0f ? x[i] : powf(x[i], e)));
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out) {
+    if (ncols <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(col_reduce_pow_kernel, dim3(ncols), dim3(256), 0, st, X, rows, ld, e, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// out = in.^e
+__global__ void pow_map_kernel(const float *in, float *out, long count, float e) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) out[idx] = powf(in[idx], e);
+}
+nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(pow_map_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, out, count, e);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // ---- row reductions: out[k] = sum_j f(X[k + ld*j]); two deterministic stages ---------------------
 constexpr int RR_BLOCKS = 256;
 __global__ __launch_bounds__(256) void row_reduce_stage1(const float *X, int rows, long ld, long ncols, int mode, double *part) {
@@ -498,11 +525,14 @@ nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long 
 // cost = scale * sum(partials) + sum_c lamW[c%K]*l1W[c] + sum_k lamH[k]*l1H[k]      nmf.m:206-218
 __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials, int count, double scale, const double *l1W, int nW,
                                                           const float *lamW, const double *l1H, int K, const float *lamH, double *out,
-                                                          const double *dotA, const double *dotB, int ndot, const double *minus) {
+                                                          const double *dotA, const double *dotB, int ndot, const double *minus, const double *pre_c,
+                                                          double pre_a, double pre_b) {
     __shared__ double red[4];
     double s = 0.0, t = 0.0;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
-    s = block_sum<4>(s, red) * scale;   // scale may be -Inf (alpha-beta divergence with alpha*beta == 0, nmf.m:214): apply it to the SUM
+    s = block_sum<4>(s, red);
+    if (pre_c || pre_b != 0.0) s += pre_a * (pre_c ? *pre_c : 0.0) + pre_b;   // constants of the divergence inside the scaled sum (fused IS / alpha-beta)
+    s *= scale;   // scale may be -Inf (alpha-beta divergence with alpha*beta == 0, nmf.m:214): apply it to the SUM
     if (l1W) for (int c = threadIdx.x; c < nW; c += 256) t += (double)lamW[c % K] * l1W[c];
     if (l1H) for (int k = threadIdx.x; k < K; k += 256) t += (double)lamH[k] * l1H[k];
     if (dotA) for (int k = threadIdx.x; k < ndot; k += 256) t += dotA[k] * dotB[k];   // closed-form sum(V_hat) of the KL cost
@@ -511,9 +541,9 @@ __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials
 }
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA, const double *dotB, int ndot,
-                        const double *minus) {
+                        const double *minus, const double *pre_c, double pre_a, double pre_b) {
     hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, l1W, nW, lamW, l1H, K, lamH, out, dotA, dotB,
-                       ndot, minus);
+                       ndot, minus, pre_c, pre_a, pre_b);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

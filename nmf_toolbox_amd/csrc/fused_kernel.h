@@ -24,6 +24,8 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 }
 
 // FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
+//       4 IS (nmf.m:155-156,186-187,212): TWO element maps per pass, A = V./S.^2 and B = 1./S, two accumulator sets (K <= 128)
+//       5 alpha-beta, alpha ~= 0 (nmf.m:162-163,193-194,214): A = V.^alpha .* S.^(beta-1), B = S.^(alpha+beta-1); D holds V.^alpha
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -34,7 +36,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 // row c of the tile starts at LDS row c; nothing is replicated.  p.Y must be preceded by TT-1 readable columns (zeros, or the left
 // halo of a column shard).  X / out slice t = TT-1-p lives at xs_t / os_t.
 template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool RAG = false, int TT = 1>
-__global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
+__global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(TT == 1 || (D_RC && EPI == 0 && (K / TT) % 32 == 0 && K % TT == 0), "TT > 1: W-step form, K/TT a multiple of 32");
     constexpr int KH = K / TT;             // floats per column of H
@@ -43,6 +45,9 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
     constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
+    constexpr bool DUAL = FUNC >= 4;       // two element maps, two accumulator sets
+    constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
+    static_assert(!DUAL || (K <= 128 && TT == 1), "dual-map kernels: K <= 128 (two accumulator sets + the stationary operand must fit 512 VGPRs)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
     // LDS float offset of contraction index kq (a multiple of 4 or of 32, never straddling a block of KH) relative to the row of streamed index c
@@ -71,10 +76,16 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
     }
 
     f32x16 acc[DO_G2 ? NKB : 1];
+    f32x16 acc2[(DO_G2 && DUAL) ? NKB : 1];   // second contraction of the dual-map divergences (the denominators)
 #pragma unroll
     for (int kb = 0; kb < (DO_G2 ? NKB : 1); ++kb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[kb][e] = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < ((DO_G2 && DUAL) ? NKB : 1); ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[kb][e] = 0.0f;
+    const float ab_e1 = p.ab_beta - 1.0f, ab_e2 = p.ab_alpha + p.ab_beta - 1.0f, ab_kappa = (p.ab_alpha + p.ab_beta) == 0.0f ? 0.0f : p.ab_beta / (p.ab_alpha + p.ab_beta);   // FUNC 5 (alpha + beta == 0: the caller reproduces the reference's division by zero)
 
     // ---- loads.  f32 MFMA shares the SIMD with VALU (every VALU instruction in the loop costs MFMA time), so all per-tile
     // addressing is wave-uniform (SGPR buffer descriptor + SGPR offset) plus ONE per-lane byte offset computed here.
@@ -178,15 +189,34 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
         // MFMAs, LDS operands are fetched one step ahead, and a sched_barrier after every MFMA pins this order (left
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
+        f32x16 sacc2[DUAL ? 2 : 1];                           // the second map's tile (B)
         float tc = 0.0f;
         const int cvh = RAG ? tile_rows(t) - 4 * h : 0;       // streamed index 32*jb + (reg&3) + 8*(reg>>2) + 4*h of this tile is real iff its h-free part < cvh
-        float es[2], er[2];                                   // element-map pipeline state: S value, reciprocal / quotient
+        float es[2], er[2], eq[2];                            // element-map pipeline state: S value, reciprocal / quotient, third temporary
         auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
             const int sl = reg & 1;
             if (PROBE & 2) { if (u == 0) asm volatile("" : "+v"(sacc[jb][reg])); return; }
             const float v = d[jb * 16 + reg];
             const bool live = !RAG || (32 * jb + (reg & 3) + 8 * (reg >> 2)) < cvh;   // streamed index inside the matrix
-            if (FUNC >= 2) {
+            if (FUNC == 4) {                                  // IS: B = 1./S, A = V./S.^2, cost terms q - ln(q) with q = V./S (the -1 per element: caller)
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
+                if (u == 1) eq[sl] = v * er[sl];
+                if (u == 2) sacc2[jb][reg] = live ? er[sl] : 0.0f;
+                if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
+                if (u == 4) er[sl] = __builtin_amdgcn_logf(eq[sl]);                  // log2(q)
+                if (u == 5) tc = live ? tc + eq[sl] : tc;
+                if (u == 6) tc = live ? fmaf(-0.6931471805599453f, er[sl], tc) : tc;
+                if (u == 5 || u == 6) asm volatile("" : "+v"(tc));
+            } else if (FUNC == 5) {                           // alpha-beta: B = S.^(a+b-1), A = V.^a .* S.^(b-1); cost terms S.*(A - b/(a+b)*B)
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_logf(es[sl]); }   // log2(S)
+                if (u == 1) eq[sl] = ab_e1 * er[sl];
+                if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
+                if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)
+                if (u == 4) { eq[sl] = v * eq[sl]; sacc[jb][reg] = live ? eq[sl] : 0.0f; }
+                if (u == 5) sacc2[jb][reg] = live ? er[sl] : 0.0f;
+                if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
+                if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
                 if (FUNC == 3) {
@@ -201,12 +231,12 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             }
             if ((FUNC == 1 && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
-        // fillers behind the i-th MFMA of a phase with M = K/2 MFMAs that hosts the 16 elements x 4 micro-ops of half jb: slot i runs
-        // micro-ops [64*i/M, 64*(i+1)/M) in element order (one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
+        // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
+        // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
         auto emap_fill = [&](int jb, int i, int M) {
-            const int q0 = 64 * i / M, q1 = 64 * (i + 1) / M;
+            const int q0 = 16 * NU * i / M, q1 = 16 * NU * (i + 1) / M;
 #pragma unroll
-            for (int q = q0; q < q1; ++q) emap_u(jb, q >> 2, q & 3);
+            for (int q = q0; q < q1; ++q) emap_u(jb, q / NU, q % NU);
         };
         auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + kofs(8 * g) + 4 * h); };
         if (NEED_S) {
@@ -249,13 +279,19 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
                 const int jb = st >> 4, reg = st & 15;
                 if (st + 1 < 32) g2_read((st + 1) >> 4, (st + 1) & 15, y_nxt);
                 const float rr = sacc[jb][reg];
+                const float rr2 = DUAL ? sacc2[jb][reg] : 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
-                    if (jb == 0) emap_fill(1, reg * NKB + kb, 16 * NKB);       // element map of half 1 under the MFMAs of half 0
+                    if (jb == 0) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
                     if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 32);   // no first product: the DMA rides here
                     if (kb == NKB / 2 && jb == 1) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4
                     __builtin_amdgcn_sched_barrier(0);
+                    if (DUAL) {
+                        acc2[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr2, acc2[kb], 0, 0, 0);
+                        if (jb == 0) emap_fill(1, (reg * NKB + kb) * 2 + 1, 32 * NKB);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) y_cur[kb] = y_nxt[kb];
@@ -264,7 +300,7 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) emap_u(1, reg, u);
+                for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
 #pragma unroll
             for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
         }
@@ -280,7 +316,11 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
-                    if (row_ok) out[r * p.os_r + (long)((32 * kb) % KH + rowmap(reg, h)) * p.os_k + (long)(TT - 1 - (32 * kb) / KH) * p.os_t] = acc[kb][reg];
+                    if (row_ok) {
+                        const long oi = r * p.os_r + (long)((32 * kb) % KH + rowmap(reg, h)) * p.os_k + (long)(TT - 1 - (32 * kb) / KH) * p.os_t;
+                        out[oi] = acc[kb][reg];
+                        if (DUAL) p.out2[(long)blockIdx.y * p.slab_stride + oi] = acc2[kb][reg];
+                    }
         } else {
             // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
 #pragma unroll
@@ -291,8 +331,14 @@ __global__ __launch_bounds__(256, (K <= 128 ? 2 : 1)) void fused_kernel(const Fu
                     if (!row_ok || (p.fix && p.fix[k])) continue;
                     const long idx = (long)k + (long)K * r;
                     if (p.sqrt_rule) { p.Hio[idx] = sqrtf(p.Hio[idx] * acc[kb][reg]); continue; }   // lnmf.m:76
-                    const float den = p.den ? p.den[idx] : (float)p.denvec[k];
                     const float lam = p.lam ? p.lam[k] : 0.0f;
+                    if (DUAL) {   // nmf.m:186-187,193-194 + 199: numerator and denominator both come out of this pass; outer .^(1/alpha) for alpha-beta
+                        float gn = acc[kb][reg], gp = acc2[kb][reg];
+                        if (p.inv_exp != 1.0f) { gn = powf(gn, p.inv_exp); gp = powf(gp, p.inv_exp); }
+                        p.Hio[idx] = p.Hio[idx] * (gn / fmaxf(gp + lam, NMFX_EPS_F));
+                        continue;
+                    }
+                    const float den = p.den ? p.den[idx] : (float)p.denvec[k];
                     p.Hio[idx] = p.Hio[idx] * (acc[kb][reg] / fmaxf(den + lam, NMFX_EPS_F));
                 }
         }

@@ -111,6 +111,9 @@ struct FusedParams {
     long c_per_split;     // streamed rows per grid.y slice (multiple of 64)
     int K;
     float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
+    float *out2;          // func 4 / 5 (dual-map divergences), EPI 0: the second contraction (denominators), same indexing
+    float ab_alpha, ab_beta;   // func 5
+    float inv_exp;        // func 4 / 5, EPI 1: outer exponent 1/alpha of nmf.m:193-194 (1 = none); set it to 1 for func 4
     long slab_stride, os_r, os_k;
     double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr.  Euclidean: sum (V-S)^2.  KL: sum V.*log(V./S) ONLY -- the caller adds
                             // sum(S) - sum(V) = sum_k colsum(W)_k*rowsum(H)_k - sum(V) in closed form (two fewer VALU ops per element
@@ -124,7 +127,7 @@ struct FusedParams {
 };
 bool fused_supported(int K);
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
-// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost;  do_g2=false: cost-only pass
+// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128);  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
 // ---- small kernels (aux.hip) ----------------------------------------------------------------
@@ -170,7 +173,10 @@ nmfx_status center_of_gravity(hipStream_t st, const void *W, int is_f64, long m,
 nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long rows, long cols, const int *order, int by_rows);
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA = nullptr, const double *dotB = nullptr,
-                        int ndot = 0, const double *minus = nullptr);   // + sum_k dotA[k]*dotB[k] - *minus
+                        int ndot = 0, const double *minus = nullptr,    // + sum_k dotA[k]*dotB[k] - *minus
+                        const double *pre_c = nullptr, double pre_a = 0.0, double pre_b = 0.0);   // scale * (sum(partials) + pre_a * *pre_c + pre_b)
+nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out);
+nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
 nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
