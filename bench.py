@@ -39,6 +39,7 @@ WORKLOADS = {
     "c2": ("nmf", "euclidean", 8192, 32768, 128, 1, 12.0),
     "c4": ("cnmf", "euclidean", 4096, 16384, 64, 8, 12.0),
     "c4kl": ("cnmf", "kl", 4096, 16384, 64, 8, 16.0),          # config 4's shape with the KL divergence (materialised V_hat; dev aid)
+    "c2is": ("nmf", "is", 8192, 32768, 128, 1, 12.0),         # config 2's shape with the Itakura-Saito divergence (dual-map fused kernels; dev aid)
     "c5": ("nmfsc", "euclidean", 8192, 32768, 128, 1, 12.0),   # H_sparsity 0.5; F_alg = (5 + tries)*2mnK = 12 mnK at one try per line search
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
     "c3_shard8": ("nmf", "kl", 16384, 8192, 256, 1, 8.0),     # what ONE of 8 ranks holds at c3 (dev aid for the small-kernel overheads)
