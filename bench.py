@@ -364,6 +364,7 @@ def main():
             "config": {"workload": "%s.m %s MU, V=%dx%d K=%d%s fp32, V column-sharded over %d GPU(s)" % (alg, div, m, n, K, (" T=%d" % T) if T > 1 else "", world),
                        "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
                        "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
+                                3: "fused cnmf passes, shift-sum in LDS + Gram denominators (V_hat never materialised)",
                                 0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),

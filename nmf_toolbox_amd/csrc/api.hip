@@ -1011,7 +1011,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->gram ? 2 : 0); }   // 1 fused kernels, 2 Gram-form cnmf, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT ? 3 : (e->gram ? 2 : 0)); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
