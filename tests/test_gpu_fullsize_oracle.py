@@ -64,6 +64,15 @@ def test_c3_full_kl(gpu_lib):
     cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
     got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
     _report("C3 16384x65536 K=256 kl", got, ref, tg, tc, wh=False)
+    # the advisor's point about the ABSOLUTE stop rule (nmf.m:221, default tolerance 1e-3): at this size the fp32 path's cost differs from
+    # float64 by a few units (1e8 * 5e-8), almost all of it a bias common to consecutive iterations; what the stop rule sees is the error of
+    # the DIFFERENCE cost(i-1) - cost(i), recorded here.  It is far above 1e-3 -- and far below the decreases of ~1e5 per iteration that
+    # this problem still makes at iteration 2, so the rule's decision is the reference's ("Cost precision and the stop rule")
+    abs_err = np.abs(got[2] - ref[2])
+    diff_err = abs((got[2][0] - got[2][1]) - (ref[2][0] - ref[2][1]))
+    record_err(cost_abs=float(abs_err.max()), cost_diff_abs=float(diff_err))
+    print("[C3 full] |cost - cost_f64| = %s, error of the decrease cost(1)-cost(2): %.3g (decrease %.4g)" % (abs_err, diff_err, ref[2][0] - ref[2][1]))
+    assert diff_err < 1e-3 * (ref[2][0] - ref[2][1])
     # W*H on a 2048-column sample (the full product would be another 8 GiB pair)
     j = np.arange(0, n, 32)
     e = rel_fro(got[0] @ got[1][:, j], ref[0] @ ref[1][:, j])
