@@ -579,3 +579,32 @@ def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
     _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_gpus=[0, 0, 0])), ref, cost_tol=1e-5)          # [N | P] through the peer exchange on three shards
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.nmf(V, 160, dict(divergence="is", maxiter=1, nmfx_path=2))                   # two accumulator sets: K <= 128 only
+
+
+# ---- cnmf on the register-stationary kernels (fused_kernel TT > 1): every instantiated (K, T) pair, aligned and ragged shapes, sparsity,
+# fixed factors, 'frobenius' (no cost); against the oracle and against the GEMM formulations -----------------------------------------
+@pytest.mark.parametrize("K,T", [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4)])
+@pytest.mark.parametrize("m,n", [(256, 512), (129, 333), (640, 65)])
+def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.cnmf(V, K, T, cfg)
+    fused = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))          # 2 = the fused passes or an error
+    _check(fused, ref)
+    _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1)), ref)     # materialised V_hat
+    assert np.allclose(np.sqrt((fused[0] ** 2).sum((0, 2))), T, rtol=1e-5)
+
+
+def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(192, 400, 64, T=4)
+    for extra in (dict(W_fixed=True), dict(H_fixed=True), dict(divergence="frobenius")):
+        cfg = dict(dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=5, tolerance=1e-12), **extra)
+        _check(gpu_lib.cnmf(V, 64, 4, dict(cfg, nmfx_path=2)), O.cnmf(V, 64, 4, cfg))
+    cfg = dict(W_init=[W0[:, :24], W0[:, 24:]], H_init=[H0[:24], H0[24:]], W_sparsity=[0.05, 0.0], H_fixed=[False, True], maxiter=5, tolerance=1e-12)
+    _check(gpu_lib.cnmf(V, [24, 40], 4, dict(cfg, nmfx_path=2)), O.cnmf(V, [24, 40], 4, cfg))
+    with pytest.raises(Exception, match="not eligible"):
+        gpu_lib.cnmf(V, 64, 4, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean
+    with pytest.raises(Exception, match="not eligible"):
+        gpu_lib.cnmf(V[:, :300], 48, 4, dict(maxiter=1, nmfx_path=2))                                   # (48, 4) is not instantiated

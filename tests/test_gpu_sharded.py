@@ -233,7 +233,8 @@ def _emulated_halo_exchange(engs, T):
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
-@pytest.mark.parametrize("nshards,m,n,K,T", [(2, 96, 200, 6, 4), (3, 128, 333, 8, 5), (2, 128, 333, 8, 5)])
+@pytest.mark.parametrize("nshards,m,n,K,T", [(2, 96, 200, 6, 4), (3, 128, 333, 8, 5), (2, 128, 333, 8, 5),
+                                             (2, 256, 520, 64, 4), (3, 192, 777, 32, 8), (4, 129, 1024, 64, 2)])   # the last three: fused shift-sum passes, halos as the left context
 def test_cnmf_shards_with_halos_equal_oracle(gpu_lib, div, nshards, m, n, K, T):
     import torch
     from oracle import nmf_oracle as O
