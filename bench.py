@@ -365,6 +365,7 @@ def main():
                        "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
                        "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
                                 3: "fused cnmf passes, shift-sum in LDS + Gram denominators (V_hat never materialised)",
+                                4: "fused cnmf passes, shift-sum in LDS; R = V./V_hat in HBM, V_hat never",
                                 0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),

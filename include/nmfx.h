@@ -232,6 +232,7 @@ nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchu
 /* make the engine's cost refer to the CURRENT (W, H): no-op when it already does, else one fused S = W*H pass */
 nmfx_status nmfx_engine_cost_pass(nmfx_engine *e);
 int32_t nmfx_engine_is_fused(nmfx_engine *e);   /* 1 = fused kernels (cost lags one pass), 3 = cnmf on the fused shift-sum passes (Gram denominators),
+                                                   4 = KL cnmf on the fused passes (cost lags one pass, R = V./V_hat in HBM),
                                                    2 = Gram form on the GEMM (no V_hat in HBM), 0 = materialised V_hat */
 /* device pointer to the fp64 cost of the last hstep for the local shard: data-fit partial + lambda*L1 terms
  * (the W term is included only when the engine is rank 0, see nmfx_engine_set_rank0); sum over ranks = nmf.m:206-218 */

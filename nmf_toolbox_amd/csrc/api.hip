@@ -145,6 +145,9 @@ struct nmfx_engine {
     // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
     // H-step numerator as ONE (KT x n x m) GEMM Q = W_flat' * V followed by the shift-sum over t
     bool fusedT, hpad_valid;
+    bool fusedT_kl;           // KL cnmf on the fused passes: an S pass stores R = V./V_hat (in the V_hat buffer) and yields the cost of the state it
+                              // started from (lagged, like the nmf fused path); the numerator passes then read R instead of V
+    double *sumV_g, *colV_g;  // its closed-form cost term sum(V)
     bool qgemm;               // cnmf, T > 1: H-step numerator sum_t W_t' * lshift_t(A) as ONE (KT x n x m) GEMM Q = W_flat' * A + a shift-sum over t
     float *Hpad, *Qbuf, *slabsT;
     int nsplit_T;
@@ -262,6 +265,14 @@ Layout layout(nmfx_engine *e, void *ws) {
         }
     }
     if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
+    if (e->fusedT_kl) {
+        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
+        const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        e->sumV_g = c.take<double>(1);
+        e->colV_g = c.take<double>(e->n);
+    }
     L.total = c.off;
     L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
     return L;
@@ -340,11 +351,13 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
     e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
-    if (d->path == 2 && e->algo == 1 && !e->fusedT) {
-        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean, T > 1, an instantiated (K, T) pair)");
+    e->fusedT_kl = !e->fused && e->algo == 1 && e->div == NMFX_DIV_KL && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 &&
+                   e->hL == 0 && e->hR == 0 && d->path != 1 && !no_fusedT;
+    if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl) {
+        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or unsharded kl, T > 1, an instantiated (K, T) pair)");
         return NMFX_ERR_UNSUPPORTED;
     }
-    if (e->fusedT) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
     static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
     e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
     e->nsplit_w = e->isplit_h = 1;
@@ -547,7 +560,9 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
 
 // cnmf fused passes (fused_kernel TT > 1) over the local columns: do_g2 -> N_all = V * H_stack' into `out` (m x KT), else the residual cost
 // partials of the CURRENT (W, H).  H's T-1 columns to the left of the shard are its halo, or zeros (Hpad) on the first / only shard.
-nmfx_status fusedT_pass(nmfx_engine *e, bool do_g2, float *out) {
+enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3 };
+nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out) {
+    const bool do_g2 = mode == FT_NUM;
     const float *Hy = e->H;
     if (e->hL < e->T - 1) {
         if (!e->hpad_valid) {   // H changed since the last pass (init, H step)
@@ -560,21 +575,39 @@ nmfx_status fusedT_pass(nmfx_engine *e, bool do_g2, float *out) {
     FusedParams f;
     memset(&f, 0, sizeof(f));
     f.X = e->W; f.xs_r = 1; f.xs_k = e->m; f.xs_t = e->m * (long)e->K; f.T = e->T;
-    f.Y = Hy; f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->KT;
+    f.Y = Hy; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->KT;
+    f.D = (mode == FT_NUM && e->fusedT_kl) ? e->Vhat : e->V;      // KL: the numerators contract R = V./V_hat (left in the V_hat buffer by the S pass)
+    if (mode == FT_S_KL) f.Rout = e->Vhat;
     f.c_per_split = e->cps_T;
     const long mKT = e->m * (long)e->KT;
     f.out = e->nsplit_T == 1 ? out : e->slabsT;
     f.slab_stride = mKT; f.os_r = 1; f.os_k = e->m; f.os_t = e->m * (long)e->K;
     f.cost_partials = do_g2 ? nullptr : e->cost_partials;
+    const int func = mode == FT_NUM ? 0 : (mode == FT_COST_EUC ? 1 : 3);
     {
         Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
-        TRY(launch_fused(e->st, f, e->nsplit_T, true, do_g2 ? 0 : 1, do_g2, 0));
+        TRY(launch_fused(e->st, f, e->nsplit_T, true, func, do_g2, 0));
     }
     if (do_g2 && e->nsplit_T > 1) {
         Scope s(e, TAG_SMALL);
         TRY(reduce_slabs(e->st, e->slabsT, e->nsplit_T, mKT, mKT, out, 0));
     }
     if (!do_g2) e->n_cost_used = (int)((e->m + 127) / 128) * e->nsplit_T;
+    return NMFX_OK;
+}
+// KL cnmf on the fused passes: the cost of the CURRENT (W, H) from the S pass's partials, sum(V.*log(V./V_hat)), plus the closed form
+// sum(V_hat) - sum(V) = sum_{t,k} colsum(W_t)_k * sum_{j < n-t} H(k, j) - sum(V)    (the rshift of RFD.m:37 drops the last t columns of H)
+nmfx_status fusedT_kl_cost(nmfx_engine *e) {
+    Scope s(e, TAG_SMALL);
+    TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+    TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, 0));
+    TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    TRY(finish_cost(e->st, e->cost_partials, e->n_cost_used, 1.0, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K, e->lamH, e->cost,
+                    e->colsum, e->Pvec, e->KT, e->sumV_g));
+    e->cost_valid = true;
     return NMFX_OK;
 }
 
@@ -706,6 +739,12 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         }
     }
     if (e->gram) return NMFX_OK;   // no V_hat state on the Gram path
+    if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = false;
+        TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV_g));
+        return sum_vec(e->st, e->colV_g, e->n, e->sumV_g);
+    }
     return recon(e, false);
 }
 
@@ -769,10 +808,14 @@ nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchu
 
 static nmfx_status generic_wstep_partial(nmfx_engine *e) {
     const size_t mKT = (size_t)e->m * e->KT;
+    if (e->fusedT_kl) {   // S pass: R = V./V_hat into the V_hat buffer + the (lagged) cost of the state this iteration starts from
+        TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
+        TRY(fusedT_kl_cost(e));
+    }
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
-    if (e->fusedT) TRY(fusedT_pass(e, true, e->packed));   // all T numerators in one pass over V, the shifted H tile in LDS
+    if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
     else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
     if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
         Scope s(e, TAG_GRAM);
@@ -839,7 +882,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         TRY(w_update(e->st, p));
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
     }
-    if (e->gram) return NMFX_OK;
+    if (e->gram || e->fusedT_kl) return NMFX_OK;
     return recon(e, false);
 }
 
@@ -924,6 +967,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     if (!e->all_fixH) {
         OpView a{}, b{};
         num_view(e, a);
+        if (e->fusedT_kl) {   // R = V./V_hat with the W just updated
+            TRY(fusedT_pass(e, FT_S_KL, nullptr));
+            a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        }
         e->hpad_valid = false;
         if (e->qgemm) {
             // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
@@ -992,7 +1039,8 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, false, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
+    if (e->fusedT_kl) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
     else TRY(recon(e, !nocost));
     Scope s(e, TAG_SMALL);
@@ -1008,10 +1056,11 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->cost_valid) return NMFX_OK;
     if (e->fused) return fused_wpass(e, false);
+    if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT ? 3 : (e->gram ? 2 : 0)); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 2 Gram form on the GEMM, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->fusedT ? 3 : (e->gram ? 2 : 0))); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
@@ -1030,16 +1079,17 @@ nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
 }
 
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
+    const bool lag = e->fused || e->fusedT_kl;   // the cost of iteration i is a by-product of the first pass of iteration i+1
     for (int it = 0; it < iters; ++it) {
         TRY(nmfx_engine_wstep_partial(e));
         // fused path: the W-step pass has just produced the cost of the state it started from, i.e. of iteration it-1
-        if (e->fused && it > 0 && dev_cost_out)
+        if (lag && it > 0 && dev_cost_out)
             NMFX_HIP(hipMemcpyAsync(dev_cost_out + it - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
         TRY(nmfx_engine_wstep_finish(e));
         TRY(nmfx_engine_hstep(e));
-        if (!e->fused && dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+        if (!lag && dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
     }
-    if (e->fused && iters > 0 && dev_cost_out) {   // cost of the last iteration: one extra S = W*H pass
+    if (lag && iters > 0 && dev_cost_out) {   // cost of the last iteration: one extra S = W*H pass
         TRY(nmfx_engine_cost_pass(e));
         NMFX_HIP(hipMemcpyAsync(dev_cost_out + iters - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
     }
@@ -1073,7 +1123,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
-        if (e->fusedT) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
+        if (e->fusedT || e->fusedT_kl) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
@@ -1257,9 +1307,10 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;
     };
     bool stopped = false;
+    const bool lag = e && (e->fused || e->fusedT_kl);
     for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
         if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
-        if (e->fused && it > 0) {
+        if (lag && it > 0) {
             // the fused W-step pass of iteration it also yields cost(it-1); W and H are untouched until wstep_finish, so
             // stopping here returns exactly the state of iteration it-1 (the numerators just computed are discarded)
             if ((s = read_cost(it - 1)) != NMFX_OK) break;
@@ -1267,12 +1318,12 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         }
         if ((s = nmfx_engine_wstep_finish(e)) != NMFX_OK) break;
         if ((s = nmfx_engine_hstep(e)) != NMFX_OK) break;
-        if (!e->fused) {
+        if (!lag) {
             if ((s = read_cost(it)) != NMFX_OK) break;
             if (stop(it)) { stopped = true; break; }
         }
     }
-    if (s == NMFX_OK && e->fused && !stopped) {
+    if (s == NMFX_OK && lag && !stopped) {
         s = nmfx_engine_cost_pass(e);
         if (s == NMFX_OK) s = read_cost(p->maxiter - 1);
     }

@@ -301,6 +301,17 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_k
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
+            if (D_RC && FUNC >= 2 && FUNC <= 3 && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
+                if (row_ok) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int jb = e >> 4, reg = e & 15;
+                        const float rv = sacc[jb][reg];   // (a bit_cast applied to the vector element itself reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rv), rs, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
         }

@@ -39,6 +39,7 @@ template <int KH, int TT>
 static nmfx_status launch_T(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2) {
     if (func == 0 && do_g2) return launch_one_T<KH * TT, 0, true, TT>(st, p, nsplit);
     if (func == 1 && !do_g2) return launch_one_T<KH * TT, 1, false, TT>(st, p, nsplit);
+    if (func == 3 && !do_g2) return launch_one_T<KH * TT, 3, false, TT>(st, p, nsplit);   // KL: S pass (cost, optionally R = V./S to HBM)
     set_error("launch_fused_T: unsupported pass (func %d, do_g2 %d)", func, (int)do_g2);
     return NMFX_ERR_UNSUPPORTED;
 }

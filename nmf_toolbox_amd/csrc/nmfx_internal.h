@@ -111,6 +111,7 @@ struct FusedParams {
     long c_per_split;     // streamed rows per grid.y slice (multiple of 64)
     int K;
     float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
+    float *Rout;          // func 2 / 3, cost-only pass, W-step form: also store R = V./S (m x n, ld = ldd); nullptr = don't
     float *out2;          // func 4 / 5 (dual-map divergences), EPI 0: the second contraction (denominators), same indexing
     float ab_alpha, ab_beta;   // func 5
     float inv_exp;        // func 4 / 5, EPI 1: outer exponent 1/alpha of nmf.m:193-194 (1 = none); set it to 1 for func 4

@@ -169,7 +169,7 @@ class Engine:
         _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
         self.path_kind = int(self.lib.nmfx_engine_is_fused(self.h))
-        self.cost_lags = self.path_kind == 1
+        self.cost_lags = self.path_kind in (1, 4)         # the cost of iteration i is a by-product of the first pass of iteration i+1
         # row chunks of the W-step partial on column shards (all-reduce of chunk c overlapping the compute of chunk c+1): fused
         # path, m a multiple of 128*n_chunks.  Off (1) unless asked for: the K = 256 kernels fill every CU (one 512-VGPR wave per
         # SIMD, 256 workgroups), so a concurrent RCCL kernel can only run by displacing compute workgroups -- whether the overlap

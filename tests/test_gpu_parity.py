@@ -583,12 +583,13 @@ def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
 
 # ---- cnmf on the register-stationary kernels (fused_kernel TT > 1): every instantiated (K, T) pair, aligned and ragged shapes, sparsity,
 # fixed factors, 'frobenius' (no cost); against the oracle and against the GEMM formulations -----------------------------------------
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
 @pytest.mark.parametrize("K,T", [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4)])
 @pytest.mark.parametrize("m,n", [(256, 512), (129, 333), (640, 65)])
-def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n):
+def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n, div):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K, T=T)
-    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
     ref = O.cnmf(V, K, T, cfg)
     fused = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))          # 2 = the fused passes or an error
     _check(fused, ref)
@@ -599,12 +600,18 @@ def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n):
 def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(192, 400, 64, T=4)
-    for extra in (dict(W_fixed=True), dict(H_fixed=True), dict(divergence="frobenius")):
+    for extra in (dict(W_fixed=True), dict(H_fixed=True), dict(divergence="frobenius"), dict(divergence="kl", W_fixed=True), dict(divergence="kl", H_fixed=True)):
         cfg = dict(dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=5, tolerance=1e-12), **extra)
         _check(gpu_lib.cnmf(V, 64, 4, dict(cfg, nmfx_path=2)), O.cnmf(V, 64, 4, cfg))
     cfg = dict(W_init=[W0[:, :24], W0[:, 24:]], H_init=[H0[:24], H0[24:]], W_sparsity=[0.05, 0.0], H_fixed=[False, True], maxiter=5, tolerance=1e-12)
     _check(gpu_lib.cnmf(V, [24, 40], 4, dict(cfg, nmfx_path=2)), O.cnmf(V, [24, 40], 4, cfg))
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=200, tolerance=2.0, nmfx_path=2)     # KL: the cost lags one pass; the stop rule must
+    got, ref = gpu_lib.cnmf(V, 64, 4, cfg), O.cnmf(V, 64, 4, cfg)                                   # return the state of the iteration it fired on
+    assert len(ref[2]) < 200
+    _check_stop(got[2], ref[2], 2.0)
+    if len(got[2]) == len(ref[2]):
+        assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[1], ref[1]) <= TOL
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.cnmf(V, 64, 4, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean
+        gpu_lib.cnmf(V, 64, 4, dict(divergence="is", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean / kl
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.cnmf(V[:, :300], 48, 4, dict(maxiter=1, nmfx_path=2))                                   # (48, 4) is not instantiated
