@@ -152,6 +152,10 @@ struct nmfx_engine {
     float *Hpad, *Qbuf, *slabsT;
     int nsplit_T;
     long cps_T;
+    // unsharded fused cnmf: the two Gram products that involve the stacked shifted H by LAG (aux.hip: gram_from_lags, lag_sum, gp_tail) --
+    // T lag Grams instead of the T x T blocks of Hs*Hs', 2T-1 lag sums of W_flat'*W_flat instead of T^2 blocks in the H-step denominator
+    bool lagram;
+    float *Llag, *Elag;
     int nsplit_w, isplit_h;
     long cps_w, cps_h;        // streamed extent per split (multiples of 64; the last split may be shorter)
     int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
@@ -256,9 +260,14 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->CC = c.take<float>((size_t)e->KT * e->KT);
         size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
         size_t gg = std::max(std::max(g4, g5), sizeof(float) * Kn * e->T);   // + T slabs of the z-batched H-step denominator
+        if (e->lagram) gg = std::max(gg, std::max(gemm_scratch_bytes(e->K, e->KT, e->n), gemm_scratch_bytes(e->K, e->n, (long)(2 * e->T - 1) * e->K)));
         if (gg > e->gemm_scratch_bytes) { e->gemm_scratch_bytes = gg; e->gemm_scratch = c.take<float>(gg / sizeof(float)); }
         if (e->fusedT) {
-            e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+            e->Hpad = c.take<float>((size_t)e->K * (e->n + (e->lagram ? 2 : 1) * (e->T - 1)));
+            if (e->lagram) {
+                e->Llag = c.take<float>((size_t)e->K * e->KT);
+                e->Elag = c.take<float>((size_t)e->K * (2 * e->T - 1) * e->K);
+            }
             e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
             const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
             if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
@@ -358,6 +367,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
+    e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
     static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
     e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
     e->nsplit_w = e->isplit_h = 1;
@@ -561,15 +572,18 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
 // cnmf fused passes (fused_kernel TT > 1) over the local columns: do_g2 -> N_all = V * H_stack' into `out` (m x KT), else the residual cost
 // partials of the CURRENT (W, H).  H's T-1 columns to the left of the shard are its halo, or zeros (Hpad) on the first / only shard.
 enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3 };
+nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-1 zero columns (lag-form Gram products only)]
+    if (e->hpad_valid) return NMFX_OK;      // H changed since the last pass (init, H step)
+    Scope s(e, TAG_SMALL);
+    TRY(pad_left(e->st, e->H, e->K, e->n, e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));
+    e->hpad_valid = true;
+    return NMFX_OK;
+}
 nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out) {
     const bool do_g2 = mode == FT_NUM;
     const float *Hy = e->H;
     if (e->hL < e->T - 1) {
-        if (!e->hpad_valid) {   // H changed since the last pass (init, H step)
-            Scope s(e, TAG_SMALL);
-            TRY(pad_left(e->st, e->H, e->K, e->n, e->T - 1, e->Hpad));
-            e->hpad_valid = true;
-        }
+        TRY(ensure_hpad(e));
         Hy = e->Hpad + (size_t)e->K * (e->T - 1);
     }
     FusedParams f;
@@ -817,7 +831,14 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
     num_view(e, a);
     if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
     else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
-    if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
+    if (e->lagram) {   // Hs*Hs' from the T lag Grams L_d = sum_u H(:,u) H(:,u+d)' (K x T*K, contraction n, on the zero-padded copy) + boundary terms
+        TRY(ensure_hpad(e));
+        Scope s(e, TAG_GRAM);
+        const float *Hc = e->Hpad + (size_t)e->K * (e->T - 1);
+        TRY(small_gemm(e, e->K, e->KT, e->n, OpView{Hc, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{Hc + (size_t)e->K * (e->T - 1), nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->T - 1}, e->Llag, e->K));
+        TRY(gram_from_lags(e->st, e->Llag, e->H, e->K, e->T, e->n, e->packed + mKT));
+    } else if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
         Scope s(e, TAG_GRAM);
         OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
         TRY(small_gemm(e, e->KT, e->KT, e->n, hs, hs, e->packed + mKT, e->KT));
@@ -967,6 +988,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     if (!e->all_fixH) {
         OpView a{}, b{};
         num_view(e, a);
+        if (e->lagram) TRY(ensure_hpad(e));   // the denominator below reads the padded copy of the CURRENT H
         if (e->fusedT_kl) {   // R = V./V_hat with the W just updated
             TRY(fusedT_pass(e, FT_S_KL, nullptr));
             a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -994,6 +1016,15 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             Scope s(e, TAG_GRAM);
             OpView wf{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
             TRY(small_gemm(e, e->KT, e->KT, e->m, wf, wf, e->CC, e->KT));
+            if (e->lagram) {
+                // by lag: E_d = sum_{t-t'=d} D_(t,t'), Gp = sum_d E_d * H(:, j+d) as ONE K x n GEMM with contraction (2T-1)*K over the padded H;
+                // the last T-1 columns (where lshift_t drops terms) term by term
+                TRY(lag_sum(e->st, e->CC, e->K, e->T, e->Elag));
+                const float *Hc = e->Hpad + (size_t)e->K * (e->T - 1);
+                TRY(small_gemm(e, e->K, e->n, (long)(2 * e->T - 1) * e->K, OpView{e->Elag, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                               OpView{Hc + (size_t)e->K * (e->T - 1), nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, 2 * (e->T - 1)}, e->Gp, e->K));
+                TRY(gp_tail(e->st, e->CC, e->H, e->K, e->T, e->n, e->Gp));
+            } else {
             GemmParams g;
             memset(&g, 0, sizeof(g));
             g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
@@ -1015,6 +1046,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                     gt.C = e->Gp; gt.accumulate = t > 0;
                     TRY(launch_gemm(e->st, gt));
                 }
+            }
             }
         } else if (div_has_matrix_den(e->div)) {
             den_view(e, b);

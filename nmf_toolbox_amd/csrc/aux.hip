@@ -1,6 +1,7 @@
 // Bandwidth-class kernels around the MFMA contractions: deterministic split-K reduction, fp64
 // column/row reductions, the multiplicative-update epilogues (nmf.m:168-169,199; cnmf.m:193-199,231)
 // and cost assembly (nmf.m:206-218).  All reductions accumulate in fp64 and are order-deterministic.
+#include <algorithm>
 #include "nmfx_internal.h"
 
 namespace nmfx {
@@ -75,16 +76,93 @@ nmfx_status shift_sum(hipStream_t st, const float *Q, int K, int T, long n, long
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
-// dst = [zeros(K, pad) | src (K x n)]: the zero left halo the cnmf fused passes read for columns j - t < 0
-__global__ void pad_left_kernel(const float *src, long count, long padcount, float *dst) {
+// dst = [zeros(K, pad) | src (K x n) | zeros(K, pad_right)]: the zero left halo the cnmf fused passes read for columns j - t < 0; the
+// right one lets the lag-form Gram products below read H(:, j + d) past the last column
+__global__ void pad_left_kernel(const float *src, long count, long padcount, long rightcount, float *dst) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < padcount) dst[idx] = 0.0f;
     if (idx < count) dst[padcount + idx] = src[idx];
+    if (idx < rightcount) dst[padcount + count + idx] = 0.0f;
 }
-nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst) {
-    const long count = (long)K * n, padcount = (long)K * pad;
-    const long tot = count > padcount ? count : padcount;
-    hipLaunchKernelGGL(pad_left_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, count, padcount, dst);
+nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst, int pad_right) {
+    const long count = (long)K * n, padcount = (long)K * pad, rightcount = (long)K * pad_right;
+    const long tot = std::max(count, std::max(padcount, rightcount));
+    hipLaunchKernelGGL(pad_left_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, count, padcount, rightcount, dst);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// ---- cnmf Gram products by lag (euclidean, unsharded).  The KT x KT Gram of the stacked shifted H (cnmf.m:191-192 with V_hat*Hs' =
+// W_flat*(Hs*Hs')) has only T distinct K x K blocks up to boundary terms:
+//   G[(t1,k1),(t2,k2)] = sum_{j >= max(t1,t2)} H(k1, j-t1) H(k2, j-t2) = L_d(k1,k2) - sum_{u = n-t1}^{n-1-d} H(k1,u) H(k2,u+d),   d = t1-t2 >= 0
+// with the lag Grams L_d = sum_{u=0}^{n-1-d} H(:,u) H(:,u+d)' (one K x T*K GEMM over the zero-padded H instead of a KT x KT one: T times
+// fewer flops); d < 0 by symmetry.  L is stored as L[k1 + K*((T-1-d)*K + k2)].
+__global__ void gram_from_lags_kernel(const float *L, const float *H, int K, int T, long n, float *G) {
+    const long KT = (long)K * T;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KT * KT) return;
+    int a = (int)(idx % KT), b = (int)(idx / KT);
+    if (a / K < b / K) { const int tmp = a; a = b; b = tmp; }   // symmetric: evaluate the (t1 >= t2) twin
+    const int t1 = a / K, k1 = a - t1 * K, t2 = b / K, k2 = b - t2 * K, d = t1 - t2;
+    float corr = 0.0f;
+    for (long u = n - t1; u <= n - 1 - d; ++u) corr += H[k1 + (long)K * u] * H[k2 + (long)K * (u + d)];
+    G[idx] = L[k1 + (long)K * ((long)(T - 1 - d) * K + k2)] - corr;
+}
+nmfx_status gram_from_lags(hipStream_t st, const float *L, const float *H, int K, int T, long n, float *G) {
+    const long cnt = (long)K * T * K * T;
+    hipLaunchKernelGGL(gram_from_lags_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, L, H, K, T, n, G);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// H-step denominator sum_t W_t' * lshift_t(V_hat) = sum_{t,t'} CC[(t,.),(t',.)] * H(:, j+t-t') (cnmf.m:217-226 without V_hat, CC = W_flat'*W_flat):
+// away from the last T-1 columns the (t, t') terms depend on d = t-t' only, so E_d = sum_{t-t'=d} CC_(t,t') (2T-1 blocks of K x K) and one
+// K x n GEMM with contraction (2T-1)*K over the zero-padded H replace the T^2-block contraction.  E[k + K*(p*K + k')], p = T-1-d.
+__global__ void lag_sum_kernel(const float *CC, int K, int T, float *E) {
+    const long KT = (long)K * T;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)K * (2 * T - 1) * K) return;
+    const int k = (int)(idx % K);
+    const long c = idx / K;
+    const int p = (int)(c / K), kp = (int)(c - (long)p * K), d = T - 1 - p;
+    float s = 0.0f;
+    for (int tp = 0; tp < T; ++tp) {
+        const int t = tp + d;
+        if (t >= 0 && t < T) s += CC[(long)t * K + k + KT * ((long)tp * K + kp)];
+    }
+    E[idx] = s;
+}
+nmfx_status lag_sum(hipStream_t st, const float *CC, int K, int T, float *E) {
+    const long cnt = (long)K * (2 * T - 1) * K;
+    hipLaunchKernelGGL(lag_sum_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, CC, K, T, E);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// ... and the last T-1 columns, where lshift_t (cnmf.m:219) drops the terms with j + t > n - 1, evaluated term by term:
+//   Gp(k, j) = sum_{t <= n-1-j} sum_{t'} sum_{k'} CC[(t,k),(t',k')] * H(k', j+t-t')     (j+t-t' >= 0)
+__global__ __launch_bounds__(256) void gp_tail_kernel(const float *CC, const float *H, int K, int T, long n, float *Gp) {
+    // one workgroup per output (k, j); CC is symmetric, so column (t,k) of it is read contiguously along (t',k')
+    __shared__ float red[4];
+    const int KT = K * T;
+    const long j = n - (T - 1) + blockIdx.x / K;
+    const int k = blockIdx.x % K;
+    const int tmax = (int)(n - 1 - j);
+    float s = 0.0f;
+    for (int t = 0; t <= tmax; ++t) {
+        const float *cc = CC + (long)KT * ((long)t * K + k);
+        for (int c = threadIdx.x; c < KT; c += 256) {
+            const int tp = c / K, kp = c - tp * K;
+            const long col = j + t - tp;
+            if (col >= 0) s += cc[c] * H[kp + (long)K * col];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) Gp[k + (long)K * j] = red[0] + red[1] + red[2] + red[3];
+}
+nmfx_status gp_tail(hipStream_t st, const float *CC, const float *H, int K, int T, long n, float *Gp) {
+    if (T < 2) return NMFX_OK;
+    hipLaunchKernelGGL(gp_tail_kernel, dim3((unsigned)((T - 1) * K)), dim3(256), 0, st, CC, H, K, T, n, Gp);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -162,7 +162,11 @@ constexpr int NMFX_MAX_GPUS = 16;
 struct PeerPtrs { float *p[NMFX_MAX_GPUS]; };
 nmfx_status peer_reduce(hipStream_t st, const PeerPtrs &bufs, int ndev, int self, long off, long count);
 nmfx_status shift_sum(hipStream_t st, const float *Q, int K, int T, long n, long nvalid, float *Gn);
-nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst);
+nmfx_status pad_left(hipStream_t st, const float *src, int K, long n, int pad, float *dst, int pad_right = 0);
+// cnmf Gram products by lag (aux.hip): KT x KT Gram of the stacked H from the T lag Grams; lag sums of CC; exact last T-1 columns of the H-step denominator
+nmfx_status gram_from_lags(hipStream_t st, const float *L, const float *H, int K, int T, long n, float *G);
+nmfx_status lag_sum(hipStream_t st, const float *CC, int K, int T, float *E);
+nmfx_status gp_tail(hipStream_t st, const float *CC, const float *H, int K, int T, long n, float *Gp);
 nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);

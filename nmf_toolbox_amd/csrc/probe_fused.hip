@@ -8,11 +8,11 @@
 namespace nmfx { void set_error(const char *, ...) {} }
 using namespace nmfx;
 
-template <int PROBE, int FUNC, bool DO_G2>
+template <int PROBE, int FUNC, bool DO_G2, bool D_RC = true>
 static float run(const FusedParams &p, int nsplit, int reps) {
     constexpr int K = 256;
     const size_t ldsb = sizeof(float) * 2 * FT_C * (K + 4);
-    auto kern = fused_kernel<K, true, FUNC, DO_G2, 0, PROBE>;
+    auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, 0, PROBE>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     dim3 grid((unsigned)(p.R / FT_ROWS), (unsigned)nsplit);
     hipEvent_t a, b;
@@ -52,6 +52,19 @@ int main() {
     rep("cost: log replaced by mul", run<8, 3, true>(p, nsplit, 5), fl);
     rep("cost: no (S-V) sum", run<16, 3, true>(p, nsplit, 5), fl);
     rep("cost: neither", run<24, 3, true>(p, nsplit, 5), fl);
+    rep("second product only (func 0)", run<0, 0, true>(p, nsplit, 5), fl / 2);
+    rep("second product only, no barrier/DMA", run<1, 0, true>(p, nsplit, 5), fl / 2);
+    rep("second product only, no V loads", run<4, 0, true>(p, nsplit, 5), fl / 2);
+    rep("second product only, no barrier/DMA/V", run<5, 0, true>(p, nsplit, 5), fl / 2);
+    {
+        FusedParams q = p;   // H-step form: stationary = columns of V, streamed = rows of W (the buffers are reused, the values do not matter)
+        q.X = H; q.xs_r = K; q.xs_k = 1; q.Y = W; q.R = n; q.Cn = m; q.c_per_split = m / nsplit; q.os_r = K; q.os_k = 1; q.slab_stride = (long)K * n;
+        rep("H form, second product only", run<0, 0, true, false>(q, nsplit, 5), fl / 2);
+        rep("H form, second only, no barrier/DMA", run<1, 0, true, false>(q, nsplit, 5), fl / 2);
+        rep("H form, second only, no V loads", run<4, 0, true, false>(q, nsplit, 5), fl / 2);
+        rep("H form, KL (func 2)", run<0, 2, true, false>(q, nsplit, 5), fl);
+        rep("H form, KL, no V loads", run<4, 2, true, false>(q, nsplit, 5), fl);
+    }
     rep("cost-only pass", run<0, 3, false>(p, nsplit, 5), fl / 2);
     rep("cost-only, no barrier/emap/V", run<7, 3, false>(p, nsplit, 5), fl / 2);
     return 0;
