@@ -38,7 +38,7 @@ WORKLOADS = {
     "c3": ("nmf", "kl", 16384, 65536, 256, 1, 8.0),
     "c2": ("nmf", "euclidean", 8192, 32768, 128, 1, 12.0),
     "c4": ("cnmf", "euclidean", 4096, 16384, 64, 8, 12.0),
-    "c4kl": ("cnmf", "kl", 4096, 16384, 64, 8, 16.0),          # config 4's shape with the KL divergence (materialised V_hat; dev aid)
+    "c4kl": ("cnmf", "kl", 4096, 16384, 64, 8, 16.0),          # config 4's shape with the KL divergence (fused S / numerator passes; dev aid)
     "c2is": ("nmf", "is", 8192, 32768, 128, 1, 12.0),         # config 2's shape with the Itakura-Saito divergence (dual-map fused kernels; dev aid)
     "c5": ("nmfsc", "euclidean", 8192, 32768, 128, 1, 12.0),   # H_sparsity 0.5; F_alg = (5 + tries)*2mnK = 12 mnK at one try per line search
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="dev aid: no hipEvent pairs around the launch groups (the line then has no roofline object)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 generic (materialised V_hat), 2 fused")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("NMFX_W_CHUNKS", "0") or 0), choices=[0, 1, 2, 4, 8],
                     help="N > 1: row chunks of the W-step partial whose all-reduces overlap the next chunk's compute (0/1 = one blocking all-reduce)")
@@ -281,7 +282,7 @@ def main():
 
     eng.iterate(args.warmup, costs)
     sync()
-    eng.profile(True)
+    eng.profile(0 if args.no_profile else 2)   # event pairs around the MFMA launch groups only: bracketing the small kernels too costs 0.4 % at N = 1, 4 % on an 8-GPU shard
     t0 = time.perf_counter()
     eng.iterate(args.steps, costs[args.warmup:])
     sync()
@@ -357,6 +358,8 @@ def main():
                         avg_launch_ms=round(avg_ms, 4), launches=d["launches"], flops_per_launch=d["flops"],
                         algorithmic_bytes_per_launch=d["bytes"],
                         phases_ms_per_step={k: round(v["ms_total"] / args.steps, 4) for k, v in prof.items() if v["launches"] > 0})
+            # everything that is not bracketed: the small kernels (reductions, updates, transposes), launch gaps and, for N > 1, the exchange
+            roof["phases_ms_per_step"]["small kernels + gaps (remainder)"] = round(1e3 * dt / args.steps - sum(roof["phases_ms_per_step"].values()), 4)
         out = {
             "metric": "NMF multiplicative-update iterations/s", "value": round(its, 4), "unit": "iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,

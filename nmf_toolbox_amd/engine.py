@@ -268,7 +268,8 @@ class Engine:
 
     # ---- measurement hooks -------------------------------------------------------------------
     def profile(self, enable=True):
-        _lib.check(self.lib.nmfx_engine_profile(self.h, 1 if enable else 0))
+        """hipEvent pairs around the launch groups: True / 1 all of them, 2 the MFMA launch groups only (bench.py), False / 0 off"""
+        _lib.check(self.lib.nmfx_engine_profile(self.h, int(enable)))
         self.comm_events = [] if (enable and self.dist is not None and self.V.is_cuda) else None
 
     def comm_ms(self):
