@@ -139,6 +139,8 @@ struct nmfx_engine {
     int n_cost_partials, n_cost_used;
     // fused path (fused.hip): V_hat is never materialised
     bool fused, cost_valid, defer_hfinish;
+    double *cost_dst2;        // fused paths: the finisher of the next lagged cost also writes it here (the caller's cost vector), or nullptr
+    bool tail_with_cost;      // fused KL: the finisher also converts rowsum(H) into the fp32 tail of `packed` (W-step partial passes only)
     bool dual;                // fused IS / alpha-beta: packed = [N | P], both contractions of a pass come out of one kernel (func 4 / 5)
     float *slabs2, *Valpha;   // dual: slabs of the second contraction; alpha-beta with alpha ~= 1: V.^alpha (the kernels' data operand)
     double *sumVab;           // dual: the constant of the cost (IS: 0; alpha-beta: sum(V.^(alpha+beta)), nmf.m:214)
@@ -498,11 +500,13 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
             else { pa = 0.0; pb = -((e->alpha + 2.0 * e->beta) * cnt) / ab; }   // nmf.m:214 divides by alpha + beta: +-Inf cost, like the reference
         }
         return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
-                           e->lamH, e->cost, nullptr, nullptr, 0, nullptr, mdiv(e) == NMFX_DIV_AB ? e->sumVab : nullptr, pa, pb);
+                           e->lamH, e->cost, nullptr, nullptr, 0, nullptr, mdiv(e) == NMFX_DIV_AB ? e->sumVab : nullptr, pa, pb, e->cost_dst2);
     }
     // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
+    const bool tail = e->fused && kl_closed_form && e->tail_with_cost;
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
-                       e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV);
+                       e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV, nullptr, 0.0, 0.0,
+                       e->fused ? e->cost_dst2 : nullptr, tail ? e->rowsum : nullptr, tail ? e->packed + (size_t)e->m * e->KT : nullptr, e->K);
 }
 
 // grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
@@ -567,6 +571,7 @@ nmfx_status fused_wpass_finish(nmfx_engine *e) {
 }
 nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
     e->chunk_parts = 0;
+    e->tail_with_cost = do_g2;   // a W-step partial: the cost finisher also fills the fp32 tail [rowsum(H)] of `packed`
     TRY(fused_wpass_rows(e, do_g2, 0, e->m, e->packed));
     return fused_wpass_finish(e);
 }
@@ -622,14 +627,14 @@ nmfx_status fusedT_kl_cost(nmfx_engine *e) {
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
     if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
     TRY(finish_cost(e->st, e->cost_partials, e->n_cost_used, 1.0, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K, e->lamH, e->cost,
-                    e->colsum, e->Pvec, e->KT, e->sumV_g));
+                    e->colsum, e->Pvec, e->KT, e->sumV_g, nullptr, 0.0, 0.0, e->cost_dst2));
     e->cost_valid = true;
     return NMFX_OK;
 }
 
-nmfx_status refresh_w_derived(nmfx_engine *e) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
+nmfx_status refresh_w_derived(nmfx_engine *e, bool have_colsum = false) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
     TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
-    if (e->div == NMFX_DIV_KL) {
+    if (e->div == NMFX_DIV_KL && !have_colsum) {   // (after a W update the update kernel has already left colsum(W) in Gpvec)
         TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->Gpvec));   // T == 1: colsum(W) is the H-step denominator as is
     }
     return NMFX_OK;
@@ -784,8 +789,7 @@ static nmfx_status fused_wstep_tail(nmfx_engine *e) {
     const size_t mKT = (size_t)e->m * e->KT;
     if (e->dual) return NMFX_OK;   // [N | P] is complete: both halves came out of the pass
     if (e->div == NMFX_DIV_KL) {
-        Scope s(e, TAG_SMALL);
-        TRY(d2f(e->st, e->rowsum, e->packed + mKT, e->K));   // rowsum(H) was formed by fused_wpass
+        // rowsum(H) was formed by fused_wpass_finish, whose cost finisher has also written it into the tail of `packed` (tail_with_cost)
     } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
         Scope s(e, TAG_GRAM);
         TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
@@ -806,6 +810,7 @@ nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32
     if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; }
     TRY(fused_wpass_rows(e, true, rows * chunk, rows, e->packed + (size_t)chunk * rows * e->K));
     if (chunk + 1 < nchunks) return NMFX_OK;
+    e->tail_with_cost = true;
     TRY(fused_wpass_finish(e));
     return fused_wstep_tail(e);
 }
@@ -881,10 +886,12 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         }
         Scope s(e, TAG_SMALL);
         p.rule = e->algo == 2 ? 1 : 0;
+        // update, column normalisation (nmf.m:169 / lnmf.m:70) and, for KL, the column sums of the final W (H-step denominator) in ONE launch
+        p.fuse_norm = norm_mode(e) == 2 ? 2 : 1;
+        p.colsum_out = e->div == NMFX_DIV_KL ? e->Gpvec : nullptr;
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, 1, e->sumsq, e->fixW, norm_mode(e), nullptr));
         e->cost_valid = false;
-        return refresh_w_derived(e);
+        return refresh_w_derived(e, true);
     }
     if (!e->all_fixW) {
         Scope s(e, TAG_SMALL);
@@ -1115,10 +1122,12 @@ nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
     const bool lag = e->fused || e->fusedT_kl;   // the cost of iteration i is a by-product of the first pass of iteration i+1
     for (int it = 0; it < iters; ++it) {
-        TRY(nmfx_engine_wstep_partial(e));
-        // fused path: the W-step pass has just produced the cost of the state it started from, i.e. of iteration it-1
-        if (lag && it > 0 && dev_cost_out)
-            NMFX_HIP(hipMemcpyAsync(dev_cost_out + it - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+        // fused path: the W-step pass also produces the cost of the state it starts from, i.e. of iteration it-1; its finisher writes it
+        // straight into the caller's vector (no separate 8-byte copy)
+        e->cost_dst2 = (lag && it > 0 && dev_cost_out) ? dev_cost_out + it - 1 : nullptr;
+        nmfx_status ws_ = nmfx_engine_wstep_partial(e);
+        e->cost_dst2 = nullptr;
+        TRY(ws_);
         TRY(nmfx_engine_wstep_finish(e));
         TRY(nmfx_engine_hstep(e));
         if (!lag && dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));

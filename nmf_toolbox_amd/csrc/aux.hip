@@ -330,8 +330,16 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     __shared__ double red[4];
     const int c = blockIdx.x;
     const int k = c % p.K;
-    if (p.fixW && p.fixW[k]) return;
     float *w = p.W + p.m * c;
+    if (p.fixW && p.fixW[k]) {
+        if (p.fuse_norm != 0 && p.colsum_out) {   // fixed column: untouched, but its sum is still part of the H-step denominator
+            double cs = 0.0;
+            for (long i = threadIdx.x; i < p.m; i += 256) cs += (double)w[i];
+            cs = block_sum<4>(cs, red);
+            if (threadIdx.x == 0) p.colsum_out[c] = cs;
+        }
+        return;
+    }
     // numerator column c: plain m x KT layout, or n_chunks contiguous (cr x KT) row blocks (chunk ch holds rows [ch*cr, (ch+1)*cr))
     const int nch = p.n_chunks > 1 ? p.n_chunks : 1;
     const long cr = p.m / nch;
@@ -395,6 +403,28 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     }
     ss = block_sum<4>(ss, red);
     if (threadIdx.x == 0) p.sumsq[c] = ss;
+    if (p.fuse_norm == 0) return;
+    // nmf.m:169 / lnmf.m:70 on the column just written: every thread re-reads exactly the elements it stored (same factor expression as
+    // w_normalize_kernel, so W is bit-identical to the two-launch sequence)
+    const float f = (float)(p.fuse_norm == 2 ? 1.0 / ss : 1.0 / sqrt(ss));
+    double cs = 0.0;
+    if (vec) {
+        for (int ch = 0; ch < nch; ++ch) {
+            float4 *w4 = reinterpret_cast<float4 *>(w + ch * cr);
+            for (long i = threadIdx.x; i < cr / 4; i += 256) {
+                float4 v = w4[i];
+                v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+                w4[i] = v;
+                cs += ((double)v.x + v.y) + ((double)v.z + v.w);
+            }
+        }
+    } else {
+        for (long i = threadIdx.x; i < p.m; i += 256) { const float v = w[i] * f; w[i] = v; cs += (double)v; }
+    }
+    if (p.colsum_out) {
+        cs = block_sum<4>(cs, red);
+        if (threadIdx.x == 0) p.colsum_out[c] = cs;
+    }
 }
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
     hipLaunchKernelGGL(w_update_kernel, dim3(p.K * p.T), dim3(256), 0, st, p);
@@ -604,8 +634,9 @@ nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long 
 __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials, int count, double scale, const double *l1W, int nW,
                                                           const float *lamW, const double *l1H, int K, const float *lamH, double *out,
                                                           const double *dotA, const double *dotB, int ndot, const double *minus, const double *pre_c,
-                                                          double pre_a, double pre_b) {
+                                                          double pre_a, double pre_b, double *out2, const double *cvt_src, float *cvt_dst, int ncvt) {
     __shared__ double red[4];
+    for (int i = threadIdx.x; i < ncvt; i += 256) cvt_dst[i] = (float)cvt_src[i];
     double s = 0.0, t = 0.0;
     for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
     s = block_sum<4>(s, red);
@@ -615,13 +646,17 @@ __global__ __launch_bounds__(256) void finish_cost_kernel(const double *partials
     if (l1H) for (int k = threadIdx.x; k < K; k += 256) t += (double)lamH[k] * l1H[k];
     if (dotA) for (int k = threadIdx.x; k < ndot; k += 256) t += dotA[k] * dotB[k];   // closed-form sum(V_hat) of the KL cost
     t = block_sum<4>(t, red);
-    if (threadIdx.x == 0) *out = (count > 0 ? s : 0.0) + t - ((dotA && minus) ? *minus : 0.0);
+    if (threadIdx.x == 0) {
+        const double cst = (count > 0 ? s : 0.0) + t - ((dotA && minus) ? *minus : 0.0);
+        *out = cst;
+        if (out2) *out2 = cst;
+    }
 }
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA, const double *dotB, int ndot,
-                        const double *minus, const double *pre_c, double pre_a, double pre_b) {
+                        const double *minus, const double *pre_c, double pre_a, double pre_b, double *out2, const double *cvt_src, float *cvt_dst, int ncvt) {
     hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, l1W, nW, lamW, l1H, K, lamH, out, dotA, dotB,
-                       ndot, minus, pre_c, pre_a, pre_b);
+                       ndot, minus, pre_c, pre_a, pre_b, out2, cvt_src, cvt_dst, cvt_src && cvt_dst ? ncvt : 0);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -154,6 +154,9 @@ struct WUpdateParams {
     float inv_exp;       // outer exponent 1/alpha (1 = none)
     int rule;            // 0: nmf/cnmf (diag terms, sum of squares out); 1: lnmf (plain ratio, column sum out)
     int n_chunks;        // <= 1: N is m x K column-major.  c > 1: N = c contiguous (m/c x K) row blocks (row-chunked W-step partial)
+    int fuse_norm;       // 0: leave the columns un-normalised (w_normalize follows).  1 / 2 (T == 1 only): also apply nmf.m:169 (L2) / lnmf.m:70 (L1)
+                         // to the column in a third sweep of the same workgroup -- one launch and one pass over W fewer
+    double *colsum_out;  // with fuse_norm != 0: [K] column sums of the FINAL W, fixed columns included (KL H-step denominator, nmf.m:184), or nullptr
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
@@ -179,7 +182,9 @@ nmfx_status permute(hipStream_t st, const void *in, void *out, int is_f64, long 
 nmfx_status finish_cost(hipStream_t st, const double *partials, int count, double scale, const double *l1W, int nW, const float *lamW,
                         const double *l1H, int K, const float *lamH, double *out, const double *dotA = nullptr, const double *dotB = nullptr,
                         int ndot = 0, const double *minus = nullptr,    // + sum_k dotA[k]*dotB[k] - *minus
-                        const double *pre_c = nullptr, double pre_a = 0.0, double pre_b = 0.0);   // scale * (sum(partials) + pre_a * *pre_c + pre_b)
+                        const double *pre_c = nullptr, double pre_a = 0.0, double pre_b = 0.0,    // scale * (sum(partials) + pre_a * *pre_c + pre_b)
+                        double *out2 = nullptr,                                                   // second destination of the cost (the caller's cost vector)
+                        const double *cvt_src = nullptr, float *cvt_dst = nullptr, int ncvt = 0);  // + cvt_dst[i] = (float)cvt_src[i]  (rowsum(H) into the tail of `packed`)
 nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out);
 nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
