@@ -173,3 +173,39 @@ def test_gateway_runs_every_branch_like_the_ctypes_path(mex, gpu_lib):
     with pytest.raises(RuntimeError, match="nmfx:error: alpha = 0 and beta = 0"):          # the library's message, as MATLAB error() text
         M.call(3, "nmf", M.arr(V), M.arr(W2), M.arr(H0), M.arr([6], "int32"), M.arr([1.0]), o(divergence=3, alpha=0, beta=0, maxiter=2))
     mex.mock_reset()
+
+
+def test_m_wrappers_call_commands_the_gateway_implements():
+    """static check of matlab/*.m (source only: no MATLAB here): every wrapper calls nmfx_mex with a command string that
+    mexFunction dispatches on and with the number of arguments that branch demands (nrhs checks of nmfx_mex.c)"""
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    mdir = os.path.join(os.path.dirname(here), "matlab")
+    gateway = open(os.path.join(mdir, "nmfx_mex.c")).read()
+    known = set(re.findall(r'!strcmp\(algo, "(\w+)"\)', gateway))
+    nrhs = {"nmf": 7, "cnmf": 7, "lnmf": 7, "nmfsc": 7, "cnmfsc": 7, "constrainednmf": 6, "reconstruct": 3, "projfunc": 5, "sortdictionary": 3}
+    assert known == set(nrhs)
+    wrappers = sorted(glob.glob(os.path.join(mdir, "nmfx_*.m")))
+    assert {os.path.basename(w)[5:-2].lower() for w in wrappers} == {"nmf", "cnmf", "lnmf", "nmfsc", "cnmfsc", "constrainednmf", "reconstructfromdecomposition",
+                                                                      "projfunc", "sortdictionary"}
+    seen = set()
+    for w in wrappers:
+        src = open(w).read()
+        calls = []
+        for mt in re.finditer(r"nmfx_mex\('(\w+)'", src):          # (the header comments do not quote the command)
+            depth, nargs, i = 1, 1, mt.end()
+            while depth > 0:             # count the top-level commas up to the matching parenthesis (the command string is argument 1)
+                ch = src[i]
+                depth += ch in "([{"
+                depth -= ch in ")]}"
+                nargs += ch == "," and depth == 1
+                i += 1
+            calls.append((mt.group(1), nargs))
+        assert calls, w
+        for cmd, nargs in calls:
+            assert cmd in known, (w, cmd)
+            assert nargs == nrhs[cmd], (w, cmd, nargs)
+            seen.add(cmd)
+        assert src.lstrip().startswith("function"), w
+    assert seen == known
