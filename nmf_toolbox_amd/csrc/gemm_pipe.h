@@ -195,7 +195,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wi0 = (wave & 1) * (BM / 2), wj0 = (wave >> 1) * (BN / 2);
-    const int i_tile0 = blockIdx.x * BM, j_tile0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest) and each XCD has its own L2.  XCD k gets
+    // the k-th CONTIGUOUS eighth of the (x fastest) tile order instead of every eighth tile, so the tiles an XCD runs together share their
+    // B panel (all i tiles of a column block) and walk the contraction in step: a skinny product (Q = W_flat' * V: 4 x 128 tiles) then
+    // fetches each column block of V into ONE L2 instead of four (HBM read per launch 1.11e9 -> see profiles/r2_13_c4_pmc.md).
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    {
+        const unsigned nt = gridDim.x * gridDim.y;
+        if ((nt & 7u) == 0u && nt >= 16u) {
+            const unsigned id = bx + gridDim.x * by;
+            const unsigned tl = (id & 7u) * (nt >> 3) + (id >> 3);
+            bx = tl % gridDim.x; by = tl / gridDim.x;
+        }
+    }
+    const int i_tile0 = bx * BM, j_tile0 = by * BN;
 
     long kbeg = 0, kend = p.Kc;
     float *C = p.C;
