@@ -130,7 +130,7 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
         tries = info1["triesH"]
         f_mnk = 2.0 * m * nl * K
         work = {names[0]: (f_mnk, 4.0 * (m * nl + m * K + K * nl)),                       # objective pass: S = W*H only
-                names[2]: (f_mnk + 2.0 * K * K * (m + nl), 4.0 * (m * nl + m * K + 3 * K * nl)),
+                names[2]: (2.0 * f_mnk, 4.0 * (m * nl + 2 * m * K + 2 * K * nl)),         # residual pass: S = W*H, then W'*(S - V); reads V, W (+ transposed copy), H, writes dH
                 names[3]: (f_mnk + 2.0 * K * K * (m + nl), 4.0 * (m * nl + 3 * m * K + K * nl))}
         phases = {names[t]: round(ms[t] / args.steps, 4) for t in range(nt) if cnt[t] > 0}
         tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in work}
@@ -155,7 +155,7 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "nmfsc.m (Hoyer projection on H, H_sparsity=%g) outer iterations, V=%dx%d K=%d fp32 on %d GPU(s)" % (args.h_sparsity, m, n, K, world),
                        "name": args.workload, "m": m, "n": n, "K": K, "T": 1, "divergence": "euclidean", "H_sparsity": args.h_sparsity,
-                       "line_search_tries_H": tries, "path": "fused kernels (objective = fused cost pass, Gram-form gradients)"},
+                       "line_search_tries_H": tries, "path": "fused kernels (objective = fused cost pass; dH = W'*(W*H - V) and the objective of the iterate from one fused residual pass; MU W step in Gram form)"},
             "effective_tflops": round((5.0 + float(np.mean(tries))) * f_mnk * world * its / 1e12, 3),
             "cost_first_last": [float(c1[0]), float(c1[-1])], "cost_monotone": bool(np.all(np.diff(c1) <= 0)),
             "roofline": roof, "projfunc": pj,

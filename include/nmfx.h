@@ -157,9 +157,9 @@ nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s
                           int32_t nn, void *v, int32_t *usediters, int32_t device);
 
 /* the same projection on DEVICE buffers (fp32), asynchronous on `stream`: X (N x count, column-major) receives the projection of
- * src + mu*dir (src NULL = X itself, dir NULL = no step: the line-search candidates of nmfsc.m:154-157 in one kernel) */
+ * src + mu*dir formed in fp64 (src NULL = X itself, dir NULL = no step: the line-search candidates of nmfsc.m:154-157 in one kernel) */
 nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
-                              const float *dir_dev, float mu, int32_t *usediters_dev);
+                              const float *dir_dev, double mu, int32_t *usediters_dev);
 
 const char *nmfx_last_error(void);
 int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */

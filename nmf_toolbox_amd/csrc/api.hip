@@ -1606,7 +1606,7 @@ nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *
 // nmfsc launch groups (bench.py --workload c5)
 enum ScTag { SC_OBJ = 0, SC_PROJ = 1, SC_HTERMS = 2, SC_WTERMS = 3, SC_SMALL = 4, SC_COUNT = 5 };
 static const char *const kScTagNames[SC_COUNT] = {"fused:objective pass (S=W*H -> 0.5||V-S||^2)", "projfunc (Hoyer projection of the rows of H)",
-                                                  "H-step terms (W'*V, (W'*W)*H)", "W-step terms (V*H', W*(H*H'))", "small kernels (transposes, updates)"};
+                                                  "H-step terms (sparse H: fused residual pass dH = W'*(W*H-V) + objective; MU: W'*V, (W'*W)*H)", "W-step terms (MU: V*H', W*(H*H'); sparse W: fused residual pass)", "small kernels (transposes, updates)"};
 static thread_local Profiler g_sc_prof;
 
 // device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
@@ -1698,13 +1698,12 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         return projfunc_cols(st, HxT, n, Kv, L1s, 1.0, 1, nullptr);
     };
     // out = projection of (base + mu*dir), rows of H as the columns of the n x K transposed copies   (nmfsc.m:154-157)
-    auto step_project_H = [&](const float *baseT, const float *dirT, float mu, float *outT) -> nmfx_status {
-        if (comm.active()) {
-            TRY(axpy_f32(st, (long)Kn, mu, dirT, baseT, outT));
-            return project_H(outT);
-        }
+    // (dir64: the direction as doubles, small K; the step is formed in fp64 while loading)
+    auto step_project_H = [&](const float *baseT, const float *dirT, const double *dir64, double mu, float *outT) -> nmfx_status {
+        if (comm.active())
+            return projfunc_cols_dist(st, outT, n, Kv, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>(), dirT, mu, baseT, dir64);
         PScope ps(pf, SC_PROJ);
-        return projfunc_cols(st, outT, n, Kv, L1s, 1.0, 1, nullptr, dirT, mu, baseT);   // the step is applied while loading
+        return projfunc_cols(st, outT, n, Kv, L1s, 1.0, 1, nullptr, dirT, mu, baseT, dir64);
     };
     TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
     const bool resume = dev && p->sc_resume;   // W / H are the state a previous call left: already projected, nothing to initialise
@@ -1749,17 +1748,27 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     //   objective         0.5*||V - W*H||^2          fused cost-only pass (S = W*H in registers)
     //   W'*V, V*H'        fused H-step / W-step passes with R = V
     //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
-    DevBuf WTb, slabs, Gb, Denb, KKb, fparts;
+    DevBuf WTb, slabs, Gb, Denb, KKb, fparts, g64, s64;
+    const bool smallk = fast && Kv <= smallk_max();   // a handful of components: gradients + objective in fp64 (aux.hip::smallk_grad), handed to projfunc as doubles
     int nsplit_w = 1, isplit_h = 1;
     long cps_w = n, cps_h = m;
     if (fast) {
         nsplit_w = fused_split((m + 127) / 128, n, K, &cps_w);
         isplit_h = fused_split((n + 127) / 128, m, K, &cps_h);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
-        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * ((m + 127) / 128) * nsplit_w));
+        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * std::max<long>(std::max(((m + 127) / 128) * nsplit_w, ((n + 127) / 128) * isplit_h), smallk ? smallk_partials(m, n) : 0)));
+        if (smallk) { TRY(g64.alloc(sizeof(double) * std::max(m, n) * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)smallk_dw_chunks(m, n) * m * Kv)); }
     }
     // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        if (smallk) {
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_OBJ);
+                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, nullptr, nullptr, fparts.as<double>(), &np_));
+            }
+            return read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm);
+        }
         FusedParams f;
         memset(&f, 0, sizeof(f));
         f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
@@ -1768,6 +1777,59 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             PScope ps(pf, SC_OBJ);
             TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
         }
+        return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
+    };
+    // The gradients of the line-search branches in RESIDUAL form, one fused pass each (func 6: S = W*H in registers -> R = S - V -> second
+    // contraction): dH = W'*(W*H - V) (nmfsc.m:144-148) and dW = (W*H - V)*H' (nmfsc.m:194-200).  The Gram form pos - neg = (W'W)H - W'V
+    // subtracts two products rounded separately, and their difference goes to zero as the fit converges while they do not: it cost parity
+    // on small K (scripts/fuzz_campaign_sc.py: H off by 1.3e-5 at K = 3).  The same pass yields 0.5*||V - W*H||^2 of the point it is taken at.
+    // Den (K x n) = Wx' * (Wx*Hx - V); *obj = the objective at (Wx, Hx) when asked for
+    auto resid_h = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        if (smallk) {   // g64 = dH' (n x Kv doubles)
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_HTERMS);
+                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
+            }
+            return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
+        }
+        {
+            PScope ps(pf, SC_HTERMS);
+            TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = cps_h;
+            f.out = isplit_h == 1 ? Denb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
+            f.cost_partials = fparts.as<double>();
+            TRY(launch_fused(st, f, isplit_h, false, 6, true, 0));
+            if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Denb.as<float>(), 0));
+        }
+        if (!obj) return NMFX_OK;
+        return read_obj(st, fparts.as<double>(), (int)(((n + 127) / 128) * isplit_h), costd.as<double>(), obj, &comm);
+    };
+    // dW_ (m x K) = (Wx*Hx - V) * Hx', summed over the column shards; *obj as above
+    auto resid_w = [&](const float *Wx, const float *Hx, float *dW_, double *obj) -> nmfx_status {
+        if (smallk) {   // g64 = dW (m x Kv doubles)
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_WTERMS);
+                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
+                if (comm.active()) TRY(comm.allreduce(g64.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+            }
+            return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
+        }
+        {
+            PScope ps(pf, SC_WTERMS);
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
+            f.out = nsplit_w == 1 ? dW_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
+            f.cost_partials = fparts.as<double>();
+            TRY(launch_fused(st, f, nsplit_w, true, 6, true, 0));
+            if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, dW_, 0));
+            if (comm.active()) TRY(comm.allreduce(dW_, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
+        }
+        if (!obj) return NMFX_OK;
         return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
     };
     auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
@@ -1825,17 +1887,21 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         float *Hcur = Hk.as<float>(), *Hcand = Hcb.as<float>();
         double *nrm2 = costd.as<double>() + 8;
         TRY(transpose_f32(st, HTd, n, K, Hcur));
-        TRY(fast_obj(Wd, Hcur, &r->cost[0]));                                                   // nmfsc.m:138-139
+        // the objective of (W, H) and the gradient dH the next sparse-H line search starts from come out of the same pass
+        const bool lsH = !fixH && sH > 0;
+        bool have_dH = false;   // Denb = dH of the current (Wd, Hcur)
+        if (lsH && p->maxiter >= 1) { TRY(resid_h(Wd, Hcur, &r->cost[0])); have_dH = true; }
+        else TRY(fast_obj(Wd, Hcur, &r->cost[0]));                                              // nmfsc.m:138-139
         int ncost = p->maxiter + 1, nH = 0, nW = 0;
         bool early = false;
         for (int it = 1; it <= p->maxiter && !early; ++it) {
             double cur_obj = r->cost[it - 1];
             if (!fixH) {
-                TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
                 if (sH > 0) {
-                    {
+                    if (!have_dH) TRY(resid_h(Wd, Hcur, nullptr));                              // dH = W'*V_hat - W'*V   nmfsc.m:144-148
+                    have_dH = false;
+                    if (!smallk) {
                         PScope ps(pf, SC_SMALL);
-                        TRY(axpy_f32(st, (long)Kn, -1.0f, Gb.as<float>(), Denb.as<float>(), Denb.as<float>()));   // dH = pos - neg   nmfsc.m:148
                         TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));         // dH' (n x K): rows of H are contiguous there
                     }
                     const double begobj = cur_obj;                                              // nmfsc.m:149
@@ -1843,7 +1909,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(step_project_H(HTd, G1.as<float>(), (float)(-stepH), HnewT));           // nmfsc.m:154-157
+                        TRY(step_project_H(HTd, smallk ? nullptr : G1.as<float>(), smallk ? g64.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
                         {
                             PScope ps(pf, SC_SMALL);
                             TRY(transpose_f32(st, HnewT, n, K, Hcand));
@@ -1860,6 +1926,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
                     cur_obj = newobj;
                 } else {
+                    TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
                     TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
                     TRY(transpose_f32(st, Hcur, K, n, HTd));
                     TRY(col_reduce(st, HTd, n, n, Kv, 1, nrm2));                                    // nmfsc.m:185
@@ -1871,18 +1938,16 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 }
             }
             if (!fixW) {
-                if (sW > 0 && !(cur_obj == cur_obj)) TRY(fast_obj(Wd, Hcur, &cur_obj));            // nmfsc.m:193,197
-                TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                        // V*H', V_hat*H'       nmfsc.m:194-195
                 if (sW > 0) {
+                    TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
                     const double begobj = cur_obj;
-                    TRY(axpy_f32(st, (long)mK, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dW = pos - neg     nmfsc.m:200
                     int tries = 0;
                     double newobj = 0;
                     for (;;) {
                         ++tries;
                         {
                             PScope ps(pf, SC_PROJ);
-                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, G2.as<float>(), (float)(-stepW), Wd));   // nmfsc.m:205-208
+                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, smallk ? nullptr : G2.as<float>(), -stepW, Wd, smallk ? g64.as<double>() : nullptr));   // nmfsc.m:205-208
                         }
                         TRY(fast_obj(Wnew, Hcur, &newobj));                                         // nmfsc.m:211-212
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
@@ -1896,12 +1961,14 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     std::swap(Wd, Wnew);                                                            // nmfsc.m:229
                     cur_obj = newobj;
                 } else {
+                    TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                    // V*H', V_hat*H'       nmfsc.m:194-195
                     PScope ps(pf, SC_SMALL);
                     TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
                     cur_obj = NAN;
                 }
             }
             if (cur_obj == cur_obj) r->cost[it] = cur_obj;                                          // same (W, H) as the accepted objective
+            else if (lsH && it < p->maxiter) { TRY(resid_h(Wd, Hcur, &r->cost[it])); have_dH = true; }   // + the next iteration's dH
             else TRY(fast_obj(Wd, Hcur, &r->cost[it]));                                             // nmfsc.m:237-238
             if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
                 ncost = it + 1;
@@ -1940,8 +2007,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 int tries = 0;
                 for (;;) {
                     ++tries;
-                    TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G1.as<float>(), HTd, HnewT));   // nmfsc.m:154
-                    TRY(projfunc_cols(st, HnewT, n, Kv, L1s, 1.0, 1, nullptr));                  // nmfsc.m:155-157
+                    TRY(projfunc_cols(st, HnewT, n, Kv, L1s, 1.0, 1, nullptr, G1.as<float>(), -stepH, HTd));   // nmfsc.m:154-157 (step formed in fp64 while loading)
                     double newobj;
                     TRY(recon_obj(Wd, HnewT, &newobj));                                         // nmfsc.m:160-161
                     if (newobj <= begobj) break;                                                // nmfsc.m:164
@@ -1971,8 +2037,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 int tries = 0;
                 for (;;) {
                     ++tries;
-                    TRY(axpy_f32(st, (long)mK, (float)(-stepW), G1.as<float>(), Wd, Wnew));     // nmfsc.m:205
-                    TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr));                   // nmfsc.m:206-208
+                    TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, G1.as<float>(), -stepW, Wd));   // nmfsc.m:205-208
                     double newobj;
                     TRY(recon_obj(Wnew, HTd, &newobj));                                         // nmfsc.m:211-212
                     if (newobj <= begobj) break;                                                // nmfsc.m:215
@@ -2034,8 +2099,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
-    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, G1, G2, stage, part, costd, scratch, rrs;
+    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, stage, part, costd, scratch, rrs;
     TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
+    TRY(HnT.alloc((size_t)p->K_total * p->n * 4));
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
     TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
     const size_t gmax = std::max(Kn, mKT);
@@ -2073,19 +2139,20 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         return gemm(g, obj);
     };
     // out (K x n) = sum_t Wx_t' * lshift_t(X)
-    auto hgrad = [&](const float *Wx, const float *X, float *out) -> nmfx_status {
+    // (X2 given: X is replaced by X2 - X element-wise while it is loaded -- the gradient in residual form, see run_nmfsc)
+    auto hgrad = [&](const float *Wx, const float *X, float *out, const float *X2 = nullptr) -> nmfx_status {
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = K; g.N = n; g.Kc = (long)T * m;
         g.A = OpView{Wx, nullptr, m, VIEW_WSTACK_KC, (int)m, m * (long)K, 0, NMFX_PRO_NONE, 0.f, 0.f};
-        g.B = OpView{X, nullptr, m, VIEW_XSHIFT_KC, (int)m, 0, (int)n, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{X, X2, m, VIEW_XSHIFT_KC, (int)m, 0, (int)n, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
         g.C = out; g.ldc = K;
         return gemm(g, nullptr);
     };
     // out (m x K) = X * rshift_t(H)'
-    auto xht = [&](const float *X, const float *Hx, int t, float *out) -> nmfx_status {
+    auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = K; g.Kc = n;
-        g.A = OpView{X, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.A = OpView{X, X2, m, VIEW_RC, 0, 0, 0, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
         g.B = OpView{Hx, nullptr, (long)K, VIEW_HSTACK_RC, K, 0, t * K, NMFX_PRO_NONE, 0.f, 0.f};
         g.C = out; g.ldc = m;
         return gemm(g, nullptr);
@@ -2099,16 +2166,16 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     double *nrm2 = costd.as<double>() + 8;
     for (int it = 1; it <= p->maxiter && !early; ++it) {
         if (!fixH) {
-            TRY(hgrad(W0, V.as<float>(), G1.as<float>()));                                       // cnmfsc.m:160-165
-            TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));
             if (sH > 0) {
-                TRY(axpy_f32(st, (long)Kn, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dH = pos - neg      cnmfsc.m:168
+                TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));                  // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
                 const double begobj = r->cost[it - 1];
                 int tries = 0;
+                TRY(transpose_f32(st, H, K, n, HT));                                                 // rows of H / dH contiguous: the projected vectors
+                TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
                 for (;;) {
                     ++tries;
-                    TRY(axpy_f32(st, (long)Kn, (float)(-stepH), G2.as<float>(), H, Hnew));           // cnmfsc.m:174
-                    TRY(project_rows(Hnew));                                                         // cnmfsc.m:175-177
+                    TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, G1.as<float>(), -stepH, HT));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
+                    TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
                     double newobj;
                     TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181
                     if (newobj <= begobj) break;
@@ -2121,6 +2188,8 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 stepH *= 1.2;
                 std::swap(H, Hnew);
             } else {
+                TRY(hgrad(W0, V.as<float>(), G1.as<float>()));                                   // cnmfsc.m:160-165
+                TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));
                 TRY(mu_plus_eps(st, H, G1.as<float>(), G2.as<float>(), (long)Kn));                   // H .* (neg ./ (pos + eps))   cnmfsc.m:202
                 TRY(row_reduce(st, H, K, K, n, 1, nrm2, rrs.p));                                     // cnmfsc.m:205
                 TRY(transpose_f32(st, H, K, n, HT));
@@ -2134,16 +2203,13 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
             TRY(rfd(W0, H, &begobj));                                                            // cnmfsc.m:215
             for (int t = 0; t < T && !early; ++t) {
                 float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
-                TRY(xht(V.as<float>(), H, t, G1.as<float>()));                                   // neg = V * Hs'
-                TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                                  // pos = V_hat * Hs'
                 if (sW > 0) {
-                    TRY(axpy_f32(st, (long)mK, -1.0f, G1.as<float>(), G2.as<float>(), G2.as<float>()));   // dW   cnmfsc.m:224
+                    TRY(xht(V.as<float>(), H, t, G2.as<float>(), Vh.as<float>()));               // dW = pos - neg = (V_hat - V) * Hs'   cnmfsc.m:221-224
                     int tries = 0;
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(axpy_f32(st, (long)mK, (float)(-stepW[t]), G2.as<float>(), W0t, Wnew));  // cnmfsc.m:229
-                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr));
+                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, G2.as<float>(), -stepW[t], W0t));   // cnmfsc.m:229-233 (step formed in fp64 while loading)
                         GemmParams g; memset(&g, 0, sizeof(g));                                      // RFD(Wnew, H) with a 2-D Wnew: plain Wnew*H  (cnmfsc.m:235)
                         g.M = m; g.N = n; g.Kc = K;
                         g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -2161,13 +2227,18 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     NMFX_HIP(hipMemcpyAsync(Wt, Wnew, mK * 4, hipMemcpyDeviceToDevice, st));         // W(:,:,t) = Wnew
                     begobj = newobj;                                                                 // next t: 0.5*||V - V_hat||^2 of the V_hat left here
                 } else {
+                    TRY(xht(V.as<float>(), H, t, G1.as<float>()));                               // neg = V * Hs'
+                    TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
                     NMFX_HIP(hipMemcpyAsync(Wt, W0t, mK * 4, hipMemcpyDeviceToDevice, st));
                     TRY(mu_plain(st, Wt, G1.as<float>(), G2.as<float>(), (long)mK));                 // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
                     TRY(axpy_f32(st, (long)mK, -1.0f, W0t, Wt, Wnew));                               // dW = W_t - W0_t
                     GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     g.M = m; g.N = n; g.Kc = K;
                     g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
-                    g.B = OpView{H - (long)K * t, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, -t, NMFX_PRO_NONE, 0.f, 0.f};
+                    // rshift_t(H) as a view whose base lies t columns BEFORE H: every element it may touch (column r - t >= 0) is inside H, but the
+                    // base itself is not -- chunks outside the view must load from inside the allocation (safe), or the launch faults when H
+                    // happens to start a mapping (found by scripts/fuzz_campaign_sc.py)
+                    g.B = OpView{H - (long)K * t, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, -t, NMFX_PRO_NONE, 0.f, 0.f, 0, (long)K * t};
                     g.C = Vh.as<float>(); g.ldc = m; g.accumulate = 1; g.clamp0 = 1; g.epi = EPI_STORE; g.splitk = 1;
                     TRY(launch_gemm(st, g));
                 }
@@ -2271,7 +2342,7 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
 }
 
 nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
-                              const float *dir_dev, float mu, int32_t *usediters_dev) {
+                              const float *dir_dev, double mu, int32_t *usediters_dev) {
     if (N <= 0 || count <= 0 || !X_dev) { set_error("nmfx_projfunc_dev: bad arguments"); return NMFX_ERR_INVALID; }
     return projfunc_cols(static_cast<hipStream_t>(stream), X_dev, N, count, k1, k2, nn, usediters_dev, dir_dev, mu, src_dev);
 }

@@ -790,6 +790,113 @@ nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out) {
     return NMFX_OK;
 }
 
+// ---- nmfsc with a handful of components (K <= 8): gradients and objective in fp64 on the VALU ------------------------------------
+// The Hoyer projection that follows the gradient step amplifies what it is given (it removes most of a row's mass; 70x on K = 3
+// problems), so an fp32-accumulated gradient -- fine at K >= 8 -- costs parity there: H off by 1.2e-5 (scripts/fuzz_campaign_sc.py).
+// With K this small the contractions are bandwidth work, so they are done exactly: r = W*H - V and the sums over it in doubles,
+// results left as doubles for projfunc (dir64).  V is read once; W / H come out of L2.
+//   dHT (n x KV, optional)  dH' = (W'*(W*H - V))'            nmfsc.m:144-148
+//   partials[gridDim.x]     sum (W*H - V).^2 per workgroup   nmfsc.m:139,161  (the caller halves the total)
+template <int KV>
+__global__ __launch_bounds__(256) void smallk_dh_kernel(const float *V, long m, long n, const float *W, const float *H, int ldh, double *dHT, double *partials) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double cost = 0.0;
+    for (long j = (long)blockIdx.x * 4 + w; j < n; j += (long)gridDim.x * 4) {   // one wave per column of V
+        double h[KV], acc[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) { h[k] = (double)H[k + (long)ldh * j]; acc[k] = 0.0; }
+        const float *v = V + m * j;
+        for (long i = lane; i < m; i += 64) {
+            double wv[KV], sv = 0.0;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) { wv[k] = (double)W[i + m * k]; sv = fma(wv[k], h[k], sv); }
+            const double r = sv - (double)v[i];
+            cost = fma(r, r, cost);
+#pragma unroll
+            for (int k = 0; k < KV; ++k) acc[k] = fma(wv[k], r, acc[k]);
+        }
+        if (dHT) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) { const double t = wave_sum(acc[k]); if (lane == 0) dHT[j + n * k] = t; }
+        }
+    }
+    cost = block_sum<4>(cost, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = cost;
+}
+//   slabs[blockIdx.y][m x KV]   (W*H - V) * H' over the column chunk [y*cpc, (y+1)*cpc)   nmfsc.m:194-200 ; partials as above
+template <int KV>
+__global__ __launch_bounds__(256) void smallk_dw_kernel(const float *V, long m, long n, const float *W, const float *H, int ldh, long cpc, double *slabs, double *partials) {
+    __shared__ double red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < m;
+    const long c0 = (long)blockIdx.y * cpc, c1 = c0 + cpc < n ? c0 + cpc : n;
+    double wv[KV], acc[KV], cost = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { wv[k] = ok ? (double)W[i + m * k] : 0.0; acc[k] = 0.0; }
+    for (long j = c0; j < c1; ++j) {
+        double h[KV], sv = 0.0;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) { h[k] = (double)H[k + (long)ldh * j]; sv = fma(wv[k], h[k], sv); }   // wave-uniform loads
+        const double r = sv - (ok ? (double)V[i + m * j] : 0.0);
+        cost = fma(r, r, cost);
+#pragma unroll
+        for (int k = 0; k < KV; ++k) acc[k] = fma(r, h[k], acc[k]);
+    }
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) slabs[(long)blockIdx.y * m * KV + i + m * k] = acc[k];
+    }
+    cost = block_sum<4>(cost, red);
+    if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = cost;
+}
+__global__ void sum_slabs_f64_kernel(const double *slabs, int nslab, long count, double *out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    double s = slabs[idx];
+    for (int z = 1; z < nslab; ++z) s += slabs[(long)z * count + idx];
+    out[idx] = s;
+}
+int smallk_max() { return 8; }
+int smallk_dw_chunks(long m, long n) {
+    const long gx = (m + 255) / 256;
+    long c = (2048 + gx - 1) / gx;
+    const long cmax = (n + 63) / 64;
+    if (c > cmax) c = cmax;
+    return (int)(c < 1 ? 1 : c);
+}
+int smallk_partials(long m, long n) { return (int)std::max<long>(std::min<long>((n + 3) / 4, 2048), (m + 255) / 256 * smallk_dw_chunks(m, n)); }
+template <int KV>
+static nmfx_status smallk_launch(hipStream_t st, int Kv, const float *V, long m, long n, const float *W, const float *H, int ldh, double *dHT, double *dW, double *slabs,
+                                 double *partials, int *nparts) {
+    if constexpr (KV > 1) { if (Kv < KV) return smallk_launch<KV - 1>(st, Kv, V, m, n, W, H, ldh, dHT, dW, slabs, partials, nparts); }
+    if (dW) {
+        const int nch = smallk_dw_chunks(m, n);
+        const long cpc = (n + nch - 1) / nch;
+        const dim3 grid((unsigned)((m + 255) / 256), (unsigned)nch);
+        hipLaunchKernelGGL(smallk_dw_kernel<KV>, grid, dim3(256), 0, st, V, m, n, W, H, ldh, cpc, nch == 1 ? dW : slabs, partials);
+        NMFX_HIP(hipGetLastError());
+        if (nch > 1) {
+            hipLaunchKernelGGL(sum_slabs_f64_kernel, dim3((unsigned)((m * KV + 255) / 256)), dim3(256), 0, st, slabs, nch, m * KV, dW);
+            NMFX_HIP(hipGetLastError());
+        }
+        *nparts = (int)(grid.x * grid.y);
+        return NMFX_OK;
+    }
+    const unsigned blocks = (unsigned)std::min<long>((n + 3) / 4, 2048);
+    hipLaunchKernelGGL(smallk_dh_kernel<KV>, dim3(blocks), dim3(256), 0, st, V, m, n, W, H, ldh, dHT, partials);
+    NMFX_HIP(hipGetLastError());
+    *nparts = (int)blocks;
+    return NMFX_OK;
+}
+// dW != nullptr: dW (m x Kv doubles) = (W*H - V)*H' (slabs: smallk_dw_chunks(m, n) * m * Kv doubles); else dHT (n x Kv doubles, may be nullptr:
+// objective only) = (W'*(W*H - V))'.  partials[*nparts] always receive sum (W*H - V).^2.  W: m x Kv (column stride m), H: column stride ldh.
+nmfx_status smallk_grad(hipStream_t st, int Kv, const float *V, long m, long n, const float *W, const float *H, int ldh, double *dHT, double *dW, double *slabs,
+                        double *partials, int *nparts) {
+    if (Kv < 1 || Kv > 8) { set_error("smallk_grad: K = %d", Kv); return NMFX_ERR_INVALID; }
+    return smallk_launch<8>(st, Kv, V, m, n, W, H, ldh, dHT, dW, slabs, partials, nparts);
+}
+
 // packed buffer helpers for the multi-GPU exchange: doubles <-> floats
 __global__ void d2f_kernel(const double *in, float *out, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

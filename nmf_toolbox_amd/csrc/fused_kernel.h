@@ -26,6 +26,8 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 // FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
 //       4 IS (nmf.m:155-156,186-187,212): TWO element maps per pass, A = V./S.^2 and B = 1./S, two accumulator sets (K <= 128)
 //       5 alpha-beta, alpha ~= 0 (nmf.m:162-163,193-194,214): A = V.^alpha .* S.^(beta-1), B = S.^(alpha+beta-1); D holds V.^alpha
+//       6 R = S - V (the residual) + euclidean cost: the gradients of nmfsc.m:144-148,194-200 in ONE contraction, dH = W'*(W*H - V) /
+//         dW = (W*H - V)*H', instead of the difference of two separately rounded products (which cancels as the fit improves)
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -36,7 +38,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 // row c of the tile starts at LDS row c; nothing is replicated.  p.Y must be preceded by TT-1 readable columns (zeros, or the left
 // halo of a column shard).  X / out slice t = TT-1-p lives at xs_t / os_t.
 template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool RAG = false, int TT = 1>
-__global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
+__global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(TT == 1 || (D_RC && EPI == 0 && (K / TT) % 32 == 0 && K % TT == 0), "TT > 1: W-step form, K/TT a multiple of 32");
     constexpr int KH = K / TT;             // floats per column of H
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_k
     constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
-    constexpr bool DUAL = FUNC >= 4;       // two element maps, two accumulator sets
+    constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
     constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
     static_assert(!DUAL || (K <= 128 && TT == 1), "dual-map kernels: K <= 128 (two accumulator sets + the stationary operand must fit 512 VGPRs)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
@@ -216,6 +218,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_k
                 if (u == 5) sacc2[jb][reg] = live ? er[sl] : 0.0f;
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
+                if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
             } else if (FUNC >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC < 4) ? 2 : 1)) void fused_k
                     sacc[jb][reg] = live ? v : 0.0f;
                 }
             }
-            if ((FUNC == 1 && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
+            if (((FUNC == 1 || FUNC == 6) && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
         // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
         // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)

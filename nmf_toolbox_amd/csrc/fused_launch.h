@@ -53,6 +53,7 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 3: return launch_one<K, D_RC, 3, DO_G2, EPI, RAG>(st, p, nsplit);
     case 4: if constexpr (K <= 128) return launch_one<K, D_RC, 4, DO_G2, EPI, RAG>(st, p, nsplit); break;   // dual-map divergences: two accumulator sets
     case 5: if constexpr (K <= 128) return launch_one<K, D_RC, 5, DO_G2, EPI, RAG>(st, p, nsplit); break;
+    case 6: if constexpr (DO_G2 && EPI == 0) return launch_one<K, D_RC, 6, DO_G2, EPI, RAG>(st, p, nsplit); break;   // residual-form gradients (nmfsc)
     }
     set_error("launch_fused: unsupported functor %d", func);
     return NMFX_ERR_UNSUPPORTED;

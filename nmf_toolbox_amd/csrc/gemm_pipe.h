@@ -102,7 +102,7 @@ struct PLoader {
         if (P == 0) okm[SET] = 0;
         okm[SET] |= ok ? (1 << P) : 0;
         if (VEC) {
-            const long o = ok ? off : 0;        // out-of-view chunks read the view's first (always valid) element and are zeroed at commit
+            const long o = ok ? off : v.safe;   // out-of-view chunks read an element that always exists (OpView.safe) and are zeroed at commit
             x[SET][P] = *reinterpret_cast<const float4 *>(v.p + o);
             if (PRO) { if (v.p2) y[PRO ? SET : 0][PRO ? P : 0] = *reinterpret_cast<const float4 *>(v.p2 + o); }
         } else {
@@ -135,11 +135,11 @@ struct PLoader {
                 if (!gnext && first_wrapped < nv) nv = first_wrapped;
             }
             nval[SET][VEC ? 0 : P] = nv;
-            const float *b1 = v.p + (nv > 0 ? off : 0);
+            const float *b1 = v.p + (nv > 0 ? off : v.safe);
             x[SET][P] = make_float4(b1[0], b1[nv > 1 ? eo1 : 0], b1[nv > 2 ? eo2 : 0], b1[nv > 3 ? eo3 : 0]);
             if (PRO) {
                 if (v.p2) {
-                    const float *b2 = v.p2 + (nv > 0 ? off : 0);
+                    const float *b2 = v.p2 + (nv > 0 ? off : v.safe);
                     y[PRO ? SET : 0][PRO ? P : 0] = make_float4(b2[0], b2[nv > 1 ? eo1 : 0], b2[nv > 2 ? eo2 : 0], b2[nv > 3 ? eo3 : 0]);
                 }
             }

@@ -57,6 +57,8 @@ struct OpView {
     int func;         // nmfx_prologue
     float e1, e2;     // NMFX_PRO_POWPROD exponents (MATLAB .^ semantics: x.^0 == 1, x.^1 == x)
     int goff;         // HSTACK views: columns j >= -goff exist (left halo of a column shard); element valid iff j - t >= -goff
+    long safe;        // element offset from p that is ALWAYS readable: the pipelined kernel loads it for chunks outside the view (and zeroes them).
+                      // 0 unless p itself lies before the allocation (a view shifted by pointer arithmetic, cnmfsc's V_hat correction)
 };
 
 enum EpiMode {
@@ -128,7 +130,7 @@ struct FusedParams {
 };
 bool fused_supported(int K);
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
-// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128);  do_g2=false: cost-only pass
+// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128) | 6 R=S-V + euclidean cost (do_g2, slabs out);  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
 // ---- small kernels (aux.hip) ----------------------------------------------------------------
@@ -188,6 +190,12 @@ nmfx_status finish_cost(hipStream_t st, const double *partials, int count, doubl
 nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out);
 nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
+// nmfsc with K <= smallk_max(): residual-form gradients and objective in fp64 (aux.hip)
+int smallk_max();
+int smallk_dw_chunks(long m, long n);
+int smallk_partials(long m, long n);   // upper bound of *nparts
+nmfx_status smallk_grad(hipStream_t st, int Kv, const float *V, long m, long n, const float *W, const float *H, int ldh, double *dHT, double *dW, double *slabs,
+                        double *partials, int *nparts);
 nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
 nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
 nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
@@ -202,14 +210,15 @@ nmfx_status cvt_to_f32(hipStream_t st, const void *in, int dtype, float *out, lo
 nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count);
 
 // ---- Hoyer projection (projfunc.hip): vectors are the COLUMNS of X (len x count), in place ----
-// dir != nullptr: the vectors projected are src + mu*dir (the line-search step of nmfsc.m:154 / 205 fused into the load); src == nullptr
-// means X itself.  X receives the result.
+// dir (or dir64, the direction as doubles) != nullptr: the vectors projected are src + mu*dir, formed in fp64 (the line-search step of
+// nmfsc.m:154 / 205 fused into the load); src == nullptr means X itself.  X receives the result.
 nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev,
-                          const float *dir = nullptr, float mu = 0.0f, const float *src = nullptr);
+                          const float *dir = nullptr, double mu = 0.0, const float *src = nullptr, const double *dir64 = nullptr);
 nmfx_status projfunc_cols_f64(hipStream_t st, double *X, long len, int count, double k1, double k2, int nn, int *usediters_dev);
 // the same projection when every vector is split over the ranks of `comm` (len = local part, N_total = whole length);
 // v_scratch: len*count doubles, flags: len*count bytes, red: 6*count doubles
 nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, long N_total, double k1, double k2, int nn, const Comm &comm,
-                               double *v_scratch, unsigned char *flags, double *red);
+                               double *v_scratch, unsigned char *flags, double *red, const float *dir = nullptr, double mu = 0.0,
+                               const float *src = nullptr, const double *dir64 = nullptr);
 
 }  // namespace nmfx

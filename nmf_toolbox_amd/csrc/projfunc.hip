@@ -86,13 +86,14 @@ __device__ __forceinline__ Red4 block_red4_w(Red4 v, double *red) {
 // of a 1024-thread block; <512, 64, 0> covers len <= 32768 (a row of H at BASELINE config 5) inside the 256-VGPR budget of a
 // 512-thread block -- the round-1 <1024 threads, 32 elements> variant spilled 212 VGPRs to scratch there.
 // TIO = float (engine buffers) or double (nmfx_projfunc on float64 input: no fp32 rounding anywhere).
-// dir != nullptr fuses the line-search step into the load: s = x + mu*dir (fp32, as the separate axpy kernel computed it; nmfsc.m:154).
+// dir != nullptr fuses the line-search step into the load: s = x + mu*dir in fp64 (nmfsc.m:154; rounding the stepped vector -- or mu -- to fp32
+// first costs parity where the projection amplifies: H off by 4e-6 on a K = 3 problem from that rounding alone).  dir64: the direction as doubles.
 // Two block reductions per inner iteration instead of the three a literal transcription needs: the pass that applies
 // v = alpha*w + v (projfunc.m:38) also gathers what lines 49-51 would need if the loop goes on -- |{v <= 0}| and the sum of the
 // entries that survive the zeroing (the zeros add exactly 0.0) -- and the zeroing + redistribution of lines 50-53 is applied
 // element-wise at the top of the next sweep.
-template <int THREADS, int ER, int EL, typename TIO>
-__global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, float mu, const TIO *src) {
+template <int THREADS, int ER, int EL, typename TIO, bool D64>
+__global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
     constexpr int WAVES = THREADS / 64;
     __shared__ double red[WAVES * 4];
     extern __shared__ __attribute__((aligned(16))) double vl[];   // [EL][THREADS]
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     const unsigned vbytes = (unsigned)(len * (long)sizeof(TIO));
     const __amdgpu_buffer_rsrc_t xo_srd = __builtin_amdgcn_make_buffer_rsrc((void *)(X + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xi_srd = __builtin_amdgcn_make_buffer_rsrc((void *)((src ? src : X) + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dx_srd = __builtin_amdgcn_make_buffer_rsrc((void *)(dir ? dir + len * blockIdx.x : (const float *)X), 0, dir ? (int)(unsigned)(len * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dx_srd = D64 ? __builtin_amdgcn_make_buffer_rsrc((void *)(dir64 + len * blockIdx.x), 0, (int)(unsigned)(len * 8), 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void *)(dir ? dir + len * blockIdx.x : (const float *)X), 0, dir ? (int)(unsigned)(len * 4) : 0, 0x00020000);
     auto ld = [&](const __amdgpu_buffer_rsrc_t srd, int e) -> double {
         const int voff = (int)(threadIdx.x * sizeof(TIO)), ioff = e * THREADS * (int)sizeof(TIO);
         if (sizeof(TIO) == 4) return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff, ioff, 0));
@@ -131,9 +133,10 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     for (int e = 0; e < EPT; ++e) {
         const bool ok = valid(e);
         double s = ld(xi_srd, e);
-        if (sizeof(TIO) == 4 && dir) {                                     // uniform branch
-            const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dx_srd, (int)(threadIdx.x * 4), e * THREADS * 4, 0));
-            s = (double)((float)s + mu * d);
+        if (D64) {                                                          // (a template switch: the 64-bit loads cost the big instantiations their last registers)
+            s = fma(mu, __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(dx_srd, (int)(threadIdx.x * 8), e * THREADS * 8, 0)), s);
+        } else if (sizeof(TIO) == 4 && dir) {
+            s = fma(mu, (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dx_srd, (int)(threadIdx.x * 4), e * THREADS * 4, 0)), s);
         }
         const bool neg = !nn && s < 0;                                     // projfunc.m:16-19
         ngm[e >> 5] |= neg ? (1u << (e & 31)) : 0u;
@@ -202,15 +205,33 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
 }
 
 template <int THREADS, int ER, int EL, typename TIO>
-static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, float mu, const TIO *src) {
-    auto kern = projfunc_kernel<THREADS, ER, EL, TIO>;
+static nmfx_status launch_pf64(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, double mu, const TIO *src, const double *dir64) {
+    if constexpr (sizeof(TIO) == 4) {
+        auto kern = projfunc_kernel<THREADS, ER, EL, TIO, true>;
+        const size_t ldsb = sizeof(double) * EL * THREADS;
+        static bool attr_done = false;
+        if (ldsb > 48 * 1024 && !attr_done) {
+            NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, nullptr, mu, src, dir64);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
+    set_error("projfunc: a float64 direction needs fp32 vectors");
+    return NMFX_ERR_INVALID;
+}
+template <int THREADS, int ER, int EL, typename TIO>
+static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
+    if (dir64) return launch_pf64<THREADS, ER, EL, TIO>(st, X, len, count, k1, k2, nn, usediters, mu, src, dir64);
+    auto kern = projfunc_kernel<THREADS, ER, EL, TIO, false>;
     const size_t ldsb = sizeof(double) * EL * THREADS;
     static bool attr_done = false;
     if (ldsb > 48 * 1024 && !attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu, src);
+    hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu, src, dir64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -218,17 +239,20 @@ static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double
 // Any length: the working vector lives in a global fp64 scratch row (L2-resident for realistic sizes) instead of registers.
 template <typename TIO>
 __global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, double *scratch,
-                                                                  unsigned char *flags, const float *dir, float mu) {
+                                                                  unsigned char *flags, const float *dir, double mu, const double *dir64) {
     __shared__ double red[PF_WAVES * 4];
     TIO *x = X + len * blockIdx.x;
     const float *dx = dir ? dir + len * blockIdx.x : nullptr;
+    const double *dx64 = dir64 ? dir64 + len * blockIdx.x : nullptr;
     double *v = scratch + len * blockIdx.x;
     unsigned char *fl = flags + len * blockIdx.x;   // bit0: in Z, bit1: was negative
     const int tid = threadIdx.x;
     const double N = (double)len;
     Red4 r = {0.0, 0.0, 0.0, 0.0};
     for (long i = tid; i < len; i += PF_THREADS) {
-        double s = (sizeof(TIO) == 4 && dx) ? (double)((float)x[i] + mu * dx[i]) : (double)x[i];
+        double s = (double)x[i];
+        if (sizeof(TIO) == 4 && dx64) s = fma(mu, dx64[i], s);
+        else if (sizeof(TIO) == 4 && dx) s = fma(mu, (double)dx[i], s);
         unsigned char f = 0;
         if (!nn) { if (s < 0) f = 2; s = fabs(s); }
         v[i] = s; fl[i] = f; r.a += s;
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(PF_THREADS) void projfunc_long_kernel(TIO *X, long 
 // ---- the same projection with every vector split over ranks (column-sharded H of nmfsc) --------------
 // projfunc.m:22-53 as four phases; between phases the caller all-reduces red[4*count] (sum over ranks), so every rank sees the
 // same sums and takes the same branches.  state[2k] = |Z| of vector k (global), state[2k+1] = 1 once all(v >= 0) held.
-__global__ __launch_bounds__(PF_THREADS) void pfd_init_kernel(const float *X, long len, int nn, double *V, unsigned char *F, double *red, double *state) {
+__global__ __launch_bounds__(PF_THREADS) void pfd_init_kernel(const float *X, long len, int nn, double *V, unsigned char *F, double *red, double *state,
+                                                              const float *dir, const double *dir64, double mu) {   // the vectors projected: X + mu*dir (fp64)
     __shared__ double sred[PF_WAVES * 4];
     const long k = blockIdx.x;
     const float *x = X + len * k;
@@ -289,6 +314,8 @@ __global__ __launch_bounds__(PF_THREADS) void pfd_init_kernel(const float *X, lo
     Red4 r = {0.0, 0.0, 0.0, 0.0};
     for (long i = threadIdx.x; i < len; i += PF_THREADS) {
         double s = (double)x[i];
+        if (dir64) s = fma(mu, dir64[len * k + i], s);
+        else if (dir) s = fma(mu, (double)dir[len * k + i], s);
         unsigned char f = 0;
         if (!nn) { if (s < 0) f = 2; s = fabs(s); }                               // projfunc.m:16-19
         v[i] = s; fl[i] = f; r.a += s;
@@ -374,13 +401,13 @@ __global__ __launch_bounds__(PF_THREADS) void pfd_store_kernel(float *X, const d
 }
 
 nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, long N_total, double k1, double k2, int nn, const Comm &comm,
-                               double *v_scratch, unsigned char *flags, double *red) {
+                               double *v_scratch, unsigned char *flags, double *red, const float *dir, double mu, const float *src, const double *dir64) {
     if (count <= 0 || len <= 0) return NMFX_OK;
     const dim3 g(count), b(PF_THREADS);
     double *state = red + 4L * count;
     const double N = (double)N_total;
     std::vector<double> host(4 * (size_t)count);
-    hipLaunchKernelGGL(pfd_init_kernel, g, b, 0, st, X, len, nn, v_scratch, flags, red, state);
+    hipLaunchKernelGGL(pfd_init_kernel, g, b, 0, st, src ? src : X, len, nn, v_scratch, flags, red, state, dir, dir64, mu);
     NMFX_HIP(hipGetLastError());
     nmfx_status rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM);
     if (rc != NMFX_OK) return rc;
@@ -406,17 +433,17 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
 }
 
 template <typename TIO>
-static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu,
-                                   const TIO *src) {
+static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, double mu,
+                                   const TIO *src, const double *dir64) {
     if (count <= 0 || len <= 0) return NMFX_OK;
     // elements per thread: registers first, then LDS (see projfunc_kernel)
-    if (len <= 1024L) return launch_pf<256, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 4096L) return launch_pf<1024, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 8192L) return launch_pf<1024, 8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 16384L) return launch_pf<1024, 16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 24576L) return launch_pf<512, 48, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 32768L) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
-    if (len <= 40960L) return launch_pf<512, 48, 32, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+    if (len <= 1024L) return launch_pf<256, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 4096L) return launch_pf<1024, 4, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 8192L) return launch_pf<1024, 8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 16384L) return launch_pf<1024, 16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 24576L) return launch_pf<512, 48, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 32768L) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 40960L) return launch_pf<512, 48, 32, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     // longer than registers + LDS hold: global fp64 working rows (allocated per call; this is the rare path)
     if (src && src != X) NMFX_HIP(hipMemcpyAsync(X, src, sizeof(TIO) * (size_t)len * count, hipMemcpyDeviceToDevice, st));
     double *scratch = nullptr;
@@ -424,7 +451,7 @@ static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, 
     NMFX_HIP(hipMalloc(&scratch, sizeof(double) * (size_t)len * count));
     hipError_t e2 = hipMalloc(&flags, (size_t)len * count);
     if (e2 != hipSuccess) { (void)hipFree(scratch); set_error("projfunc: hipMalloc failed: %s", hipGetErrorString(e2)); return NMFX_ERR_NOMEM; }
-    hipLaunchKernelGGL(projfunc_long_kernel<TIO>, dim3(count), dim3(PF_THREADS), 0, st, X, len, k1, k2, nn, usediters_dev, scratch, flags, dir, mu);
+    hipLaunchKernelGGL(projfunc_long_kernel<TIO>, dim3(count), dim3(PF_THREADS), 0, st, X, len, k1, k2, nn, usediters_dev, scratch, flags, dir, mu, dir64);
     hipError_t e3 = hipGetLastError();
     if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
     (void)hipFree(scratch); (void)hipFree(flags);
@@ -432,12 +459,12 @@ static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, 
     return NMFX_OK;
 }
 
-nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, float mu,
-                          const float *src) {
-    return projfunc_cols_t<float>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src);
+nmfx_status projfunc_cols(hipStream_t st, float *X, long len, int count, double k1, double k2, int nn, int *usediters_dev, const float *dir, double mu,
+                          const float *src, const double *dir64) {
+    return projfunc_cols_t<float>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
 }
 nmfx_status projfunc_cols_f64(hipStream_t st, double *X, long len, int count, double k1, double k2, int nn, int *usediters_dev) {
-    return projfunc_cols_t<double>(st, X, len, count, k1, k2, nn, usediters_dev, nullptr, 0.0f, nullptr);
+    return projfunc_cols_t<double>(st, X, len, count, k1, k2, nn, usediters_dev, nullptr, 0.0, nullptr, nullptr);
 }
 
 }  // namespace nmfx

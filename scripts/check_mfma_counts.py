@@ -27,7 +27,7 @@ for f in files:
         K, func, g2 = int(m.group(1)), int(m.group(3)), int(m.group(4))
         if func == 2 and not g2:
             continue                                  # instantiated but never launched (no cost, no second product)
-        want = (K if func != 0 else 0) + (32 * (K // 32) * (2 if func >= 4 else 1) if g2 else 0)
+        want = (K if func != 0 else 0) + (32 * (K // 32) * (2 if func in (4, 5) else 1) if g2 else 0)
         got = sum("v_mfma" in l for l in lines[s:end])
         if got != want:
             bad += 1
