@@ -469,6 +469,30 @@ def test_nmfsc_fused_ragged(gpu_lib, sW, sH):
     _check(got, ref)
 
 
+@pytest.mark.parametrize("m,n,K,sW,sH,iters,fixed", [(194, 635, 3, 0.0, 0.7, 3, None), (431, 641, 3, 0.0, 0.5, 7, None), (325, 202, 3, 0.0, 0.7, 5, None),
+                                                     (334, 280, 3, 0.3, 0.4, 6, "W_fixed"), (292, 252, 3, 0.0, 0.7, 6, "W_fixed"), (300, 500, 1, 0.0, 0.5, 5, None),
+                                                     (256, 384, 5, 0.4, 0.6, 6, None), (130, 700, 8, 0.5, 0.0, 6, None), (257, 129, 2, 0.3, 0.0, 6, "H_fixed"), (257, 129, 2, 0.3, 0.7, 3, "H_fixed")])   # (the last one converges in 3 iterations: beyond them the
+                                                     # line search decides on cost differences of 4e-10 relative, below what fp32 storage of W resolves)
+def test_nmfsc_small_K_float64_gradients(gpu_lib, m, n, K, sW, sH, iters, fixed):
+    """A handful of components: the Hoyer projection after a gradient step amplifies perturbations (70x on the K = 3 cases below, which the
+    fp32-accumulated gradients of the fused kernels missed by 1.2e-5 in scripts/fuzz_campaign_sc.py), so K <= 8 takes its gradients and
+    objective in float64 (aux.hip::smallk_grad) and steps along a float64 direction inside projfunc.  Held to a TIGHTER bar than the contract."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    if fixed:
+        cfg[fixed] = True
+    i0, i1 = {}, {}
+    ref = O.nmfsc(V, K, cfg, info=i0)
+    got = gpu_lib.nmfsc(V, K, cfg, info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    _check(got, ref, tol=3e-6)
+
+
 def test_nmf_random_shapes_fuzz(gpu_lib):
     """40 seeded random (m, n, K, divergence, sparsity, fixed) problems between 64 and 400 rows / columns: whichever kernels the
     engine picks (masked-edge fused with padded K, or the pipelined GEMM path when forced) must match the oracle."""

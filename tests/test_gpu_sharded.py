@@ -411,6 +411,23 @@ def test_nmfsc_sharded_any_K_and_negative_data(gpu_lib):
         _nmfsc_threads(Vn, W0, H0, 2, maxiter=2)
 
 
+@pytest.mark.parametrize("K", [3, 8])
+def test_nmfsc_small_K_column_shards_equal_oracle(gpu_lib, K):
+    """K <= 8 on column shards: the float64 gradient kernels (aux.hip::smallk_grad), dW summed over the shards as doubles, the
+    distributed projfunc stepping along a float64 direction"""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(200, 640, K)
+    for sW, sH in ((0.0, 0.7), (0.3, 0.4), (0.5, 0.0)):
+        i0 = {}
+        cfg = dict(W_init=W0, H_init=H0, maxiter=6, tolerance=1e-300, W_sparsity=sW, H_sparsity=sH)
+        W, H, cost = O.nmfsc(V, K, cfg, info=i0)
+        res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=sW, H_sparsity=sH, maxiter=6, tolerance=1e-300)
+        Hs = np.concatenate([r[1] for r in res], axis=1)
+        assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
+        assert np.array_equal(res[1][0], res[0][0])
+        assert rel_fro(res[0][0], W) <= 1e-5 and rel_fro(Hs, H) <= 1e-5 and rel_fro(res[0][2], cost) <= 1e-6, (K, sW, sH, rel_fro(res[0][0], W), rel_fro(Hs, H))
+
+
 def test_nmfsc_ragged_column_shards_equal_oracle(gpu_lib):
     """300 + 300 columns (not multiples of 128) and m = 257: the masked-edge kernels under the sharded nmfsc"""
     from oracle import nmf_oracle as O
@@ -421,7 +438,7 @@ def test_nmfsc_ragged_column_shards_equal_oracle(gpu_lib):
     res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
     Hs = np.concatenate([r[1] for r in res], axis=1)
     assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
-    assert rel_fro(res[0][0], W) <= 2e-5 and rel_fro(Hs, H) <= 2e-5 and rel_fro(res[0][2], cost) <= 2e-6
+    assert rel_fro(res[0][0], W) <= 1e-5 and rel_fro(Hs, H) <= 1e-5 and rel_fro(res[0][2], cost) <= 1e-6, (rel_fro(res[0][0], W), rel_fro(Hs, H))
 
 
 def _nmfsc_dist_worker(rank, world, port, q):
