@@ -6,6 +6,7 @@
 // HBM traffic is one read and one write of the vector.
 #include <vector>
 
+#include <cstdlib>
 #include "nmfx_internal.h"
 
 namespace nmfx {
@@ -14,7 +15,7 @@ constexpr int PF_THREADS = 1024;
 constexpr int PF_WAVES = PF_THREADS / 64;
 constexpr int PF_MAX_ITERS = 100000;
 #ifndef PF_GROUP
-#define PF_GROUP 4
+#define PF_GROUP 8
 #endif  // safety cap: the reference loops forever on NaN input
 
 struct Red4 { double a, b, c, d; };
@@ -92,8 +93,8 @@ __device__ __forceinline__ Red4 block_red4_w(Red4 v, double *red) {
 // v = alpha*w + v (projfunc.m:38) also gathers what lines 49-51 would need if the loop goes on -- |{v <= 0}| and the sum of the
 // entries that survive the zeroing (the zeros add exactly 0.0) -- and the zeroing + redistribution of lines 50-53 is applied
 // element-wise at the top of the next sweep.
-template <int THREADS, int ER, int EL, typename TIO, bool D64>
-__global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
+template <int THREADS, int ER, int EL, typename TIO, int DM>   // DM: 0 no step | 1 fp32 direction | 2 float64 direction -- compile-time: with run-time branches hipcc
+__global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X,   /* joins all EPT loaded values in PHIs and processes them after the join: twice the live set, 50 spilled VGPRs */ long len, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
     constexpr int WAVES = THREADS / 64;
     __shared__ double red[WAVES * 4];
     extern __shared__ __attribute__((aligned(16))) double vl[];   // [EL][THREADS]
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     const unsigned vbytes = (unsigned)(len * (long)sizeof(TIO));
     const __amdgpu_buffer_rsrc_t xo_srd = __builtin_amdgcn_make_buffer_rsrc((void *)(X + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xi_srd = __builtin_amdgcn_make_buffer_rsrc((void *)((src ? src : X) + len * blockIdx.x), 0, (int)vbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dx_srd = D64 ? __builtin_amdgcn_make_buffer_rsrc((void *)(dir64 + len * blockIdx.x), 0, (int)(unsigned)(len * 8), 0x00020000)
+    const __amdgpu_buffer_rsrc_t dx_srd = DM == 2 ? __builtin_amdgcn_make_buffer_rsrc((void *)(dir64 + len * blockIdx.x), 0, (int)(unsigned)(len * 8), 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc((void *)(dir ? dir + len * blockIdx.x : (const float *)X), 0, dir ? (int)(unsigned)(len * 4) : 0, 0x00020000);
     auto ld = [&](const __amdgpu_buffer_rsrc_t srd, int e) -> double {
         const int voff = (int)(threadIdx.x * sizeof(TIO)), ioff = e * THREADS * (int)sizeof(TIO);
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     for (int e = 0; e < EPT; ++e) {
         const bool ok = valid(e);
         double s = ld(xi_srd, e);
-        if (D64) {                                                          // (a template switch: the 64-bit loads cost the big instantiations their last registers)
+        if (DM == 2) {
             s = fma(mu, __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(dx_srd, (int)(threadIdx.x * 8), e * THREADS * 8, 0)), s);
-        } else if (sizeof(TIO) == 4 && dir) {
+        } else if (DM == 1) {
             s = fma(mu, (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dx_srd, (int)(threadIdx.x * 4), e * THREADS * 4, 0)), s);
         }
         const bool neg = !nn && s < 0;                                     // projfunc.m:16-19
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
         r.a += s;
         if ((e & (PF_GROUP - 1)) == PF_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
+    // pin the sign bits NOW: left alone, hipcc re-derives them at the store phase from the loaded values, which then stay live through
+    // the whole kernel (one VGPR per element for fp32 input, two -- 50 of them spilled -- once the values are doubles: stepped or fp64 input)
+#pragma unroll
+    for (int q = 0; q < (EPT + 31) / 32; ++q) asm volatile("" : "+v"(ngm[q]));
     r = block_red4_w<WAVES>(r, red);
     double shift = (k1 - r.a) / N;                                         // projfunc.m:22
     bool zero_first = false;                                               // the pending element-wise step: v += shift off Z (first: everywhere)
@@ -204,27 +209,9 @@ __global__ __launch_bounds__(THREADS) void projfunc_kernel(TIO *X, long len, dou
     if (usediters && tid == 0) usediters[blockIdx.x] = j + 1;
 }
 
-template <int THREADS, int ER, int EL, typename TIO>
-static nmfx_status launch_pf64(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, double mu, const TIO *src, const double *dir64) {
-    if constexpr (sizeof(TIO) == 4) {
-        auto kern = projfunc_kernel<THREADS, ER, EL, TIO, true>;
-        const size_t ldsb = sizeof(double) * EL * THREADS;
-        static bool attr_done = false;
-        if (ldsb > 48 * 1024 && !attr_done) {
-            NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, nullptr, mu, src, dir64);
-        NMFX_HIP(hipGetLastError());
-        return NMFX_OK;
-    }
-    set_error("projfunc: a float64 direction needs fp32 vectors");
-    return NMFX_ERR_INVALID;
-}
-template <int THREADS, int ER, int EL, typename TIO>
-static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
-    if (dir64) return launch_pf64<THREADS, ER, EL, TIO>(st, X, len, count, k1, k2, nn, usediters, mu, src, dir64);
-    auto kern = projfunc_kernel<THREADS, ER, EL, TIO, false>;
+template <int THREADS, int ER, int EL, typename TIO, int DM>
+static nmfx_status launch_pf_dm(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
+    auto kern = projfunc_kernel<THREADS, ER, EL, TIO, DM>;
     const size_t ldsb = sizeof(double) * EL * THREADS;
     static bool attr_done = false;
     if (ldsb > 48 * 1024 && !attr_done) {
@@ -234,6 +221,17 @@ static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double
     hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu, src, dir64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
+}
+template <int THREADS, int ER, int EL, typename TIO>
+static nmfx_status launch_pf(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
+    if constexpr (sizeof(TIO) == 4) {
+        if (dir64) return launch_pf_dm<THREADS, ER, EL, TIO, 2>(st, X, len, count, k1, k2, nn, usediters, nullptr, mu, src, dir64);
+        if (dir) return launch_pf_dm<THREADS, ER, EL, TIO, 1>(st, X, len, count, k1, k2, nn, usediters, dir, mu, src, nullptr);
+    } else if (dir || dir64) {
+        set_error("projfunc: the fused line-search step needs fp32 vectors");
+        return NMFX_ERR_INVALID;
+    }
+    return launch_pf_dm<THREADS, ER, EL, TIO, 0>(st, X, len, count, k1, k2, nn, usediters, nullptr, 0.0, src, nullptr);
 }
 
 // Any length: the working vector lives in a global fp64 scratch row (L2-resident for realistic sizes) instead of registers.
@@ -442,7 +440,10 @@ static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, 
     if (len <= 8192L) return launch_pf<1024, 8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 16384L) return launch_pf<1024, 16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 24576L) return launch_pf<512, 48, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
-    if (len <= 32768L) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    static const int pf_variant = getenv("NMFX_PF_VARIANT") ? atoi(getenv("NMFX_PF_VARIANT")) : 0;   // dev switch (A/B runs)
+    if (len <= 32768L && pf_variant == 1) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 32768L && pf_variant == 2) return launch_pf<1024, 32, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    if (len <= 32768L) return launch_pf<512, 64, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 40960L) return launch_pf<512, 48, 32, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     // longer than registers + LDS hold: global fp64 working rows (allocated per call; this is the rare path)
     if (src && src != X) NMFX_HIP(hipMemcpyAsync(X, src, sizeof(TIO) * (size_t)len * count, hipMemcpyDeviceToDevice, st));
