@@ -111,7 +111,7 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
     kw = dict(H_sparsity=args.h_sparsity, tolerance=-1.0, path=args.path)
     c0, info = nmfsc_sharded(V, W, H, maxiter=max(args.warmup, 1), **kw)
     sync()
-    _lib.check(lib.nmfx_nmfsc_profile(1))
+    _lib.check(lib.nmfx_nmfsc_profile(0 if args.no_profile else 1))
     t0 = time.perf_counter()
     c1, info1 = nmfsc_sharded(V, W, H, maxiter=args.steps, resume=info, **kw)
     sync()

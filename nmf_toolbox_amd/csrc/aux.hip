@@ -661,6 +661,29 @@ nmfx_status finish_cost(hipStream_t st, const double *partials, int count, doubl
     return NMFX_OK;
 }
 
+// out[0] = scale * sum(partials) (or *src when partials == nullptr), also published to a host-mapped slot: slot[0] = the value, then -- after a
+// system-scope fence -- slot[1] = seq (bit pattern), which the host thread polls instead of synchronising the stream
+__global__ __launch_bounds__(256) void publish_obj_kernel(const double *partials, int count, double scale, const double *src, double *out, double *slot, unsigned long long seq) {
+    __shared__ double red[4];
+    double s = 0.0;
+    if (partials) {
+        for (int i = threadIdx.x; i < count; i += 256) s += partials[i];
+        s = block_sum<4>(s, red) * scale;
+    } else s = *src;
+    if (threadIdx.x == 0) {
+        if (out) *out = s;
+        if (slot) {
+            __hip_atomic_store(slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+nmfx_status publish_obj(hipStream_t st, const double *partials, int count, double scale, const double *src, double *out, double *slot, unsigned long long seq) {
+    hipLaunchKernelGGL(publish_obj_kernel, dim3(1), dim3(256), 0, st, partials, count, scale, src, out, slot, seq);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 __global__ void fill_kernel(float *p, long count, float v) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < count) p[idx] = v;

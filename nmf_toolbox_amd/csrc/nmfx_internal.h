@@ -187,6 +187,7 @@ nmfx_status finish_cost(hipStream_t st, const double *partials, int count, doubl
                         const double *pre_c = nullptr, double pre_a = 0.0, double pre_b = 0.0,    // scale * (sum(partials) + pre_a * *pre_c + pre_b)
                         double *out2 = nullptr,                                                   // second destination of the cost (the caller's cost vector)
                         const double *cvt_src = nullptr, float *cvt_dst = nullptr, int ncvt = 0);  // + cvt_dst[i] = (float)cvt_src[i]  (rowsum(H) into the tail of `packed`)
+nmfx_status publish_obj(hipStream_t st, const double *partials, int count, double scale, const double *src, double *out, double *slot, unsigned long long seq);
 nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out);
 nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
