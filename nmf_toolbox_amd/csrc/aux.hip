@@ -49,8 +49,42 @@ __global__ void reduce_slabs_kernel(const float *slabs, int nslab, long stride, 
         }
     }
 }
+// first level of the two-level reduction: group y sums its `g` consecutive slabs into the first of them (in place)
+__global__ void reduce_slab_groups_kernel(float *slabs, int nslab, int g, long stride, long count) {
+    const int s0 = blockIdx.y * g, ns = nslab - s0 < g ? nslab - s0 : g;
+    float *base = slabs + (long)s0 * stride;
+    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (idx + 3 < count && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (stride & 3) == 0) {
+        float4 s = *reinterpret_cast<const float4 *>(base + idx);
+        for (int z = 1; z < ns; ++z) {
+            const float4 t = *reinterpret_cast<const float4 *>(base + z * stride + idx);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(base + idx) = s;
+    } else {
+        for (long e = idx; e < idx + 4 && e < count; ++e) {
+            float s = base[e];
+            for (int z = 1; z < ns; ++z) s += base[z * stride + e];
+            base[e] = s;
+        }
+    }
+}
 nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out, int accumulate) {
     if (count <= 0) return NMFX_OK;
+    // Small outputs with many slabs (the K x K Gram products: 128 x 128 floats, up to 256 split-K slabs) gave the single-level kernel 16
+    // workgroups to pull 16 MB through (31 us at C2).  Two levels: ~sqrt(nslab) groups summed in place by their own workgroups, then the
+    // group heads.  The summation order is fixed by (nslab, count) alone: results stay run-to-run deterministic.  The slabs are scratch.
+    if (nslab >= 16 && count <= (1L << 18)) {
+        int g = 4;
+        while (g * g < nslab) g *= 2;
+        const int ngroups = (nslab + g - 1) / g;
+        const long nthr1 = (count + 3) / 4;
+        hipLaunchKernelGGL(reduce_slab_groups_kernel, dim3((unsigned)((nthr1 + 255) / 256), (unsigned)ngroups), dim3(256), 0, st, const_cast<float *>(slabs), nslab, g, slab_stride, count);
+        NMFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nthr1 + 255) / 256)), dim3(256), 0, st, slabs, ngroups, slab_stride * g, count, out, accumulate);
+        NMFX_HIP(hipGetLastError());
+        return NMFX_OK;
+    }
     long nthr = (count + 3) / 4;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, slabs, nslab, slab_stride, count, out, accumulate);
     NMFX_HIP(hipGetLastError());

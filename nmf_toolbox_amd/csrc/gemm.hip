@@ -339,7 +339,7 @@ int gemm_pick_split(long M, long N, long Kc) {
     int split = 1;
     if (tiles < 512 && ktiles >= 8) {   // two workgroups fit a CU: aim for >= 512 of them
         split = (int)((512 + tiles - 1) / tiles);
-        if (split > 128) split = 128;   // K x K Grams over n: one output tile, all parallelism must come from the contraction
+        if (split > 256) split = 256;   // K x K Grams over n: one output tile, all parallelism must come from the contraction (one workgroup per CU)
         if (split > ktiles / 4) split = (int)(ktiles / 4);
     }
     return split < 1 ? 1 : split;
