@@ -165,6 +165,8 @@ struct nmfx_engine {
     int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
     int chunk_parts;          // cost partials written by the chunks so far
     float *WT, *slabs, *Pbuf, *GW;
+    float *VT;                // euclidean fused path: V' (n x m), built once at init -- the H-step numerator W'*V runs as (V'*W)' on the W-step-form kernel
+    bool use_vt;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
     // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
     float *Z;
@@ -236,6 +238,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
         e->slabs2 = e->dual ? f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn)) : nullptr;
         e->Valpha = (e->dual && e->div == NMFX_DIV_AB && e->alpha != 1.0) ? f.take<float>((size_t)e->m * e->n) : nullptr;
+        e->VT = e->use_vt ? f.take<float>((size_t)e->m * e->n) : nullptr;
         e->Gn = f.take<float>(Kn);
         const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
         e->Gp = (euc || e->dual) ? f.take<float>(Kn) : nullptr;
@@ -359,6 +362,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     e->fused = eligible && d->path != 1;
     if (!e->fused) e->dual = false;
+    static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
+    e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
@@ -747,6 +752,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
         if (e->fused) {
             e->cost_valid = false;
+            if (e->VT) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
             if (e->div == NMFX_DIV_KL) {   // sum(V_local), once
                 TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumV));
@@ -942,7 +948,27 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             if (e->Valpha) f.D = e->Valpha;
         }
         static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
-        if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
+        if (func == 0 && e->VT && !euc_fused_h) {
+            // euclidean: the numerator W'*V has no first product.  The H-step form of the stationary kernel reads its V tile with the lanes
+            // ACROSS columns (16-byte pieces at stride m) and, with half the MFMA work per tile to hide that under, ran 0.61 ms at C2; the
+            // pipelined two-operand GEMM 0.60 ms (0.75 of peak).  V never changes, so a transposed copy made once turns the product into
+            // (V'*W)' on the W-STEP form -- lanes along the contiguous dimension, the pass V*H' already runs at 0.86 of peak:
+            //   stationary rows = columns j of V (rows of V'), streamed rows = rows i of W (the W' copy), out(k, j) at Gn[k + K*j]
+            FusedParams g;
+            memset(&g, 0, sizeof(g));
+            g.Y = e->WT; g.D = e->VT; g.ldd = e->n; g.R = e->n; g.Cn = e->m; g.K = e->K; g.c_per_split = e->cps_h;
+            g.out = e->isplit_h == 1 ? e->Gn : e->slabs; g.slab_stride = (long)e->K * e->n; g.os_r = e->K; g.os_k = 1;
+            {
+                Scope s(e, TAG_HNUM);
+                TRY(launch_fused(e->st, g, e->isplit_h, true, 0, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
+            if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, g.slab_stride, g.slab_stride, e->Gn, 0));
+            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, e->isplit_h, g.slab_stride));
+            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        } else if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
             // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
             {
