@@ -167,6 +167,9 @@ struct nmfx_engine {
     float *WT, *slabs, *Pbuf, *GW;
     float *VT;                // euclidean fused path: V' (n x m), built once at init -- the H-step numerator W'*V runs as (V'*W)' on the W-step-form kernel
     bool use_vt;
+    float *WTf;               // cnmf on the fused passes, euclidean: W_flat' (row i = its K*T floats), rebuilt before each Q product
+    bool use_vtq;             // ... whose Q = W_flat'*V runs as (V'*W_flat)' on the W-step-form kernel, K-wide column blocks in grid.z
+    int vtq_block;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
     // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
     float *Z;
@@ -281,6 +284,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         }
     }
     if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
+    if (e->use_vtq) { e->VT = c.take<float>((size_t)e->m * e->n); e->WTf = c.take<float>(mKT); }
     if (e->fusedT_kl) {
         e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
         e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
@@ -380,6 +384,12 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
     static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
     e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
+    {   // euclidean cnmf on the fused passes, unsharded: the Q product of the H step on a transposed copy of V (see nmfx_engine_hstep)
+        static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;
+        static const int vtq_env = getenv("NMFX_VTQ_BLOCK") ? atoi(getenv("NMFX_VTQ_BLOCK")) : 0;   // dev switch: 128 | 256
+        e->vtq_block = vtq_env ? vtq_env : 128;   // C4 (K*T = 512): four 128-wide blocks, two workgroups per CU, 0.526 ms; two 256-wide blocks 0.549; the two-operand GEMM 0.585
+        e->use_vtq = e->fusedT && e->qgemm && e->hL == 0 && e->hR == 0 && !no_vt && e->KT % e->vtq_block == 0 && fused_supported(e->vtq_block);
+    }
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
         e->nsplit_w = fused_split((e->m + 127) / 128, e->n, e->K, &e->cps_w);
@@ -765,7 +775,10 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             return refresh_w_derived(e);
         }
     }
-    if (e->gram) return NMFX_OK;   // no V_hat state on the Gram path
+    if (e->gram) {                 // no V_hat state on the Gram path
+        if (e->use_vtq) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+        return NMFX_OK;
+    }
     if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
         Scope s(e, TAG_SMALL);
         e->cost_valid = false;
@@ -1032,7 +1045,30 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         if (e->qgemm) {
             // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
             // (K x n) GEMM with contraction T*m whose 64-row output starves the tiles
-            {
+            if (e->use_vtq && a.p == e->V && !a.p2 && a.func == NMFX_PRO_NONE && e->nvalid == e->n) {
+                // Q' = V' * W_flat on the W-step form of the stationary kernel (rows of V' stationary, rows of W_flat streamed as K-wide column
+                // blocks, one block per grid.z): its V tile is read along the contiguous dimension, which the two-operand GEMM (0.77 of peak
+                // here) and the H-step form cannot offer
+                {
+                    Scope s2(e, TAG_SMALL);
+                    TRY(transpose_f32(e->st, e->W, e->m, e->KT, e->WTf));
+                }
+                FusedParams q;
+                memset(&q, 0, sizeof(q));
+                const int kb = e->vtq_block;
+                q.Y = e->WTf; q.y_stride = e->KT; q.nz = e->KT / kb; q.yz_stride = kb; q.oz_stride = kb;
+                q.D = e->VT; q.ldd = e->n; q.R = e->n; q.Cn = e->m; q.K = kb;
+                long cps = 0;
+                const int split = fused_split(((e->n + 127) / 128) * q.nz, e->m, kb, &cps);
+                const bool can_split = split > 1 && e->gemm_scratch_bytes >= sizeof(float) * (size_t)split * e->KT * e->n;
+                q.c_per_split = can_split ? cps : (e->m + 63) / 64 * 64;
+                q.out = can_split ? e->gemm_scratch : e->Qbuf; q.slab_stride = (long)e->KT * e->n; q.os_r = e->KT; q.os_k = 1;
+                {
+                    Scope s2(e, TAG_HNUM);
+                    TRY(launch_fused(e->st, q, can_split ? split : 1, true, 0, true, 0));
+                }
+                if (can_split) { Scope s2(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->gemm_scratch, split, q.slab_stride, q.slab_stride, e->Qbuf, 0)); }
+            } else {
                 Scope s(e, TAG_HNUM);
                 GemmParams g;
                 memset(&g, 0, sizeof(g));

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // Streamed tile: LDS-DMA (buffer_load_dwordx4 ... lds), one 1-KiB row of K floats per wave-instruction, wave w moves rows
     // w, w+4, ...  Issued as inline asm so hipcc does not see an LDS write (with the builtin it drains vmcnt(0) before the next
     // ds_read and serialises the DMA latency into every tile); completion = s_waitcnt vmcnt(0) + barrier at the tile top.
+    const float *const Yz = p.Y + (TT == 1 ? (long)blockIdx.z * p.yz_stride : 0L);   // grid.z: K-wide column blocks of wider streamed rows (one launch for a Kw > 256 wide factor)
     const int ystride = p.y_stride > 0 ? (int)p.y_stride : K;   // floats between streamed rows in memory (> K: a K-wide column block of wider rows)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned y_voff = (unsigned)lane * 16u;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     };
     auto y_srd = [&](int t) {
         if (TT > 1) return make_srd(p.Y + (cbeg + (long)t * FT_C - (TT - 1)) * KH, (unsigned)((tile_rows(t) + TT - 1) * KH * 4));
-        return make_srd(p.Y + (cbeg + (long)t * FT_C) * ystride, (unsigned)(tile_rows(t) > 0 ? ((tile_rows(t) - 1) * ystride + K) * 4 : 0));
+        return make_srd(Yz + (cbeg + (long)t * FT_C) * ystride, (unsigned)(tile_rows(t) > 0 ? ((tile_rows(t) - 1) * ystride + K) * 4 : 0));
     };
 
     // V tile of step t: d[jb*16 + reg] = V(r, c = c0 + 32*jb + rowmap(reg, h))
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // epilogue: acc[kb][reg] = O(k = 32*kb + rowmap(reg,h), r)
     if (DO_G2) {
         if (EPI == 0) {
-            float *out = p.out + (long)blockIdx.y * p.slab_stride;
+            float *out = p.out + (long)blockIdx.y * p.slab_stride + (TT == 1 ? (long)blockIdx.z * p.oz_stride : 0L);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll

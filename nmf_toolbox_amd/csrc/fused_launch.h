@@ -13,7 +13,7 @@ static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) 
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_done = true;
     }
-    dim3 grid((unsigned)((p.R + FT_ROWS - 1) / FT_ROWS), (unsigned)nsplit);
+    dim3 grid((unsigned)((p.R + FT_ROWS - 1) / FT_ROWS), (unsigned)nsplit, (unsigned)(p.nz > 1 ? p.nz : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

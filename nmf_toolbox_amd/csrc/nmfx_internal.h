@@ -107,6 +107,8 @@ struct FusedParams {
     long xs_t, os_t;      //   preceded by T-1 readable columns (zeros or a shard's left halo).  0 or 1: plain nmf
     const float *Y;       // streamed factor: row c = K contiguous floats at Y + c*y_stride  (W step: columns of H; H step: rows of W = W^T copy)
     long y_stride;        // 0 = K.  > K: the K floats are a column block of longer rows (H-step numerator of a wide factor in blocks of <= 256)
+    int nz;               // grid.z (0 / 1: none): block z streams the K floats at Y + z*yz_stride of every row and writes at out + z*oz_stride (T <= 1 only)
+    long yz_stride, oz_stride;
     const float *D;       // V (m x n, ld = ldd); W step reads V(r, c) = D[r + ldd*c], H step V(c, r) = D[c + ldd*r]
     long ldd;
     long R, Cn;           // stationary rows (multiple of 128), streamed rows (multiple of 64)
