@@ -49,6 +49,26 @@ def test_nmf_full_size_paths_agree(gpu_lib, name, div, m, n, K):
     assert np.allclose(cf, cg, rtol=2e-6)
 
 
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
+def test_nmf_beyond_4GiB_paths_agree(gpu_lib, div):
+    """V = 16384 x 131072 fp32 = 8 GiB, 2^31 elements: past every 32-bit element index and byte offset (buffer descriptors are per tile,
+    lane offsets 32-bit, bases 64-bit).  A 288 GB part is meant to hold shards of this size and larger; the euclidean fused path also
+    carries its transposed copy of V here (another 8 GiB)."""
+    import torch
+    m, n, K = 16384, 131072, 64
+    V, W0, H0 = _rand(torch, (n, m), 1000), _rand(torch, (K, m), 1), _rand(torch, (n, K), 2)
+    fused, cf = _run(torch, V, W0, H0, 2, divergence=div, path=2)
+    Wf, Hf = fused.W.clone(), fused.H.clone()
+    fused.close()
+    del fused
+    torch.cuda.empty_cache()
+    gen, cg = _run(torch, V, W0, H0, 2, divergence=div, path=1)
+    assert _rel(Wf, gen.W) < 1e-5 and _rel(Hf, gen.H) < 1e-5, (_rel(Wf, gen.W), _rel(Hf, gen.H))
+    assert np.allclose(cf, cg, rtol=2e-6) and np.all(np.diff(cf) < 0)
+    # the last columns / rows were really reached: an index that wrapped would leave them at their initial values
+    assert float((Hf[-4:] - H0[-4:]).abs().max()) > 0 and float((Wf[:, -4:] - W0[:, -4:]).abs().max()) > 0
+
+
 def test_cnmf_c4_full_size_gram_vs_materialised(gpu_lib):
     import torch
     m, n, K, T = 4096, 16384, 64, 8
