@@ -139,8 +139,16 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
             name = max(tags, key=lambda k: tags[k][0])
             avg_ms = tags[name][0] / tags[name][1]
             ach = work[name][0] / (avg_ms * 1e-3) / 1e12
+            traffic, tsrc = None, None
+            try:   # HBM bytes per launch of the dominant kernel from the separate --pmc passes (not measured in this run)
+                pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json"))).get(args.workload, {})
+                hit = [v for k, v in pm.items() if name.startswith(k)]
+                if hit:
+                    traffic, tsrc = hit[0], "profiles/pmc_traffic.json: HBM bytes per launch from a separate rocprofv3 --pmc pass of the same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run"
+            except Exception:
+                pass
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=None, avg_launch_ms=round(avg_ms, 4), launches=int(tags[name][1]), flops_per_launch=work[name][0],
+                        traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=int(tags[name][1]), flops_per_launch=work[name][0],
                         algorithmic_bytes_per_launch=work[name][1], phases_ms_per_step=phases)
         pj = None
         if cnt[1] > 0:   # projfunc: HBM-class -- one read of H' and of the step direction, one write, per call (nmfsc.m:154-157)

@@ -180,7 +180,7 @@ struct nmfx_engine {
 
 enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6,
                TAG_FUSED_W = 7, TAG_FUSED_H = 8, TAG_FUSED_COST = 9, TAG_GRAM = 10, TAG_COUNT = 11 };
-static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'", "gemm:P=B*H'", "gemm:Gn=W'*A", "gemm:Gp=W'*B",
+static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'", "gemm:P=B*H'", "H-step numerator Gn=W'*A (two-operand GEMM, or the stationary kernel over V')", "gemm:Gp=W'*B",
                                                  "gemm:V_hat=W*H+cost", "small kernels", "fused:W-step (S=W*H -> R -> R*H')",
                                                  "fused:H-step (S=W*H -> R -> W'*R + update)", "fused:cost pass (S=W*H -> D(V||S))",
                                                  "gemm:Gram/K x K products"};
