@@ -139,6 +139,7 @@ struct nmfx_engine {
     int n_cost_partials, n_cost_used;
     // fused path (fused.hip): V_hat is never materialised
     bool fused, cost_valid, defer_hfinish;
+    bool cost_dst2_done;      // set by the finisher that honoured cost_dst2
     double *cost_dst2;        // fused paths: the finisher of the next lagged cost also writes it here (the caller's cost vector), or nullptr
     bool tail_with_cost;      // fused KL: the finisher also converts rowsum(H) into the fp32 tail of `packed` (W-step partial passes only)
     bool dual;                // fused IS / alpha-beta: packed = [N | P], both contractions of a pass come out of one kernel (func 4 / 5)
@@ -497,6 +498,7 @@ nmfx_status small_gemm(nmfx_engine *e, long M, long N, long Kc, OpView A, OpView
 
 nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form = false) {
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (e->cost_dst2) e->cost_dst2_done = true;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
     if (useH) {   // constrainednmf.m:251 charges Z_sparsity on |Z|, not on H = Z*A
         if (e->algo == 3) TRY(row_reduce(e->st, e->Z, e->K, e->K, e->nz, 2, e->l1H, e->rr_scratch));
@@ -521,7 +523,7 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
     const bool tail = e->fused && kl_closed_form && e->tail_with_cost;
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
                        e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV, nullptr, 0.0, 0.0,
-                       e->fused ? e->cost_dst2 : nullptr, tail ? e->rowsum : nullptr, tail ? e->packed + (size_t)e->m * e->KT : nullptr, e->K);
+                       e->cost_dst2, tail ? e->rowsum : nullptr, tail ? e->packed + (size_t)e->m * e->KT : nullptr, e->K);
 }
 
 // grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
@@ -1191,8 +1193,13 @@ nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_
         e->cost_dst2 = nullptr;
         TRY(ws_);
         TRY(nmfx_engine_wstep_finish(e));
-        TRY(nmfx_engine_hstep(e));
-        if (!lag && dev_cost_out) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+        // un-lagged paths: the cost of this iteration is finished inside the H step; its finisher writes the caller's slot too
+        e->cost_dst2 = (!lag && dev_cost_out) ? dev_cost_out + it : nullptr;
+        e->cost_dst2_done = false;
+        nmfx_status hs_ = nmfx_engine_hstep(e);
+        e->cost_dst2 = nullptr;
+        TRY(hs_);
+        if (!lag && dev_cost_out && !e->cost_dst2_done) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
     }
     if (lag && iters > 0 && dev_cost_out) {   // cost of the last iteration: one extra S = W*H pass
         TRY(nmfx_engine_cost_pass(e));
