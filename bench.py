@@ -355,7 +355,7 @@ def main():
             ach = d["flops"] / (avg_ms * 1e-3) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and world == 1:   # the PMC passes were taken on the whole problem: they say nothing about a shard's launch
                 try:
                     traffic = json.load(open(pmc)).get(args.workload, {}).get(name)
                 except Exception:
