@@ -1846,7 +1846,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     //   objective         0.5*||V - W*H||^2          fused cost-only pass (S = W*H in registers)
     //   W'*V, V*H'        fused H-step / W-step passes with R = V
     //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
-    DevBuf WTb, slabs, Gb, Denb, KKb, fparts, g64, s64;
+    DevBuf WTb, slabs, Gb, Denb, KKb, fparts, g64h, g64w, s64;
     const bool smallk = fast && Kv <= smallk_max();   // a handful of components: gradients + objective in fp64 (aux.hip::smallk_grad), handed to projfunc as doubles
     int nsplit_w = 1, isplit_h = 1;
     long cps_w = n, cps_h = m;
@@ -1855,7 +1855,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         isplit_h = fused_split((n + 127) / 128, m, K, &cps_h);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
         TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * std::max<long>(std::max(((m + 127) / 128) * nsplit_w, ((n + 127) / 128) * isplit_h), smallk ? smallk_partials(m, n) : 0)));
-        if (smallk) { TRY(g64.alloc(sizeof(double) * std::max(m, n) * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)smallk_dw_chunks(m, n) * m * Kv)); }
+        if (smallk) { TRY(g64h.alloc(sizeof(double) * n * Kv)); TRY(g64w.alloc(sizeof(double) * m * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)smallk_dw_chunks(m, n) * m * Kv)); }
     }
     // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
@@ -1883,11 +1883,11 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // on small K (scripts/fuzz_campaign_sc.py: H off by 1.3e-5 at K = 3).  The same pass yields 0.5*||V - W*H||^2 of the point it is taken at.
     // Den (K x n) = Wx' * (Wx*Hx - V); *obj = the objective at (Wx, Hx) when asked for
     auto resid_h = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
-        if (smallk) {   // g64 = dH' (n x Kv doubles)
+        if (smallk) {   // g64h = dH' (n x Kv doubles)
             int np_ = 0;
             {
                 PScope ps(pf, SC_HTERMS);
-                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
+                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64h.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
             }
             return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
         }
@@ -1906,13 +1906,14 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         return read_obj(st, fparts.as<double>(), (int)(((n + 127) / 128) * isplit_h), costd.as<double>(), obj, &comm);
     };
     // dW_ (m x K) = (Wx*Hx - V) * Hx', summed over the column shards; *obj as above
-    auto resid_w = [&](const float *Wx, const float *Hx, float *dW_, double *obj) -> nmfx_status {
-        if (smallk) {   // g64 = dW (m x Kv doubles)
+    // (reduce = false: the sum over the column shards is left to the caller -- a speculative evaluation inside the H line search, see below)
+    auto resid_w = [&](const float *Wx, const float *Hx, float *dW_, double *obj, bool reduce = true) -> nmfx_status {
+        if (smallk) {   // g64w = dW (m x Kv doubles)
             int np_ = 0;
             {
                 PScope ps(pf, SC_WTERMS);
-                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
-                if (comm.active()) TRY(comm.allreduce(g64.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64w.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
+                if (comm.active() && reduce) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
             }
             return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
         }
@@ -1925,7 +1926,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             f.cost_partials = fparts.as<double>();
             TRY(launch_fused(st, f, nsplit_w, true, 6, true, 0));
             if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, dW_, 0));
-            if (comm.active()) TRY(comm.allreduce(dW_, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
+            if (comm.active() && reduce) TRY(comm.allreduce(dW_, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
         }
         if (!obj) return NMFX_OK;
         return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
@@ -1987,6 +1988,11 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         TRY(transpose_f32(st, HTd, n, K, Hcur));
         // the objective of (W, H) and the gradient dH the next sparse-H line search starts from come out of the same pass
         const bool lsH = !fixH && sH > 0;
+        // With BOTH line searches active every objective evaluation is made by the residual pass of the OTHER factor: the try that is
+        // accepted (4 of 5 are) has then already produced the gradient the next line search starts from, and a 4*mnK pass per search is gone.
+        static const bool no_spec = getenv("NMFX_SC_NO_SPEC") != nullptr;   // dev switch (A/B runs)
+        const bool spec = lsH && !fixW && sW > 0 && !no_spec;
+        bool have_dW = false;   // G2 (g64w) = dW of the current (Wd, Hcur), not yet summed over the shards
         bool have_dH = false;   // Denb = dH of the current (Wd, Hcur)
         if (lsH && p->maxiter >= 1) { TRY(resid_h(Wd, Hcur, &r->cost[0])); have_dH = true; }
         else TRY(fast_obj(Wd, Hcur, &r->cost[0]));                                              // nmfsc.m:138-139
@@ -2007,12 +2013,13 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(step_project_H(HTd, smallk ? nullptr : G1.as<float>(), smallk ? g64.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
+                        TRY(step_project_H(HTd, smallk ? nullptr : G1.as<float>(), smallk ? g64h.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
                         {
                             PScope ps(pf, SC_SMALL);
                             TRY(transpose_f32(st, HnewT, n, K, Hcand));
                         }
-                        TRY(fast_obj(Wd, Hcand, &newobj));                                          // nmfsc.m:160-161
+                        if (spec) TRY(resid_w(Wd, Hcand, G2.as<float>(), &newobj, false));          // nmfsc.m:160-161 (+ dW at the candidate)
+                        else TRY(fast_obj(Wd, Hcand, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
                         stepH /= 2;                                                                 // nmfsc.m:169
                         if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
@@ -2023,6 +2030,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     stepH *= 1.2;                                                                   // nmfsc.m:178
                     std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
                     cur_obj = newobj;
+                    have_dW = spec;
                 } else {
                     TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
                     TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
@@ -2037,7 +2045,13 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             }
             if (!fixW) {
                 if (sW > 0) {
-                    TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
+                    if (!have_dW) TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
+                    else if (comm.active()) {
+                        if (smallk) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+                        else TRY(comm.allreduce(G2.p, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));
+                    }
+                    have_dW = false;
+                    const bool spec_h = spec && it < p->maxiter;
                     const double begobj = cur_obj;
                     int tries = 0;
                     double newobj = 0;
@@ -2045,9 +2059,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                         ++tries;
                         {
                             PScope ps(pf, SC_PROJ);
-                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, smallk ? nullptr : G2.as<float>(), -stepW, Wd, smallk ? g64.as<double>() : nullptr));   // nmfsc.m:205-208
+                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, smallk ? nullptr : G2.as<float>(), -stepW, Wd, smallk ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
                         }
-                        TRY(fast_obj(Wnew, Hcur, &newobj));                                         // nmfsc.m:211-212
+                        if (spec_h) TRY(resid_h(Wnew, Hcur, &newobj));                              // nmfsc.m:211-212 (+ dH at the candidate)
+                        else TRY(fast_obj(Wnew, Hcur, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
                         stepW /= 2;
                         if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
@@ -2058,6 +2073,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     stepW *= 1.2;                                                                   // nmfsc.m:228
                     std::swap(Wd, Wnew);                                                            // nmfsc.m:229
                     cur_obj = newobj;
+                    have_dH = spec_h;
                 } else {
                     TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                    // V*H', V_hat*H'       nmfsc.m:194-195
                     PScope ps(pf, SC_SMALL);
