@@ -440,9 +440,7 @@ static nmfx_status projfunc_cols_t(hipStream_t st, TIO *X, long len, int count, 
     if (len <= 8192L) return launch_pf<1024, 8, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 16384L) return launch_pf<1024, 16, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 24576L) return launch_pf<512, 48, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
-    static const int pf_variant = getenv("NMFX_PF_VARIANT") ? atoi(getenv("NMFX_PF_VARIANT")) : 0;   // dev switch (A/B runs)
-    if (len <= 32768L && pf_variant == 1) return launch_pf<512, 48, 16, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
-    if (len <= 32768L && pf_variant == 2) return launch_pf<1024, 32, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
+    // (measured at 128 x 32768: <512, 64, 0> 0.0795 ms, <512, 48 + 16 in LDS> 0.0897, <1024, 32, 0> 0.0892)
     if (len <= 32768L) return launch_pf<512, 64, 0, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     if (len <= 40960L) return launch_pf<512, 48, 32, TIO>(st, X, len, count, k1, k2, nn, usediters_dev, dir, mu, src, dir64);
     // longer than registers + LDS hold: global fp64 working rows (allocated per call; this is the rare path)
