@@ -368,7 +368,17 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->fused = eligible && d->path != 1;
     if (!e->fused) e->dual = false;
     static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
-    e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt;
+    // the transposed copy of V (euclidean paths) is a luxury: only where the device clearly has the room for it next to V
+    // itself (V may or may not be allocated yet at this point: 2.5 x its size + 1 GiB must be free either way)
+    bool room_vt = true;
+    {
+        size_t free_b = 0, total_b = 0;
+        DeviceGuard dg_;
+        if (hipSetDevice(d->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            room_vt = (double)free_b >= 2.5 * 4.0 * (double)e->m * (double)e->n + (double)(1ull << 30);
+        (void)hipGetLastError();
+    }
+    e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt && room_vt;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
@@ -389,7 +399,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;
         static const int vtq_env = getenv("NMFX_VTQ_BLOCK") ? atoi(getenv("NMFX_VTQ_BLOCK")) : 0;   // dev switch: 128 | 256
         e->vtq_block = vtq_env ? vtq_env : 128;   // C4 (K*T = 512): four 128-wide blocks, two workgroups per CU, 0.526 ms; two 256-wide blocks 0.549; the two-operand GEMM 0.585
-        e->use_vtq = e->fusedT && e->qgemm && e->hL == 0 && e->hR == 0 && !no_vt && e->KT % e->vtq_block == 0 && fused_supported(e->vtq_block);
+        e->use_vtq = e->fusedT && e->qgemm && e->hL == 0 && e->hR == 0 && !no_vt && room_vt && e->KT % e->vtq_block == 0 && fused_supported(e->vtq_block);
     }
     e->nsplit_w = e->isplit_h = 1;
     if (e->fused) {
@@ -691,6 +701,15 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     nmfx_status s = fill_from_desc(e, d);
     if (s != NMFX_OK) { delete e; return s; }
     e->V = V; e->W = W; e->Hext = H; e->H = H + (size_t)e->K * e->hL; e->packed = packed;
+    // the transposed copy of V is optional: it is used when the workspace the caller brought has the room for it (nmfx_engine_workspace_bytes
+    // asks for it when the device looked roomy at that moment; a caller that allocated less simply gets the path without it)
+    if ((e->use_vt || e->use_vtq) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = false;
+    else if (!e->use_vt && !e->use_vtq) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
+        nmfx_engine probe = *e;
+        probe.use_vt = probe.fused && probe.div == NMFX_DIV_EUCLIDEAN && getenv("NMFX_NO_VT") == nullptr;
+        probe.use_vtq = probe.fusedT && probe.qgemm && probe.hL == 0 && probe.hR == 0 && getenv("NMFX_NO_VT") == nullptr && probe.KT % probe.vtq_block == 0 && fused_supported(probe.vtq_block);
+        if ((probe.use_vt || probe.use_vtq) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; }
+    }
     Layout L = layout(e, workspace);
     if (L.total > workspace_bytes) {
         set_error("nmfx_engine_create: workspace too small (%zu < %zu)", workspace_bytes, L.total);
