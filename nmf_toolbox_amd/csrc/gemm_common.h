@@ -69,6 +69,16 @@ __device__ __forceinline__ double div_term(int div, float v, float s, float al, 
     }
 }
 
+// the same terms in fp32, for the pipelined kernel's epilogue: 16 of them are summed in fp32 (one accumulator block of a thread) before the
+// sum is promoted -- per-element conversions and fp64 adds made the KL cost epilogue cost two thirds of the product it follows
+__device__ __forceinline__ float div_term_f32(int div, float v, float s) {
+    switch (div) {
+    case NMFX_DIV_KL: { const float q = v * __builtin_amdgcn_rcpf(s); return fmaf(v, 0.6931471805599453f * __builtin_amdgcn_logf(q), s - v); }
+    case NMFX_DIV_IS: { const float q = v * __builtin_amdgcn_rcpf(s); return fmaf(-0.6931471805599453f, __builtin_amdgcn_logf(q), q) - 1.0f; }
+    default: { const float d = v - s; return d * d; }
+    }
+}
+
 inline bool is_kc(int mode) { return mode == VIEW_KC || mode == VIEW_HSTACK_KC || mode == VIEW_WSTACK_KC || mode == VIEW_XSHIFT_KC; }
 // launch gemm_pipe_kernel<BM,BN,...> for (bm, bn) in {(128,128), (64,128), (128,64)}
 nmfx_status dispatch_pipe_whole(hipStream_t st, const GemmParams &p, int bm, int bn);            // gemm_pipe.hip

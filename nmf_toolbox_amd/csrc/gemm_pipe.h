@@ -318,13 +318,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
 #pragma unroll
         for (int b = 0; b < MR; ++b) {
             const long i = i_tile0 + wi0 + 32 * b + l31;
+            float pf = 0.0f;   // this block's 16 cost terms
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long j = j_tile0 + wj0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (EDGE) { if (i >= p.M || j >= p.N) continue; }       // edge tiles
                 float sv = acc[a][b][e];
                 if (p.epi == EPI_COST) {
-                    if (p.cost_ncols == 0 || j < p.cost_ncols) part += div_term<false>(p.cost_div, p.Vref[i + p.ldv * j], sv, p.cost_alpha, p.cost_beta);
+                    if (p.cost_ncols == 0 || j < p.cost_ncols) pf += div_term_f32(p.cost_div, p.Vref[i + p.ldv * j], sv);
                     if (p.store_c) C[i + p.ldc * j] = sv;
                 } else {
                     if (p.accumulate) sv += C[i + p.ldc * j];
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
                     C[i + p.ldc * j] = sv;
                 }
             }
+            part += (double)pf;
         }
     if (p.epi == EPI_COST) {
 #pragma unroll
