@@ -2232,7 +2232,11 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
-    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, stage, part, costd, scratch, rrs;
+    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, stage, part, costd, scratch, rrs, g64, s64;
+    // sparse-W gradients in fp64 where that is cheap (aux.hip::resid_xht64): m*n*K fp64 FMAs per slice
+    const bool small64 = p->sc_W_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
+    const int nch64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((p->m + 255) / 256) * p->K_total)), (p->n + 63) / 64) : 1;
+    if (small64) { TRY(g64.alloc(sizeof(double) * (size_t)p->m * p->K_total)); TRY(s64.alloc(sizeof(double) * (size_t)nch64 * p->m * p->K_total)); }
     TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
     TRY(HnT.alloc((size_t)p->K_total * p->n * 4));
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
@@ -2337,12 +2341,13 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
             for (int t = 0; t < T && !early; ++t) {
                 float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
                 if (sW > 0) {
-                    TRY(xht(V.as<float>(), H, t, G2.as<float>(), Vh.as<float>()));               // dW = pos - neg = (V_hat - V) * Hs'   cnmfsc.m:221-224
+                    if (small64) TRY(resid_xht64(st, V.as<float>(), Vh.as<float>(), m, n, H, K, t, s64.as<double>(), nch64, g64.as<double>()));   // dW in fp64 (small problems)
+                    else TRY(xht(V.as<float>(), H, t, G2.as<float>(), Vh.as<float>()));          // dW = pos - neg = (V_hat - V) * Hs'   cnmfsc.m:221-224
                     int tries = 0;
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, G2.as<float>(), -stepW[t], W0t));   // cnmfsc.m:229-233 (step formed in fp64 while loading)
+                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, small64 ? nullptr : G2.as<float>(), -stepW[t], W0t, small64 ? g64.as<double>() : nullptr));   // cnmfsc.m:229-233 (step formed in fp64 while loading)
                         GemmParams g; memset(&g, 0, sizeof(g));                                      // RFD(Wnew, H) with a 2-D Wnew: plain Wnew*H  (cnmfsc.m:235)
                         g.M = m; g.N = n; g.Kc = K;
                         g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};

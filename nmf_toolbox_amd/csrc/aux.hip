@@ -954,6 +954,31 @@ nmfx_status smallk_grad(hipStream_t st, int Kv, const float *V, long m, long n, 
     return smallk_launch<8>(st, Kv, V, m, n, W, H, ldh, dHT, dW, slabs, partials, nparts);
 }
 
+// cnmfsc, sparse-W branch on small problems: dW_t = (V_hat - V) * rshift_t(H)' (cnmfsc.m:221-224) accumulated in fp64, one thread per
+// output element and column chunk.  The columns of W are short there and the Hoyer projection amplifies the fp32 accumulation noise of
+// an MFMA contraction over n (W off by 1.3e-5 on 71 x 218 and 388 x 156 problems in scripts/fuzz_campaign_sc.py); the work is m*n*K
+// fp64 FMAs, so this is for small problems only (the caller decides).
+__global__ __launch_bounds__(256) void resid_xht64_kernel(const float *V, const float *Vh, long m, long n, const float *H, int K, int t, long cpc, double *slabs) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= m) return;
+    long c0 = (long)blockIdx.z * cpc, c1 = c0 + cpc < n ? c0 + cpc : n;
+    if (c0 < t) c0 = t;                                   // rshift_t(H)(:, j) = H(:, j - t), zero for j < t
+    double acc = 0.0;
+    for (long j = c0; j < c1; ++j) acc = fma((double)Vh[i + m * j] - (double)V[i + m * j], (double)H[k + (long)K * (j - t)], acc);
+    slabs[(long)blockIdx.z * m * K + i + m * k] = acc;
+}
+nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out) {
+    const long cpc = (n + nch - 1) / nch;
+    hipLaunchKernelGGL(resid_xht64_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)K, (unsigned)nch), dim3(256), 0, st, V, Vh, m, n, H, K, t, cpc, nch == 1 ? out : slabs);
+    NMFX_HIP(hipGetLastError());
+    if (nch > 1) {
+        hipLaunchKernelGGL(sum_slabs_f64_kernel, dim3((unsigned)((m * K + 255) / 256)), dim3(256), 0, st, slabs, nch, m * K, out);
+        NMFX_HIP(hipGetLastError());
+    }
+    return NMFX_OK;
+}
+
 // packed buffer helpers for the multi-GPU exchange: doubles <-> floats
 __global__ void d2f_kernel(const double *in, float *out, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

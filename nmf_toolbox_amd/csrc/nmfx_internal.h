@@ -194,6 +194,8 @@ nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, i
 nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 // nmfsc with K <= smallk_max(): residual-form gradients and objective in fp64 (aux.hip)
+// out (m x K doubles) = (Vh - V) * rshift_t(H)' in fp64; slabs: nch * m * K doubles (nch column chunks)
+nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out);
 int smallk_max();
 int smallk_dw_chunks(long m, long n);
 int smallk_partials(long m, long n);   // upper bound of *nparts

@@ -493,6 +493,24 @@ def test_nmfsc_small_K_float64_gradients(gpu_lib, m, n, K, sW, sH, iters, fixed)
     _check(got, ref, tol=3e-6)
 
 
+@pytest.mark.parametrize("m,n,K,T,iters", [(71, 218, 32, 4, 5), (145, 390, 32, 2, 7), (388, 156, 20, 4, 4), (200, 300, 16, 3, 6)])
+@pytest.mark.parametrize("h_fixed", [True, False])
+def test_cnmfsc_sparse_W_float64_gradients(gpu_lib, m, n, K, T, iters, h_fixed):
+    """cnmfsc's sparse-W line search on short columns: the Hoyer projection amplifies the accumulation noise of an fp32 MFMA contraction over n
+    (W off by 1.3e-5 / 1.6e-5 on the first three problems in scripts/fuzz_campaign_sc.py), so small problems take dW from a float64 VALU
+    kernel (aux.hip::resid_xht64) and step along a float64 direction.  Held to a tighter bar than the contract."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(W_init=W0, H_init=H0, tolerance=1e-300, maxiter=iters, W_sparsity=0.6)
+    if h_fixed:
+        cfg["H_fixed"] = True
+    i0, i1 = {}, {}
+    ref = O.cnmfsc(V, K, T, cfg, info=i0)
+    got = gpu_lib.cnmfsc(V, K, T, cfg, info=i1)
+    assert i1["triesW"] == i0["triesW"] and i1["triesH"] == i0["triesH"]
+    _check(got, ref, tol=3e-6)
+
+
 def test_nmf_random_shapes_fuzz(gpu_lib):
     """40 seeded random (m, n, K, divergence, sparsity, fixed) problems between 64 and 400 rows / columns: whichever kernels the
     engine picks (masked-edge fused with padded K, or the pipelined GEMM path when forced) must match the oracle."""
