@@ -279,6 +279,9 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     bm = 128; bn = 128;
     if (M % 128 != 0 && M % 64 == 0 && M <= 192) bm = 64;
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
+    // few output tiles (W*(H*H'): 64 of them at C2): half-height tiles double the workgroups of a launch that cannot fill the chip anyway
+    static const bool no_half = getenv("NMFX_GEMM_NO_HALF_TILES") != nullptr;   // dev switch (A/B runs)
+    if (!no_half && bm == 128 && bn == 128 && M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) < 256 && M >= 256) bm = 64;
 }
 
 // pipelined kernel: no powf maps.  vec = float4 loads: 16-byte aligned views
