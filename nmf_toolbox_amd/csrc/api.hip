@@ -2237,6 +2237,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     const bool small64 = p->sc_W_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
     const int nch64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((p->m + 255) / 256) * p->K_total)), (p->n + 63) / 64) : 1;
     if (small64) { TRY(g64.alloc(sizeof(double) * (size_t)p->m * p->K_total)); TRY(s64.alloc(sizeof(double) * (size_t)nch64 * p->m * p->K_total)); }
+    DevBuf g64h;   // the same for the sparse-H gradient (aux.hip::resid_hgrad64): m*n*K*T fp64 FMAs
+    const bool small64h = p->sc_H_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total * (double)p->T <= (double)(1 << 27);
+    if (small64h) TRY(g64h.alloc(sizeof(double) * (size_t)p->n * p->K_total));
     TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
     TRY(HnT.alloc((size_t)p->K_total * p->n * 4));
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
@@ -2304,14 +2307,17 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     for (int it = 1; it <= p->maxiter && !early; ++it) {
         if (!fixH) {
             if (sH > 0) {
-                TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));                  // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
                 const double begobj = r->cost[it - 1];
                 int tries = 0;
                 TRY(transpose_f32(st, H, K, n, HT));                                                 // rows of H / dH contiguous: the projected vectors
-                TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
+                if (small64h) TRY(resid_hgrad64(st, V.as<float>(), Vh.as<float>(), m, n, W0, K, T, g64h.as<double>()));   // dH' in fp64 (small problems)
+                else {
+                    TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));              // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
+                    TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
+                }
                 for (;;) {
                     ++tries;
-                    TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, G1.as<float>(), -stepH, HT));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
+                    TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, small64h ? nullptr : G1.as<float>(), -stepH, HT, small64h ? g64h.as<double>() : nullptr));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
                     TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
                     double newobj;
                     TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181

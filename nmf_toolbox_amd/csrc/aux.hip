@@ -979,6 +979,28 @@ nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m,
     return NMFX_OK;
 }
 
+// ... and the sparse-H branch: dH'(j, k) = sum_t sum_i W_t(i, k) * (V_hat - V)(i, j + t), j + t < n (cnmfsc.m:160-168), in fp64: one wave per
+// output element, lanes along i (the columns of V_hat / V and of W_t are contiguous there); out is n x K (the layout projfunc reads)
+__global__ __launch_bounds__(256) void resid_hgrad64_kernel(const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT) {
+    const int lane = threadIdx.x & 63;
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // o = j + n * k
+    if (o >= n * K) return;
+    const long j = o % n;
+    const int k = (int)(o / n);
+    double acc = 0.0;
+    for (int t = 0; t < T && j + t < n; ++t) {
+        const float *v = V + m * (j + t), *vh = Vh + m * (j + t), *w = W + m * ((long)k + (long)K * t);
+        for (long i = lane; i < m; i += 64) acc = fma((double)w[i], (double)vh[i] - (double)v[i], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) outT[o] = acc;
+}
+nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT) {
+    hipLaunchKernelGGL(resid_hgrad64_kernel, dim3((unsigned)((n * K + 3) / 4)), dim3(256), 0, st, V, Vh, m, n, W, K, T, outT);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // packed buffer helpers for the multi-GPU exchange: doubles <-> floats
 __global__ void d2f_kernel(const double *in, float *out, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -196,6 +196,8 @@ nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 // nmfsc with K <= smallk_max(): residual-form gradients and objective in fp64 (aux.hip)
 // out (m x K doubles) = (Vh - V) * rshift_t(H)' in fp64; slabs: nch * m * K doubles (nch column chunks)
 nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out);
+// outT (n x K doubles) = (sum_t W_t' * lshift_t(Vh - V))' in fp64
+nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT);
 int smallk_max();
 int smallk_dw_chunks(long m, long n);
 int smallk_partials(long m, long n);   // upper bound of *nparts
