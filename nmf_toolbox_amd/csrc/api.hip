@@ -1867,22 +1867,31 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
     DevBuf WTb, slabs, Gb, Denb, KKb, fparts, g64h, g64w, s64;
     const bool smallk = fast && Kv <= smallk_max();   // a handful of components: gradients + objective in fp64 (aux.hip::smallk_grad), handed to projfunc as doubles
+    // ... and small problems with any K (m*n*K <= 2^27 fp64 FMAs per evaluation), unless the fused kernels are asked for by name (path 2):
+    // R64 = W*H - V as doubles, both contractions on it in fp64 (aux.hip::resid64 / r64_wt / r64_ht).  What this buys is parity -- the Hoyer
+    // projection amplifies the accumulation noise of an fp32 MFMA contraction 10-100x on short vectors
+    const bool small64 = fast && !smallk && p->path != 2 && (double)m * (double)n * (double)Kv <= (double)(1 << 27);
+    const bool use64 = smallk || small64;
+    const int nch_w64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((m + 255) / 256) * Kv)), (n + 63) / 64) : 1;
+    DevBuf r64b;
     int nsplit_w = 1, isplit_h = 1;
     long cps_w = n, cps_h = m;
     if (fast) {
         nsplit_w = fused_split((m + 127) / 128, n, K, &cps_w);
         isplit_h = fused_split((n + 127) / 128, m, K, &cps_h);
         TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
-        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * std::max<long>(std::max(((m + 127) / 128) * nsplit_w, ((n + 127) / 128) * isplit_h), smallk ? smallk_partials(m, n) : 0)));
-        if (smallk) { TRY(g64h.alloc(sizeof(double) * n * Kv)); TRY(g64w.alloc(sizeof(double) * m * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)smallk_dw_chunks(m, n) * m * Kv)); }
+        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * std::max<long>(std::max(((m + 127) / 128) * nsplit_w, ((n + 127) / 128) * isplit_h), smallk ? smallk_partials(m, n) : (small64 ? resid64_blocks(m, n) : 0))));
+        if (use64) { TRY(g64h.alloc(sizeof(double) * n * Kv)); TRY(g64w.alloc(sizeof(double) * m * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)(smallk ? smallk_dw_chunks(m, n) : nch_w64) * m * Kv)); }
+        if (small64) TRY(r64b.alloc(sizeof(double) * mn));
     }
     // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
     auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
-        if (smallk) {
+        if (use64) {
             int np_ = 0;
             {
                 PScope ps(pf, SC_OBJ);
-                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, nullptr, nullptr, fparts.as<double>(), &np_));
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, nullptr, nullptr, fparts.as<double>(), &np_));
+                else TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, nullptr, fparts.as<double>(), &np_));
             }
             return read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm);
         }
@@ -1902,11 +1911,15 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // on small K (scripts/fuzz_campaign_sc.py: H off by 1.3e-5 at K = 3).  The same pass yields 0.5*||V - W*H||^2 of the point it is taken at.
     // Den (K x n) = Wx' * (Wx*Hx - V); *obj = the objective at (Wx, Hx) when asked for
     auto resid_h = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
-        if (smallk) {   // g64h = dH' (n x Kv doubles)
+        if (use64) {   // g64h = dH' (n x Kv doubles)
             int np_ = 0;
             {
                 PScope ps(pf, SC_HTERMS);
-                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64h.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64h.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
+                else {
+                    TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, r64b.as<double>(), fparts.as<double>(), &np_));
+                    TRY(r64_wt(st, r64b.as<double>(), m, n, Wx, Kv, g64h.as<double>()));
+                }
             }
             return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
         }
@@ -1927,11 +1940,15 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // dW_ (m x K) = (Wx*Hx - V) * Hx', summed over the column shards; *obj as above
     // (reduce = false: the sum over the column shards is left to the caller -- a speculative evaluation inside the H line search, see below)
     auto resid_w = [&](const float *Wx, const float *Hx, float *dW_, double *obj, bool reduce = true) -> nmfx_status {
-        if (smallk) {   // g64w = dW (m x Kv doubles)
+        if (use64) {   // g64w = dW (m x Kv doubles)
             int np_ = 0;
             {
                 PScope ps(pf, SC_WTERMS);
-                TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64w.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64w.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
+                else {
+                    TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, r64b.as<double>(), fparts.as<double>(), &np_));
+                    TRY(r64_ht(st, r64b.as<double>(), m, n, Hx, Kv, K, s64.as<double>(), nch_w64, g64w.as<double>()));
+                }
                 if (comm.active() && reduce) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
             }
             return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
@@ -2023,7 +2040,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 if (sH > 0) {
                     if (!have_dH) TRY(resid_h(Wd, Hcur, nullptr));                              // dH = W'*V_hat - W'*V   nmfsc.m:144-148
                     have_dH = false;
-                    if (!smallk) {
+                    if (!use64) {
                         PScope ps(pf, SC_SMALL);
                         TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));         // dH' (n x K): rows of H are contiguous there
                     }
@@ -2032,7 +2049,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     double newobj = 0;
                     for (;;) {
                         ++tries;
-                        TRY(step_project_H(HTd, smallk ? nullptr : G1.as<float>(), smallk ? g64h.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
+                        TRY(step_project_H(HTd, use64 ? nullptr : G1.as<float>(), use64 ? g64h.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
                         {
                             PScope ps(pf, SC_SMALL);
                             TRY(transpose_f32(st, HnewT, n, K, Hcand));
@@ -2066,7 +2083,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                 if (sW > 0) {
                     if (!have_dW) TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
                     else if (comm.active()) {
-                        if (smallk) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+                        if (use64) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
                         else TRY(comm.allreduce(G2.p, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));
                     }
                     have_dW = false;
@@ -2078,7 +2095,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                         ++tries;
                         {
                             PScope ps(pf, SC_PROJ);
-                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, smallk ? nullptr : G2.as<float>(), -stepW, Wd, smallk ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
+                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, use64 ? nullptr : G2.as<float>(), -stepW, Wd, use64 ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
                         }
                         if (spec_h) TRY(resid_h(Wnew, Hcur, &newobj));                              // nmfsc.m:211-212 (+ dH at the candidate)
                         else TRY(fast_obj(Wnew, Hcur, &newobj));

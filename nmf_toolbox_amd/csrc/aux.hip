@@ -1001,6 +1001,70 @@ nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long 
     return NMFX_OK;
 }
 
+// nmfsc on small problems with K > 8 (no V_hat in HBM there): R64 = W*H - V as doubles (one thread per element, K fp64 FMAs each) with the
+// objective's sum of squares per workgroup; the two contractions above then run on it (Vh = nullptr: X IS the residual)
+__global__ __launch_bounds__(256) void resid64_kernel(const float *V, long m, long n, const float *W, const float *H, int K, int ldh, double *R64, double *partials) {
+    __shared__ double red[4];
+    const long total = m * n;
+    double cost = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e % m, j = e / m;
+        double sv = 0.0;
+        for (int k = 0; k < K; ++k) sv = fma((double)W[i + m * k], (double)H[k + (long)ldh * j], sv);
+        const double r = sv - (double)V[e];
+        if (R64) R64[e] = r;
+        cost = fma(r, r, cost);
+    }
+    cost = block_sum<4>(cost, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = cost;
+}
+int resid64_blocks(long m, long n) { return (int)std::min<long>((m * n + 255) / 256, 2048); }
+nmfx_status resid64(hipStream_t st, const float *V, long m, long n, const float *W, const float *H, int K, int ldh, double *R64, double *partials, int *nparts) {
+    const int blocks = resid64_blocks(m, n);
+    hipLaunchKernelGGL(resid64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, V, m, n, W, H, K, ldh, R64, partials);
+    NMFX_HIP(hipGetLastError());
+    *nparts = blocks;
+    return NMFX_OK;
+}
+// dH'(j, k) = sum_i W(i, k) * R64(i, j)   (n x K doubles): one wave per output element
+__global__ __launch_bounds__(256) void r64_wt_kernel(const double *R64, long m, long n, const float *W, int K, double *outT) {
+    const int lane = threadIdx.x & 63;
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n * K) return;
+    const long j = o % n;
+    const float *w = W + m * (o / n);
+    const double *r = R64 + m * j;
+    double acc = 0.0;
+    for (long i = lane; i < m; i += 64) acc = fma((double)w[i], r[i], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) outT[o] = acc;
+}
+// dW(i, k) = sum_j R64(i, j) * H(k, j)   (m x K doubles): one thread per output element and column chunk
+__global__ __launch_bounds__(256) void r64_ht_kernel(const double *R64, long m, long n, const float *H, int K, int ldh, long cpc, double *slabs) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= m) return;
+    const long c0 = (long)blockIdx.z * cpc, c1 = c0 + cpc < n ? c0 + cpc : n;
+    double acc = 0.0;
+    for (long j = c0; j < c1; ++j) acc = fma(R64[i + m * j], (double)H[k + (long)ldh * j], acc);
+    slabs[(long)blockIdx.z * m * K + i + m * k] = acc;
+}
+nmfx_status r64_wt(hipStream_t st, const double *R64, long m, long n, const float *W, int K, double *outT) {
+    hipLaunchKernelGGL(r64_wt_kernel, dim3((unsigned)((n * K + 3) / 4)), dim3(256), 0, st, R64, m, n, W, K, outT);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+nmfx_status r64_ht(hipStream_t st, const double *R64, long m, long n, const float *H, int K, int ldh, double *slabs, int nch, double *out) {
+    const long cpc = (n + nch - 1) / nch;
+    hipLaunchKernelGGL(r64_ht_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)K, (unsigned)nch), dim3(256), 0, st, R64, m, n, H, K, ldh, cpc, nch == 1 ? out : slabs);
+    NMFX_HIP(hipGetLastError());
+    if (nch > 1) {
+        hipLaunchKernelGGL(sum_slabs_f64_kernel, dim3((unsigned)((m * K + 255) / 256)), dim3(256), 0, st, slabs, nch, m * K, out);
+        NMFX_HIP(hipGetLastError());
+    }
+    return NMFX_OK;
+}
+
 // packed buffer helpers for the multi-GPU exchange: doubles <-> floats
 __global__ void d2f_kernel(const double *in, float *out, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

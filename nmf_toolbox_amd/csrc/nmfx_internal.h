@@ -198,6 +198,11 @@ nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out);
 // outT (n x K doubles) = (sum_t W_t' * lshift_t(Vh - V))' in fp64
 nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT);
+// nmfsc on small problems, any K: R64 = W*H - V (m x n doubles, or nullptr: objective only) + sum of squares per workgroup; then dH' = (W'*R64)' and dW = R64*H'
+int resid64_blocks(long m, long n);
+nmfx_status resid64(hipStream_t st, const float *V, long m, long n, const float *W, const float *H, int K, int ldh, double *R64, double *partials, int *nparts);
+nmfx_status r64_wt(hipStream_t st, const double *R64, long m, long n, const float *W, int K, double *outT);
+nmfx_status r64_ht(hipStream_t st, const double *R64, long m, long n, const float *H, int K, int ldh, double *slabs, int nch, double *out);
 int smallk_max();
 int smallk_dw_chunks(long m, long n);
 int smallk_partials(long m, long n);   // upper bound of *nparts

@@ -511,6 +511,26 @@ def test_cnmfsc_sparse_W_float64_gradients(gpu_lib, m, n, K, T, iters, h_fixed):
     _check(got, ref, tol=3e-6)
 
 
+@pytest.mark.parametrize("m,n,K,iters,sW,sH", [(256, 2048, 16, 30, 0.4, 0.6), (256, 1024, 64, 20, 0.4, 0.6), (500, 700, 128, 8, 0.3, 0.5),
+                                                (129, 200, 32, 12, 0.4, 0.6), (400, 300, 20, 8, 0.6, 0.0), (257, 333, 40, 8, 0.0, 0.7)])
+def test_nmfsc_small_problems_float64_gradients(gpu_lib, m, n, K, iters, sW, sH):
+    """nmfsc on problems of up to 2^27 multiply-adds per evaluation (default path): the residual W*H - V, both gradient contractions and
+    the objective in float64 on the VALU, the step along a float64 direction.  An order of magnitude inside the contract (the MFMA path on
+    the same problems, nmfx_path=2: 1e-6 ... 3e-6); the fused kernels stay covered by the path=2 tests and the BASELINE-size tests."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(W_init=W0, H_init=H0, tolerance=1e-300, maxiter=iters)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1 = {}, {}
+    ref = O.nmfsc(V, K, cfg, info=i0)
+    got = gpu_lib.nmfsc(V, K, cfg, info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    _check(got, ref, tol=1e-6, cost_tol=1e-8)
+
+
 def test_nmf_random_shapes_fuzz(gpu_lib):
     """40 seeded random (m, n, K, divergence, sparsity, fixed) problems between 64 and 400 rows / columns: whichever kernels the
     engine picks (masked-edge fused with padded K, or the pipelined GEMM path when forced) must match the oracle."""
