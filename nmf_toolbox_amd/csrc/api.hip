@@ -1870,7 +1870,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // ... and small problems with any K (m*n*K <= 2^27 fp64 FMAs per evaluation), unless the fused kernels are asked for by name (path 2):
     // R64 = W*H - V as doubles, both contractions on it in fp64 (aux.hip::resid64 / r64_wt / r64_ht).  What this buys is parity -- the Hoyer
     // projection amplifies the accumulation noise of an fp32 MFMA contraction 10-100x on short vectors
-    const bool small64 = fast && !smallk && p->path != 2 && (double)m * (double)n * (double)Kv <= (double)(1 << 27);
+    const bool small64 = fast && !smallk && p->path != 2 && (double)m * (double)n_total * (double)Kv <= (double)(1 << 27);   // n_total: every rank of a sharded run must take the same path (the all-reduced buffers differ)
     const bool use64 = smallk || small64;
     const int nch_w64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((m + 255) / 256) * Kv)), (n + 63) / 64) : 1;
     DevBuf r64b;

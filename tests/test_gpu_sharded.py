@@ -366,8 +366,8 @@ def _nmfsc_threads(V, W0, H0, world, **kw):
 
 
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
-@pytest.mark.parametrize("world", [2, 4])
-def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world):
+@pytest.mark.parametrize("world,path", [(2, 2), (4, 2), (2, 0)])   # path 2: the fused MFMA kernels by name; 0: what a problem this small gets by default (float64 gradients)
+def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world, path):
     from oracle import nmf_oracle as O
     m, n, K = 256, 1024, 64
     V, W0, H0 = synth(m, n, K)
@@ -379,7 +379,7 @@ def test_nmfsc_column_shards_equal_oracle(gpu_lib, sW, sH, world):
         cfg["H_sparsity"] = sH
     i0 = {}
     W, H, cost = O.nmfsc(V, K, cfg, info=i0)
-    res = _nmfsc_threads(V, W0, H0, world, W_sparsity=sW, H_sparsity=sH, maxiter=12, tolerance=1e-12)
+    res = _nmfsc_threads(V, W0, H0, world, W_sparsity=sW, H_sparsity=sH, maxiter=12, tolerance=1e-12, path=path)
     for r in res[1:]:
         assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[2], res[0][2])      # W and cost replicated bit-for-bit
     Hs = np.concatenate([r[1] for r in res], axis=1)
@@ -435,7 +435,7 @@ def test_nmfsc_ragged_column_shards_equal_oracle(gpu_lib):
     cfg = dict(W_init=W0, H_init=H0, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
     i0 = {}
     W, H, cost = O.nmfsc(V, 32, cfg, info=i0)
-    res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12)
+    res = _nmfsc_threads(V, W0, H0, 2, W_sparsity=0.3, H_sparsity=0.5, maxiter=8, tolerance=1e-12, path=2)
     Hs = np.concatenate([r[1] for r in res], axis=1)
     assert res[0][3]["triesH"] == i0["triesH"] and res[0][3]["triesW"] == i0["triesW"]
     assert rel_fro(res[0][0], W) <= 1e-5 and rel_fro(Hs, H) <= 1e-5 and rel_fro(res[0][2], cost) <= 1e-6, (rel_fro(res[0][0], W), rel_fro(Hs, H))
