@@ -12,6 +12,8 @@ import nmf_toolbox_amd as A
 from oracle import nmf_oracle as O
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
+import os
+FORCE_PATH = int(os.environ.get("NMFX_FUZZ_PATH", "0"))   # 2: nmfsc on the fused MFMA kernels by name (problems this small get the float64 VALU path by default)
 rs = np.random.RandomState(seed)
 t0 = time.time(); cnt = 0; worst = dict(W=0.0, H=0.0, cost=0.0); bad = 0; mism = 0
 while time.time() - t0 < budget:
@@ -34,7 +36,7 @@ while time.time() - t0 < budget:
     if conv:
         ref = O.cnmfsc(V, K, T, cfg, info=i0); got = A.cnmfsc(V, K, T, cfg, info=i1)
     else:
-        ref = O.nmfsc(V, K, cfg, info=i0); got = A.nmfsc(V, K, cfg, info=i1)
+        ref = O.nmfsc(V, K, cfg, info=i0); got = A.nmfsc(V, K, dict(cfg, nmfx_path=FORCE_PATH) if FORCE_PATH else cfg, info=i1)
     cnt += 1
     tag = ("cnmfsc" if conv else "nmfsc", m, n, K, T, sW, sH, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
     if i1.get("triesH") != i0.get("triesH") or i1.get("triesW") != i0.get("triesW") or len(got[2]) != len(ref[2]):
