@@ -74,7 +74,7 @@ nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long sla
     // Small outputs with many slabs (the K x K Gram products: 128 x 128 floats, up to 256 split-K slabs) gave the single-level kernel 16
     // workgroups to pull 16 MB through (31 us at C2).  Two levels: ~sqrt(nslab) groups summed in place by their own workgroups, then the
     // group heads.  The summation order is fixed by (nslab, count) alone: results stay run-to-run deterministic.  The slabs are scratch.
-    if (nslab >= 16 && count <= (1L << 18)) {
+    if (nslab >= 16 && count <= (1L << 18) && (long)nslab * count >= (1L << 20)) {   // (below 4 MB of slabs the second launch costs more than it saves)
         int g = 4;
         while (g * g < nslab) g *= 2;
         const int ngroups = (nslab + g - 1) / g;

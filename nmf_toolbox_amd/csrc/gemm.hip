@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <algorithm>
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace nmfx {
@@ -348,12 +350,59 @@ int gemm_pick_split(long M, long N, long Kc) {
     return split < 1 ? 1 : split;
 }
 
+// slabs of the VALU kernel for tiny products (tiny_gemm_kernel below): a small output over a long contraction needs the contraction split
+// finely to put a few hundred waves on the chip
+static bool tiny_size(long M, long N, long Kc) { return M > 0 && N > 0 && Kc > 0 && 2.0 * (double)M * (double)N * (double)Kc <= (double)(1 << 25); }
+static long tiny_split(long M, long N, long Kc, long *per) {
+    long S = 1;
+    *per = Kc;
+    if (Kc >= 256 && M * N <= 65536) {
+        *per = std::max<long>(32, (Kc + 63) / 64);
+        S = (Kc + *per - 1) / *per;
+    }
+    return S;
+}
 size_t gemm_scratch_bytes(long M, long N, long Kc) {
-    const int split = gemm_pick_split(M, N, Kc);
+    long split = gemm_pick_split(M, N, Kc), per = 0;
+    if (tiny_size(M, N, Kc)) split = std::max(split, tiny_split(M, N, Kc, &per));
     return split > 1 ? sizeof(float) * (size_t)M * (size_t)N * split : 0;
 }
 
+// Products too small for a 128 x 128 MFMA tile and its software pipeline to be worth starting (a 32 x 32 Gram over 513 rows took 30 us, the four
+// K x K products of a 513 x 2000, K = 32 euclidean iteration 80 of its 137 us): one thread per output element on the VALU, fp64 accumulation,
+// the contraction split over blockIdx.y into slabs when the output alone cannot fill the chip
+__global__ __launch_bounds__(256) void tiny_gemm_kernel(const float *A, long lda, int a_kc, const float *B, long ldb, int b_kc, long M, long N, long Kc, long per,
+                                                        float *C, long ldc, long slab_stride) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= M * N) return;
+    const long r = o % M, c = o / M;
+    const long k0 = (long)blockIdx.y * per, k1 = k0 + per < Kc ? k0 + per : Kc;
+    const float *a = a_kc ? A + lda * r : A + r;
+    const float *b = b_kc ? B + ldb * c : B + c;
+    const long sa = a_kc ? 1 : lda, sb = b_kc ? 1 : ldb;
+    double acc = 0.0;
+    for (long k = k0; k < k1; ++k) acc = fma((double)a[k * sa], (double)b[k * sb], acc);
+    C[(long)blockIdx.y * slab_stride + r + ldc * c] = (float)acc;
+}
+static bool tiny_plain(const OpView &v) { return (v.mode == VIEW_RC || v.mode == VIEW_KC) && v.func == NMFX_PRO_NONE && !v.p2; }
+
 nmfx_status gemm_auto(hipStream_t st, GemmParams p, void *scratch, size_t scratch_bytes) {
+    static const bool no_tiny = getenv("NMFX_GEMM_NO_TINY") != nullptr;   // dev switch (A/B runs)
+    if (!no_tiny && p.epi == EPI_STORE && !p.accumulate && !p.clamp0 && p.zbatch == 0 && p.M > 0 && p.N > 0 && p.Kc > 0 && tiny_plain(p.A) && tiny_plain(p.B) &&
+        tiny_size(p.M, p.N, p.Kc)) {
+        long per = p.Kc, S = (p.ldc == p.M && scratch) ? tiny_split(p.M, p.N, p.Kc, &per) : 1;
+        if (S > 1) {
+            const long cap = (long)(scratch_bytes / (sizeof(float) * (size_t)p.M * p.N));   // slabs the scratch holds
+            if (cap < S) { per = cap >= 2 ? (p.Kc + cap - 1) / cap : p.Kc; S = cap >= 2 ? (p.Kc + per - 1) / per : 1; }
+        }
+        if (S <= 1) { S = 1; per = p.Kc; }
+        float *dst = S > 1 ? static_cast<float *>(scratch) : p.C;
+        hipLaunchKernelGGL(tiny_gemm_kernel, dim3((unsigned)((p.M * p.N + 255) / 256), (unsigned)S), dim3(256), 0, st, p.A.p, p.A.ld, is_kc(p.A.mode) ? 1 : 0,
+                           p.B.p, p.B.ld, is_kc(p.B.mode) ? 1 : 0, p.M, p.N, p.Kc, per, dst, S > 1 ? p.M : p.ldc, p.M * p.N);
+        NMFX_HIP(hipGetLastError());
+        if (S > 1) return reduce_slabs(st, dst, (int)S, p.M * p.N, p.M * p.N, p.C, 0);
+        return NMFX_OK;
+    }
     const long ktiles = (p.Kc + BK - 1) / BK;
     int split = 1;
     if (p.epi == EPI_STORE && scratch) {
