@@ -500,9 +500,9 @@ def nmfsc(V, num_basis_elems, config=None, rng=None, info=None):
     triesH, triesW = [], []
     n_cost = maxiter + 1
 
-    def _finish(ncost):
+    def _finish(ncost, early=False):
         if info is not None:
-            info.update(triesH=triesH, triesW=triesW, stepsizeH=stepsizeH, stepsizeW=stepsizeW)
+            info.update(triesH=triesH, triesW=triesW, stepsizeH=stepsizeH, stepsizeW=stepsizeW, converged_early=early)
         return W, H, cost[:ncost]
 
     for it in range(1, maxiter + 1):                      # nmfsc.m:141
@@ -525,7 +525,7 @@ def nmfsc(V, num_basis_elems, config=None, rng=None, info=None):
                     stepsizeH = stepsizeH / 2             # nmfsc.m:169
                     if stepsizeH < 1e-200:                # nmfsc.m:170-174
                         triesH.append(tries)
-                        return _finish(it)
+                        return _finish(it, True)
                 triesH.append(tries)
                 stepsizeH = 1.2 * stepsizeH               # nmfsc.m:178
                 H = Hnew                                  # nmfsc.m:179
@@ -554,7 +554,7 @@ def nmfsc(V, num_basis_elems, config=None, rng=None, info=None):
                     stepsizeW = stepsizeW / 2             # nmfsc.m:220
                     if stepsizeW < 1e-200:                # nmfsc.m:221-225
                         triesW.append(tries)
-                        return _finish(it)
+                        return _finish(it, True)
                 triesW.append(tries)
                 stepsizeW = 1.2 * stepsizeW               # nmfsc.m:228
                 W = Wnew                                  # nmfsc.m:229
@@ -625,9 +625,9 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
     cost[0] = 0.5 * np.sum((V - V_hat) ** 2)
     triesH, triesW = [], []
 
-    def _finish(ncost):
+    def _finish(ncost, early=False):
         if info is not None:
-            info.update(triesH=triesH, triesW=triesW, stepsizeH=stepsizeH, stepsizeW=stepsizeW.copy())
+            info.update(triesH=triesH, triesW=triesW, stepsizeH=stepsizeH, stepsizeW=stepsizeW.copy(), converged_early=early)
         Wout = W[:, :, 0] if T == 1 else W
         return Wout, H, cost[:ncost]
 
@@ -655,7 +655,7 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
                     stepsizeH = stepsizeH / 2
                     if stepsizeH < 1e-200:                # cnmfsc.m:190-194
                         triesH.append(tries)
-                        return _finish(it)
+                        return _finish(it, True)
                 triesH.append(tries)
                 stepsizeH = 1.2 * stepsizeH               # cnmfsc.m:198
                 H = Hnew
@@ -688,7 +688,7 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, rng=None, info=None):
                         stepsizeW[t - 1] = stepsizeW[t - 1] / 2
                         if stepsizeW[t - 1] < 1e-200:     # cnmfsc.m:245-249
                             triesW.append(tries)
-                            return _finish(it)
+                            return _finish(it, True)
                     triesW.append(tries)
                     stepsizeW[t - 1] = 1.2 * stepsizeW[t - 1]             # cnmfsc.m:252
                     W[:, :, t - 1] = Wnew

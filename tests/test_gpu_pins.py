@@ -36,3 +36,42 @@ def test_hip_cnmf_fixed_points(gpu_lib):
 
 def test_hip_projfunc_closed_forms(gpu_lib):
     pins.pin_projfunc(gpu_lib, 1e-12)       # float64 in, float64 arithmetic, float64 out
+
+
+# ---- nmfsc / cnmfsc / lnmf / constrainednmf (tests/pins_sc.py): hand-derived cases, exact rationals, 50-digit decimals with the closed
+# form of the Hoyer projection -- none of it from oracle/ ---------------------------------------------------------------------------
+import pins_sc
+
+
+def test_hip_nmfsc_underflow_return(gpu_lib):
+    pins_sc.pin_nmfsc_underflow(gpu_lib, TOL, CTOL)                               # 665 rejected tries, cost trimmed to cost(1:1)
+
+
+def test_hip_nmfsc_mu_branches(gpu_lib):
+    pins_sc.pin_nmfsc_mu(gpu_lib, TOL, CTOL)
+
+
+def test_hip_nmfsc_line_searches(gpu_lib):
+    pins_sc.pin_nmfsc_linesearch(gpu_lib, TOL, CTOL)                              # tries [2], step 0.6, both searches over two iterations
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_hip_nmfsc_pins_on_named_kernel_paths(gpu_lib, path):
+    """path 1: materialised V_hat on the general GEMM; path 2: the fused MFMA kernels (K padded to 32, masked edges) -- the default for
+    problems this small is the float64 VALU path, which the three tests above cover"""
+    cfg = dict(nmfx_path=path)
+    pins_sc.pin_nmfsc_mu(gpu_lib, TOL, CTOL, extra_cfg=cfg)
+    pins_sc.pin_nmfsc_linesearch(gpu_lib, TOL, CTOL, extra_cfg=cfg)
+    pins_sc.pin_nmfsc_underflow(gpu_lib, TOL, CTOL, extra_cfg=cfg)
+
+
+def test_hip_cnmfsc_pins(gpu_lib):
+    pins_sc.pin_cnmfsc(gpu_lib, TOL, CTOL)                                        # pos + eps, shift-less line search, early return, MU branches
+
+
+def test_hip_lnmf_pins(gpu_lib):
+    pins_sc.pin_lnmf(gpu_lib, TOL, CTOL)                                          # incl. `<=` stop at equal costs, untrimmed cost vector
+
+
+def test_hip_constrainednmf_pins(gpu_lib):
+    pins_sc.pin_constrainednmf(gpu_lib, TOL, CTOL)
