@@ -1,0 +1,182 @@
+// Shared by the translation units behind the C ABI (engine.hip, host_io.hip, blocking.hip, sc.hip): device guard, workspace carver,
+// hipEvent profiler, the engine object, host <-> device staging.
+#pragma once
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nmfx_internal.h"
+
+namespace nmfx {
+
+nmfx_status check_device(int device);
+
+// every entry point leaves the caller's current HIP device as it found it (torch and MATLAB hosts keep their own idea of "current")
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *b) : base(static_cast<char *>(b)), off(0) {}
+    template <class T> T *take(size_t count) {
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += al256(sizeof(T) * count);
+        return p;
+    }
+};
+
+// grid.y of a fused pass over `blocks` 128-row blocks (engine.hip)
+int fused_split(long blocks, long extent, int K, long *c_per_split);
+
+}  // namespace nmfx
+
+#define TRY(x) do { nmfx_status s_ = (x); if (s_ != NMFX_OK) return s_; } while (0)
+
+struct ProfEvent {
+    int tag;
+    hipEvent_t a, b;
+};
+// hipEvent pairs around launch groups, on the stream the kernels run on (bench.py's per-kernel durations)
+struct Profiler {
+    bool on = false;
+    int skip_tag = -1;         // coarse mode: launch groups with this tag (the small kernels) are not bracketed -- an event pair costs ~5 us of
+                               // stream time, 14 pairs per iteration are 4 % of a 2.2 ms iteration on an 8-GPU shard
+    hipStream_t st = nullptr;
+    std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    void enable(bool e) { on = e; events.clear(); pool_used = 0; }
+    void release() { for (hipEvent_t ev : pool) (void)hipEventDestroy(ev); pool.clear(); events.clear(); pool_used = 0; }
+    nmfx_status read(int ntags, double *ms_per_tag, int32_t *count_per_tag) const {
+        for (int t = 0; t < ntags; ++t) { ms_per_tag[t] = 0.0; count_per_tag[t] = 0; }
+        for (const ProfEvent &pe : events) {
+            float ms = 0.f;
+            NMFX_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+            if (pe.tag >= 0 && pe.tag < ntags) { ms_per_tag[pe.tag] += ms; count_per_tag[pe.tag] += 1; }
+        }
+        return NMFX_OK;
+    }
+};
+struct PScope {
+    Profiler *p;
+    int idx;
+    PScope(Profiler *p_, int tag) : p(p_), idx(-1) {
+        if (!p || !p->on || tag == p->skip_tag) return;
+        auto get = [&]() {
+            if (p->pool_used == p->pool.size()) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) return (hipEvent_t) nullptr;
+                p->pool.push_back(ev);
+            }
+            return p->pool[p->pool_used++];
+        };
+        ProfEvent pe{tag, get(), get()};
+        if (!pe.a || !pe.b) return;
+        (void)hipEventRecord(pe.a, p->st);
+        p->events.push_back(pe);
+        idx = (int)p->events.size() - 1;
+    }
+    ~PScope() {
+        if (idx >= 0) (void)hipEventRecord(p->events[idx].b, p->st);
+    }
+};
+
+struct nmfx_engine {
+    long m, n;                // n = local columns owned by this shard
+    int hL, hR;               // halo columns of H on each side; V / V_hat carry hR extra columns on the right
+    long nvalid;              // columns of V that exist globally (<= n + hR)
+    float *Hext;              // base of the K x (hL + n + hR) buffer; H points at its centre
+    int K, T, KT, div, algo;
+    int K_valid;              // components k >= K_valid are zero padding (0 = none)
+    double alpha, beta;       // NMFX_DIV_AB only; alpha == 0 selects the dual update equations (nmf.m:124-128)
+    int device;
+    hipStream_t st;
+    const float *V;
+    float *W, *H, *packed;
+    int rank0;
+    bool any_lamW, any_lamH;
+    // workspace
+    float *Vhat, *Gn, *Gp, *gemm_scratch;
+    size_t gemm_scratch_bytes;
+    float *lamW, *lamH;
+    uint8_t *fixW, *fixH;
+    bool all_fixW, all_fixH;
+    double *sumsq, *f_out, *rowsum, *colsum, *Pvec, *Gpvec, *cost_partials, *cost, *l1W, *l1H;
+    void *rr_scratch;
+    int n_cost_partials, n_cost_used;
+    // fused path (fused.hip): V_hat is never materialised
+    bool fused, cost_valid, defer_hfinish;
+    bool cost_dst2_done;      // set by the finisher that honoured cost_dst2
+    double *cost_dst2;        // fused paths: the finisher of the next lagged cost also writes it here (the caller's cost vector), or nullptr
+    bool tail_with_cost;      // fused KL: the finisher also converts rowsum(H) into the fp32 tail of `packed` (W-step partial passes only)
+    bool dual;                // fused IS / alpha-beta: packed = [N | P], both contractions of a pass come out of one kernel (func 4 / 5)
+    float *slabs2, *Valpha;   // dual: slabs of the second contraction; alpha-beta with alpha ~= 1: V.^alpha (the kernels' data operand)
+    double *sumVab;           // dual: the constant of the cost (IS: 0; alpha-beta: sum(V.^(alpha+beta)), nmf.m:214)
+    bool gram;                // cnmf euclidean in Gram form: V_hat*Hs' = W_flat*(Hs*Hs'), sum_t W_t'*lshift(V_hat) from W_flat'*W_flat (no V_hat in HBM)
+    float *CC;                // KT x KT Gram of the stacked W (gram path)
+    // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
+    // H-step numerator as ONE (KT x n x m) GEMM Q = W_flat' * V followed by the shift-sum over t
+    bool fusedT, hpad_valid;
+    bool fusedT_kl;           // KL cnmf on the fused passes: an S pass stores R = V./V_hat (in the V_hat buffer) and yields the cost of the state it
+                              // started from (lagged, like the nmf fused path); the numerator passes then read R instead of V
+    double *sumV_g, *colV_g;  // its closed-form cost term sum(V)
+    bool qgemm;               // cnmf, T > 1: H-step numerator sum_t W_t' * lshift_t(A) as ONE (KT x n x m) GEMM Q = W_flat' * A + a shift-sum over t
+    float *Hpad, *Qbuf, *slabsT;
+    int nsplit_T;
+    long cps_T;
+    // unsharded fused cnmf: the two Gram products that involve the stacked shifted H by LAG (aux.hip: gram_from_lags, lag_sum, gp_tail) --
+    // T lag Grams instead of the T x T blocks of Hs*Hs', 2T-1 lag sums of W_flat'*W_flat instead of T^2 blocks in the H-step denominator
+    bool lagram;
+    float *Llag, *Elag;
+    int nsplit_w, isplit_h;
+    long cps_w, cps_h;        // streamed extent per split (multiples of 64; the last split may be shorter)
+    int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
+    int chunk_parts;          // cost partials written by the chunks so far
+    float *WT, *slabs, *Pbuf, *GW;
+    float *VT;                // euclidean fused path: V' (n x m), built once at init -- the H-step numerator W'*V runs as (V'*W)' on the W-step-form kernel
+    bool use_vt;
+    float *WTf;               // cnmf on the fused passes, euclidean: W_flat' (row i = its K*T floats), rebuilt before each Q product
+    bool use_vtq;             // ... whose Q = W_flat'*V runs as (V'*W_flat)' on the W-step-form kernel, K-wide column blocks in grid.z
+    int vtq_block;
+    double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
+    // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
+    float *Z;
+    long nz;
+    long *seg_dev;            // owned (hipMalloc) -- the only allocation the engine makes itself
+    Profiler prof;
+};
+
+namespace nmfx {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    nmfx_status alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); p = nullptr; return NMFX_ERR_NOMEM; }
+        return NMFX_OK;
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+inline size_t dsize(int dtype) { return dtype == NMFX_F64 ? 8 : 4; }
+
+constexpr size_t STAGE_ELEMS = (size_t)8 << 20;  // 64 MiB of doubles
+
+// host (f32/f64) -> device fp32 (out = in / divide_by) and back, converted on the device through a staging buffer (host_io.hip)
+nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by, DevBuf &stage, size_t stage_elems);
+nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count, DevBuf &stage, size_t stage_elems);
+nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true);
+
+}  // namespace nmfx

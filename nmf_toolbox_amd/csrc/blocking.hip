@@ -1,0 +1,427 @@
+// Blocking host-buffer entry points of the C ABI (what the MEX gateway binds): nmf / cnmf / lnmf / constrainednmf on one GPU or
+// column-sharded over the GPUs of this process, ReconstructFromDecomposition, SortDictionary, projfunc.
+#include "api_common.h"
+
+using namespace nmfx;
+
+namespace {
+
+nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const int64_t *seg = nullptr, int64_t nz = 0, const void *Z_init = nullptr,
+                   void *Z_out = nullptr) {
+    TRY(validate_problem(p, r, false, algorithm != 3));
+    if (algorithm != 1 && p->T != 1) { set_error("nmf / lnmf / constrainednmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm == 3) {
+        if (!seg || !Z_init || !Z_out || nz <= 0) { set_error("constrainednmf: segments, Z_init and Z_out are required"); return NMFX_ERR_INVALID; }
+        if (p->num_sources != 1) { set_error("constrainednmf: single source only (constrainednmf.m has no multi-source form)"); return NMFX_ERR_INVALID; }
+        if (p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("constrainednmf: unknown divergence (constrainednmf.m:204-205)"); return NMFX_ERR_INVALID; }
+    }
+    if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(check_device(p->device));
+    const int Kt = p->K_total, S = p->num_sources;
+    // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
+    // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
+    const int dv = p->divergence;
+    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;   // fused IS / alpha-beta: K <= 128
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 &&
+                     (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
+    const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
+    std::vector<float> lw(K, 0.f), lh(K, 0.f);
+    std::vector<uint8_t> fw(K, 0), fh(K, 0);
+    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
+    for (int s = 0, k0 = 0; s < S; ++s) {
+        const int Ks = p->K_s ? p->K_s[s] : Kt;
+        for (int k = k0; k < k0 + Ks; ++k) {
+            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
+            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
+            if (p->W_fixed) fw[k] = p->W_fixed[s];
+            if (p->H_fixed) fh[k] = p->H_fixed[s];
+        }
+        k0 += Ks;
+    }
+    nmfx_engine_desc d{};
+    d.m = p->m; d.n_local = p->n; d.K_total = K; d.T = p->T; d.divergence = p->divergence; d.alpha = p->alpha; d.beta = p->beta;
+    d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
+    d.device = p->device; d.stream = nullptr; d.algorithm = algorithm; d.path = p->path;
+    d.K_valid = pad ? Kt : 0;
+    size_t ws_bytes = 0, packed_count = 0;
+    TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
+    TRY(nmfx_engine_packed_count(&d, &packed_count));
+    const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
+    DevBuf V, W, H, Z, ws, packed, stage;
+    TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(ws.alloc(ws_bytes)); TRY(packed.alloc(packed_count * 4));
+    TRY(stage.alloc(STAGE_ELEMS * 8));
+    hipStream_t st = nullptr;
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0, stage, STAGE_ELEMS));
+    const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
+    DevBuf tmp;   // K x cols staging of the un-padded row-interleaved arrays (H, Z)
+    if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
+    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0, stage, STAGE_ELEMS));   // the first K columns of the m x K_pad array
+    if (pad) NMFX_HIP(hipMemsetAsync(W.as<float>() + mKt, 0, (mKT - mKt) * 4, st));
+    if (algorithm != 3) {
+        if (pad) {
+            TRY(upload(st, p->H_init, p->dtype, tmp.as<float>(), Ktn, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, tmp.as<float>(), Kt, H.as<float>(), K, p->n));
+        } else TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    } else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
+        TRY(Z.alloc((size_t)K * nz * 4));
+        if (pad) {
+            TRY(upload(st, Z_init, p->dtype, tmp.as<float>(), (size_t)Kt * nz, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, tmp.as<float>(), Kt, Z.as<float>(), K, nz));
+        } else TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0, stage, STAGE_ELEMS));
+    }
+    nmfx_engine *e = nullptr;
+    TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
+    nmfx_status s = algorithm == 3 ? nmfx_engine_set_constraint(e, seg, nz, Z.as<float>()) : NMFX_OK;
+    if (s == NMFX_OK) s = nmfx_engine_init(e);
+    int it = 0;
+    r->iters_run = 0;
+    auto read_cost = [&](int idx) -> nmfx_status {
+        hipError_t he = hipMemcpy(&r->cost[idx], e->cost, sizeof(double), hipMemcpyDeviceToHost);   // syncs the iteration
+        if (he != hipSuccess) { set_error("cost readback: %s", hipGetErrorString(he)); return NMFX_ERR_HIP; }
+        r->iters_run = idx + 1;
+        return NMFX_OK;
+    };
+    // nmf.m:221-224 / cnmf.m:254-257
+    auto stop = [&](int idx) {
+        if (p->tolerance < 0 || idx == 0) return false;
+        if (algorithm == 2) return r->cost[idx] <= r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] <= p->tolerance;   // lnmf.m:84
+        return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;
+    };
+    bool stopped = false;
+    const bool lag = e && (e->fused || e->fusedT_kl);
+    for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
+        if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
+        if (lag && it > 0) {
+            // the fused W-step pass of iteration it also yields cost(it-1); W and H are untouched until wstep_finish, so
+            // stopping here returns exactly the state of iteration it-1 (the numerators just computed are discarded)
+            if ((s = read_cost(it - 1)) != NMFX_OK) break;
+            if (stop(it - 1)) { stopped = true; break; }
+        }
+        if ((s = nmfx_engine_wstep_finish(e)) != NMFX_OK) break;
+        if ((s = nmfx_engine_hstep(e)) != NMFX_OK) break;
+        if (!lag) {
+            if ((s = read_cost(it)) != NMFX_OK) break;
+            if (stop(it)) { stopped = true; break; }
+        }
+    }
+    if (s == NMFX_OK && lag && !stopped) {
+        s = nmfx_engine_cost_pass(e);
+        if (s == NMFX_OK) s = read_cost(p->maxiter - 1);
+    }
+    r->cost_len = r->iters_run;
+    if (algorithm == 2) {   // lnmf.m:84-86 breaks WITHOUT trimming: the cost vector keeps its maxiter length, zero after the stop
+        for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
+        r->cost_len = p->maxiter;
+    }
+    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS);
+    if (s == NMFX_OK && pad) {
+        s = repack_rows(st, H.as<float>(), K, tmp.as<float>(), Kt, p->n);
+        if (s == NMFX_OK) s = download(st, tmp.as<float>(), p->dtype, r->H, Ktn, stage, STAGE_ELEMS);
+        if (s == NMFX_OK && algorithm == 3) s = repack_rows(st, Z.as<float>(), K, tmp.as<float>(), Kt, nz);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, tmp.as<float>(), p->dtype, Z_out, (size_t)Kt * nz, stage, STAGE_ELEMS);
+    } else {
+        if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz, stage, STAGE_ELEMS);
+    }
+    nmfx_engine_destroy(e);
+    return s;
+}
+
+// ---- nmfx_problem.n_gpus > 1: one process, one host thread, one stream + engine per device (what a MEX caller of nmf() needs) -------
+// V and H are column-sharded over the devices, W is replicated.  Per iteration ONE exchange of the packed W-step sums
+// (SURVEY 8(e)), done here without a collective library: every device reduces its own 1/N slice of `packed` straight out of its
+// peers' HBM over xGMI (all links in parallel, fixed summation order), then copies the other N-1 reduced slices from their owners.
+// Each slice has exactly one owner, so all replicas of W stay bit-identical.  device_ids may name one device several times
+// (N shards on one GPU): that is how the 1-GPU test box exercises this path.
+struct MultiDev {
+    int ndev = 0;
+    int dev[NMFX_MAX_GPUS];
+    hipStream_t st[NMFX_MAX_GPUS] = {};
+    hipEvent_t evP[NMFX_MAX_GPUS] = {}, evR[NMFX_MAX_GPUS] = {}, evG[NMFX_MAX_GPUS] = {};
+    nmfx_engine *eng[NMFX_MAX_GPUS] = {};
+    DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
+    long lo[NMFX_MAX_GPUS + 1];
+    ~MultiDev() {
+        for (int g = 0; g < ndev; ++g) {
+            (void)hipSetDevice(dev[g]);
+            if (eng[g]) nmfx_engine_destroy(eng[g]);
+            if (evP[g]) (void)hipEventDestroy(evP[g]);
+            if (evR[g]) (void)hipEventDestroy(evR[g]);
+            if (evG[g]) (void)hipEventDestroy(evG[g]);
+            if (st[g]) (void)hipStreamDestroy(st[g]);
+        }
+    }
+};
+
+nmfx_status multi_allreduce(MultiDev &M, size_t count) {
+    const int N = M.ndev;
+    PeerPtrs ptrs{};
+    for (int g = 0; g < N; ++g) ptrs.p[g] = M.packed[g].as<float>();
+    const long per = (long)(((count + N - 1) / N + 3) & ~(size_t)3);   // slice length, a multiple of 4 floats
+    auto slice = [&](int g, long *off, long *cnt) { *off = std::min((long)count, per * g); *cnt = std::min((long)count, per * (g + 1)) - *off; };
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipEventRecord(M.evP[g], M.st[g])); }
+    for (int g = 0; g < N; ++g) {   // reduce-scatter: device g owns slice g
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) if (h != g) NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evP[h], 0));
+        long off, cnt;
+        slice(g, &off, &cnt);
+        TRY(peer_reduce(M.st[g], ptrs, N, g, off, cnt));
+        NMFX_HIP(hipEventRecord(M.evR[g], M.st[g]));
+    }
+    for (int g = 0; g < N; ++g) {   // all-gather: fetch the slices the others reduced
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) {
+            if (h == g) continue;
+            long off, cnt;
+            slice(h, &off, &cnt);
+            NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evR[h], 0));
+            if (cnt > 0) NMFX_HIP(hipMemcpyPeerAsync(ptrs.p[g] + off, M.dev[g], ptrs.p[h] + off, M.dev[h], (size_t)cnt * 4, M.st[g]));
+        }
+        NMFX_HIP(hipEventRecord(M.evG[g], M.st[g]));
+    }
+    for (int g = 0; g < N; ++g) {   // nobody refills its `packed` (next W-step partial) before every peer has copied out of it
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        for (int h = 0; h < N; ++h) if (h != g) NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evG[h], 0));
+    }
+    return NMFX_OK;
+}
+
+nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
+    TRY(validate_problem(p, r, false, true));
+    if (algorithm != 0 && algorithm != 2) { set_error("n_gpus > 1 is implemented for nmf and lnmf (cnmf / nmfsc shard through the device-level API)"); return NMFX_ERR_UNSUPPORTED; }
+    if (p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
+    const int N = p->n_gpus;
+    if (N > NMFX_MAX_GPUS || N > p->n) { set_error("n_gpus = %d: at most %d devices and one column per device", N, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    MultiDev M;
+    for (int g = 0; g < N; ++g) {
+        M.dev[g] = p->device_ids ? p->device_ids[g] : g;
+        TRY(check_device(M.dev[g]));
+    }
+    for (int g = 0; g < N; ++g)      // peer mappings: the reduce kernel reads the other devices' `packed` in place
+        for (int h = 0; h < N; ++h) {
+            if (M.dev[g] == M.dev[h]) continue;
+            int can = 0;
+            NMFX_HIP(hipDeviceCanAccessPeer(&can, M.dev[g], M.dev[h]));
+            if (!can) { set_error("device %d cannot access device %d as a peer", M.dev[g], M.dev[h]); return NMFX_ERR_UNSUPPORTED; }
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            hipError_t pe = hipDeviceEnablePeerAccess(M.dev[h], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { set_error("hipDeviceEnablePeerAccess(%d -> %d): %s", M.dev[g], M.dev[h], hipGetErrorString(pe)); return NMFX_ERR_HIP; }
+            (void)hipGetLastError();
+        }
+    const int Kt = p->K_total, S = p->num_sources, dv = p->divergence;
+    const long m = p->m, n = p->n;
+    M.lo[0] = 0;
+    for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
+    long nmin = n;
+    for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
+    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;
+    const bool pad = Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
+    const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
+    std::vector<float> lw(K, 0.f), lh(K, 0.f);
+    std::vector<uint8_t> fw(K, 0), fh(K, 0);
+    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
+    for (int s = 0, k0 = 0; s < S; ++s) {
+        const int Ks = p->K_s ? p->K_s[s] : Kt;
+        for (int k = k0; k < k0 + Ks; ++k) {
+            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
+            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
+            if (p->W_fixed) fw[k] = p->W_fixed[s];
+            if (p->H_fixed) fh[k] = p->H_fixed[s];
+        }
+        k0 += Ks;
+    }
+    const size_t mK = (size_t)m * K, mKt = (size_t)m * Kt;
+    size_t packed_count = 0;
+    int kind = -1;
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        M.ndev = g + 1;
+        NMFX_HIP(hipStreamCreateWithFlags(&M.st[g], hipStreamNonBlocking));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evP[g], hipEventDisableTiming));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evR[g], hipEventDisableTiming));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evG[g], hipEventDisableTiming));
+        const long nl = M.lo[g + 1] - M.lo[g];
+        nmfx_engine_desc d{};
+        d.m = m; d.n_local = nl; d.K_total = K; d.T = 1; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
+        d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
+        d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = p->path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
+        size_t wsb = 0, pc = 0;
+        TRY(nmfx_engine_workspace_bytes(&d, &wsb));
+        TRY(nmfx_engine_packed_count(&d, &pc));
+        if (g == 0) packed_count = pc;
+        else if (pc != packed_count) { set_error("n_gpus: shards disagree on the packed layout"); return NMFX_ERR_INVALID; }
+        DevBuf stage, tmp;
+        TRY(M.V[g].alloc((size_t)m * nl * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nl * 4)); TRY(M.ws[g].alloc(wsb));
+        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64)); TRY(stage.alloc(STAGE_ELEMS * 8));
+        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
+        const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
+        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * nl, 1.0, stage, STAGE_ELEMS));
+        TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0, stage, STAGE_ELEMS));
+        if (pad) {
+            NMFX_HIP(hipMemsetAsync(M.W[g].as<float>() + mKt, 0, (mK - mKt) * 4, M.st[g]));
+            TRY(tmp.alloc((size_t)Kt * nl * 4));
+            TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(M.st[g], tmp.as<float>(), Kt, M.H[g].as<float>(), K, nl));
+            NMFX_HIP(hipStreamSynchronize(M.st[g]));
+        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nl, 1.0, stage, STAGE_ELEMS));
+        TRY(nmfx_engine_create(&d, M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb, M.packed[g].as<float>(), &M.eng[g]));
+        TRY(nmfx_engine_set_rank0(M.eng[g], g == 0));
+        const int kd = nmfx_engine_is_fused(M.eng[g]);
+        if (kind < 0) kind = kd;
+        else if (kd != kind) { set_error("n_gpus: shards picked different kernel paths; pass path = 1"); return NMFX_ERR_UNSUPPORTED; }
+        TRY(nmfx_engine_init(M.eng[g]));
+    }
+    const bool lag = kind == 1;
+    std::vector<double> hc(N);
+    auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
+        for (int g = 0; g < N; ++g) {
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            NMFX_HIP(hipMemcpyAsync(&hc[g], M.eng[g]->cost, sizeof(double), hipMemcpyDeviceToHost, M.st[g]));
+        }
+        double c = 0.0;
+        for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); c += hc[g]; }
+        r->cost[idx] = c;
+        r->iters_run = idx + 1;
+        return NMFX_OK;
+    };
+    auto stop = [&](int idx) {
+        if (p->tolerance < 0 || idx == 0) return false;
+        if (algorithm == 2) return r->cost[idx] <= r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] <= p->tolerance;   // lnmf.m:84
+        return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;                         // nmf.m:221
+    };
+    r->iters_run = 0;
+    bool stopped = false;
+    for (int it = 0; it < p->maxiter; ++it) {
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_wstep_partial(M.eng[g]));
+        if (lag && it > 0) {
+            TRY(read_cost(it - 1));
+            if (stop(it - 1)) { stopped = true; break; }
+        }
+        TRY(multi_allreduce(M, packed_count));
+        for (int g = 0; g < N; ++g) { TRY(nmfx_engine_wstep_finish(M.eng[g])); TRY(nmfx_engine_hstep(M.eng[g])); }
+        if (!lag) {
+            TRY(read_cost(it));
+            if (stop(it)) { stopped = true; break; }
+        }
+    }
+    if (lag && !stopped) {
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_cost_pass(M.eng[g]));
+        TRY(read_cost(p->maxiter - 1));
+    }
+    r->cost_len = r->iters_run;
+    if (algorithm == 2) {
+        for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
+        r->cost_len = p->maxiter;
+    }
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        const long nl = M.lo[g + 1] - M.lo[g];
+        DevBuf stage, tmp;
+        TRY(stage.alloc(STAGE_ELEMS * 8));
+        if (g == 0) TRY(download(M.st[g], M.W[g].as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS));
+        char *Hh = static_cast<char *>(r->H) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
+        if (pad) {
+            TRY(tmp.alloc((size_t)Kt * nl * 4));
+            TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, tmp.as<float>(), Kt, nl));
+            TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl, stage, STAGE_ELEMS));
+        } else TRY(download(M.st[g], M.H[g].as<float>(), p->dtype, Hh, (size_t)K * nl, stage, STAGE_ELEMS));
+    }
+    return NMFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 0) : run_mu(p, r, 0); }
+nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 1) : run_mu(p, r, 1); }
+nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 2) : run_mu(p, r, 2); }
+nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, int64_t nz, const void *Z_init, nmfx_result *r, void *Z_out) {
+    return run_mu(p, r, 3, segments, nz, Z_init, Z_out);
+}
+
+nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W, const void *H, void *V_hat,
+                             int32_t device) {
+    if (m <= 0 || n <= 0 || K <= 0 || T <= 0 || !W || !H || !V_hat) { set_error("nmfx_reconstruct: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(check_device(device));
+    const size_t mn = (size_t)m * n, mKT = (size_t)m * K * T, Kn = (size_t)K * n;
+    DevBuf Wd, Hd, Vd, stage;
+    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    hipStream_t st = nullptr;
+    TRY(upload(st, W, dtype, Wd.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, H, dtype, Hd.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = m; g.N = n; g.Kc = (long)K * T;
+    g.A = OpView{Wd.as<float>(), nullptr, (long)m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    if (T == 1) g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    g.C = Vd.as<float>(); g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
+    TRY(launch_gemm(st, g));
+    return download(st, Vd.as<float>(), dtype, V_hat, mn, stage, STAGE_ELEMS);
+}
+
+// [W_sorted, H_sorted] = SortDictionary(W, H): basis columns by increasing centre of mass (SortDictionary.m:33-47), computed in the
+// buffers' own dtype; H / H_sorted may be NULL (nargin < 2).  order_out[K] receives the 0-based permutation (`sorted` - 1).
+nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype, const void *W, const void *H, void *W_sorted, void *H_sorted,
+                                 int32_t *order_out, int32_t device) {
+    if (m <= 0 || K <= 0 || !W || !W_sorted || (H && (!H_sorted || n <= 0))) { set_error("nmfx_sort_dictionary: bad arguments"); return NMFX_ERR_INVALID; }
+    if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(check_device(device));
+    const size_t es = dsize(dtype), wb = (size_t)m * K * es, hb = H ? (size_t)K * n * es : 0;
+    DevBuf Wd, Ws, Hd, Hs, cog, ord;
+    TRY(Wd.alloc(wb)); TRY(Ws.alloc(wb)); TRY(cog.alloc(sizeof(int) * K)); TRY(ord.alloc(sizeof(int) * K));
+    hipStream_t st = nullptr;
+    NMFX_HIP(hipMemcpyAsync(Wd.p, W, wb, hipMemcpyHostToDevice, st));
+    TRY(center_of_gravity(st, Wd.p, dtype == NMFX_F64, m, K, cog.as<int>()));
+    std::vector<int> cg(K), order(K);
+    NMFX_HIP(hipMemcpyAsync(cg.data(), cog.p, sizeof(int) * K, hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < K; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cg[a] < cg[b]; });   // MATLAB sort is stable (SortDictionary.m:43)
+    NMFX_HIP(hipMemcpyAsync(ord.p, order.data(), sizeof(int) * K, hipMemcpyHostToDevice, st));
+    TRY(permute(st, Wd.p, Ws.p, dtype == NMFX_F64, m, K, ord.as<int>(), 0));
+    NMFX_HIP(hipMemcpyAsync(W_sorted, Ws.p, wb, hipMemcpyDeviceToHost, st));
+    if (H) {
+        TRY(Hd.alloc(hb)); TRY(Hs.alloc(hb));
+        NMFX_HIP(hipMemcpyAsync(Hd.p, H, hb, hipMemcpyHostToDevice, st));
+        TRY(permute(st, Hd.p, Hs.p, dtype == NMFX_F64, K, n, ord.as<int>(), 1));
+        NMFX_HIP(hipMemcpyAsync(H_sorted, Hs.p, hb, hipMemcpyDeviceToHost, st));
+    }
+    NMFX_HIP(hipStreamSynchronize(st));
+    if (order_out) for (int k = 0; k < K; ++k) order_out[k] = order[k];
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
+                              const float *dir_dev, double mu, int32_t *usediters_dev) {
+    if (N <= 0 || count <= 0 || !X_dev) { set_error("nmfx_projfunc_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    return projfunc_cols(static_cast<hipStream_t>(stream), X_dev, N, count, k1, k2, nn, usediters_dev, dir_dev, mu, src_dev);
+}
+
+nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,
+                          int32_t *usediters, int32_t device) {
+    if (N <= 0 || count <= 0 || !s || !v) { set_error("nmfx_projfunc: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(check_device(device));
+    if (dtype != NMFX_F32 && dtype != NMFX_F64) { set_error("nmfx_projfunc: dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
+    const size_t tot = (size_t)N * count;
+    DevBuf X, it;
+    TRY(X.alloc(tot * dsize(dtype))); TRY(it.alloc(sizeof(int) * count));
+    hipStream_t st = nullptr;
+    // the vectors stay in the caller's precision: float64 input is projected in float64 end to end (projfunc.m computes in double)
+    NMFX_HIP(hipMemcpyAsync(X.p, s, tot * dsize(dtype), hipMemcpyHostToDevice, st));
+    if (dtype == NMFX_F64) TRY(projfunc_cols_f64(st, X.as<double>(), N, count, k1, k2, nn, it.as<int>()));
+    else TRY(projfunc_cols(st, X.as<float>(), N, count, k1, k2, nn, it.as<int>()));
+    if (usediters) NMFX_HIP(hipMemcpyAsync(usediters, it.p, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipMemcpyAsync(v, X.p, tot * dsize(dtype), hipMemcpyDeviceToHost, st));
+    NMFX_HIP(hipStreamSynchronize(st));
+    return NMFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1146 @@
+// The device-resident engine behind the C ABI (include/nmfx.h): error plumbing and the phases of one multiplicative-update iteration
+// (nmf.m:143-225, cnmf.m:175-258, lnmf.m:66-88, constrainednmf.m:183-258).  Kernels live in gemm.hip / fused*.hip / aux.hip.
+#include "api_common.h"
+
+namespace nmfx {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+nmfx_status check_device(int device) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        set_error("nmfx: no usable HIP device (hipGetDeviceCount: %s). There is no CPU fallback.", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return NMFX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= cnt) {
+        set_error("nmfx: device %d out of range (have %d)", device, cnt);
+        return NMFX_ERR_INVALID;
+    }
+    NMFX_HIP(hipSetDevice(device));
+    return NMFX_OK;
+}
+
+}  // namespace nmfx
+
+using namespace nmfx;
+
+enum ProfTag { TAG_RECON = 0, TAG_WNUM = 1, TAG_WDEN = 2, TAG_HNUM = 3, TAG_HDEN = 4, TAG_RECON_COST = 5, TAG_SMALL = 6,
+               TAG_FUSED_W = 7, TAG_FUSED_H = 8, TAG_FUSED_COST = 9, TAG_GRAM = 10, TAG_COUNT = 11 };
+static const char *const kTagNames[TAG_COUNT] = {"gemm:V_hat=W*H", "gemm:N=A*H'", "gemm:P=B*H'", "H-step numerator Gn=W'*A (two-operand GEMM, or the stationary kernel over V')", "gemm:Gp=W'*B",
+                                                 "gemm:V_hat=W*H+cost", "small kernels", "fused:W-step (S=W*H -> R -> R*H')",
+                                                 "fused:H-step (S=W*H -> R -> W'*R + update)", "fused:cost pass (S=W*H -> D(V||S))",
+                                                 "gemm:Gram/K x K products"};
+
+namespace {
+
+struct Scope : PScope {
+    Scope(nmfx_engine *e, int tag) : PScope(&e->prof, tag) {}
+};
+
+struct Layout {
+    size_t total;
+    size_t packed_count;
+};
+
+bool div_has_matrix_den(int div) { return div != NMFX_DIV_KL; }
+
+// carve (or just size, when ws == nullptr) the workspace
+Layout layout(nmfx_engine *e, void *ws) {
+    Carver c(ws);
+    const size_t mn = (size_t)e->m * (e->n + e->hR), Kn = (size_t)e->K * e->n, mKT = (size_t)e->m * e->KT;
+    e->Vhat = c.take<float>(mn);
+    e->Gn = c.take<float>(Kn);
+    e->Gp = div_has_matrix_den(e->div) ? c.take<float>(Kn) : nullptr;
+    size_t gs = gemm_scratch_bytes(e->m, e->KT, e->n);
+    size_t gs2 = gemm_scratch_bytes(e->K, e->n, (long)e->T * e->m);
+    size_t gs3 = gemm_scratch_bytes(e->m, e->n + e->hR, e->KT);
+    size_t gs4 = e->qgemm ? gemm_scratch_bytes(e->KT, e->n + e->hR, e->m) : 0;
+    if (gs2 > gs) gs = gs2;
+    if (gs3 > gs) gs = gs3;
+    if (gs4 > gs) gs = gs4;
+    e->gemm_scratch_bytes = gs;
+    e->gemm_scratch = gs ? c.take<float>(gs / sizeof(float)) : nullptr;
+    e->lamW = c.take<float>(e->K);
+    e->lamH = c.take<float>(e->K);
+    e->fixW = c.take<uint8_t>(e->K);
+    e->fixH = c.take<uint8_t>(e->K);
+    e->sumsq = c.take<double>(e->KT);
+    e->f_out = c.take<double>(e->K);
+    e->rowsum = c.take<double>(e->K);
+    e->colsum = c.take<double>(e->KT);
+    e->Pvec = c.take<double>(e->KT);
+    e->Gpvec = c.take<double>(e->K);
+    e->l1W = c.take<double>(e->KT);
+    e->l1H = c.take<double>(e->K);
+    e->cost = c.take<double>(4);
+    e->n_cost_partials = (int)gemm_grid_blocks(e->m, e->n + e->hR);
+    e->cost_partials = c.take<double>(e->n_cost_partials);
+    e->rr_scratch = c.take<char>(row_reduce_scratch_bytes(e->K));
+    Layout L;
+    if (e->fused) {
+        // V_hat, Gn/Gp of the generic path are not needed: rewind and carve the fused buffers instead
+        Carver f(ws);
+        e->Vhat = nullptr;
+        e->WT = f.take<float>(mKT);
+        // row-chunked W steps use more splits on fewer rows: rows*split per launch never exceeds max(nsplit_w, 2) * m / 2
+        e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
+        e->slabs2 = e->dual ? f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn)) : nullptr;
+        e->Valpha = (e->dual && e->div == NMFX_DIV_AB && e->alpha != 1.0) ? f.take<float>((size_t)e->m * e->n) : nullptr;
+        e->VT = e->use_vt ? f.take<float>((size_t)e->m * e->n) : nullptr;
+        e->Gn = f.take<float>(Kn);
+        const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
+        e->Gp = (euc || e->dual) ? f.take<float>(Kn) : nullptr;
+        e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
+        e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
+        size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
+        e->gemm_scratch_bytes = euc ? std::max(std::max(g1, g2), g3) : 0;
+        e->gemm_scratch = e->gemm_scratch_bytes ? f.take<float>(e->gemm_scratch_bytes / sizeof(float)) : nullptr;
+        e->lamW = f.take<float>(e->K); e->lamH = f.take<float>(e->K);
+        e->fixW = f.take<uint8_t>(e->K); e->fixH = f.take<uint8_t>(e->K);
+        e->sumsq = f.take<double>(e->KT); e->f_out = f.take<double>(e->K); e->rowsum = f.take<double>(e->K);
+        e->colsum = f.take<double>(e->KT); e->Pvec = f.take<double>(e->KT); e->Gpvec = f.take<double>(e->K);
+        e->l1W = f.take<double>(e->KT); e->l1H = f.take<double>(e->K); e->cost = f.take<double>(4);
+        e->n_cost_partials = (int)((e->m + 127) / 128) + 8 * 1024;   // any decomposition of the W-step pass into <= 8 row chunks (blocks*split < 1024 each, or = blocks)
+        e->cost_partials = f.take<double>(e->n_cost_partials);
+        e->rr_scratch = f.take<char>(row_reduce_scratch_bytes(e->K));
+        e->sumV = f.take<double>(1);
+        e->sumVab = f.take<double>(1);
+        e->colV = f.take<double>(e->n);
+        L.total = f.off;
+        L.packed_count = e->dual ? 2 * mKT : (euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT);
+        return L;
+    }
+    if (e->gram) {
+        e->Pbuf = c.take<float>(mKT);
+        e->CC = c.take<float>((size_t)e->KT * e->KT);
+        size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
+        size_t gg = std::max(std::max(g4, g5), sizeof(float) * Kn * e->T);   // + T slabs of the z-batched H-step denominator
+        if (e->lagram) gg = std::max(gg, std::max(gemm_scratch_bytes(e->K, e->KT, e->n), gemm_scratch_bytes(e->K, e->n, (long)(2 * e->T - 1) * e->K)));
+        if (gg > e->gemm_scratch_bytes) { e->gemm_scratch_bytes = gg; e->gemm_scratch = c.take<float>(gg / sizeof(float)); }
+        if (e->fusedT) {
+            e->Hpad = c.take<float>((size_t)e->K * (e->n + (e->lagram ? 2 : 1) * (e->T - 1)));
+            if (e->lagram) {
+                e->Llag = c.take<float>((size_t)e->K * e->KT);
+                e->Elag = c.take<float>((size_t)e->K * (2 * e->T - 1) * e->K);
+            }
+            e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
+            const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+            if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        }
+    }
+    if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
+    if (e->use_vtq) { e->VT = c.take<float>((size_t)e->m * e->n); e->WTf = c.take<float>(mKT); }
+    if (e->fusedT_kl) {
+        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
+        const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        e->sumV_g = c.take<double>(1);
+        e->colV_g = c.take<double>(e->n);
+    }
+    L.total = c.off;
+    L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
+    return L;
+}
+
+nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
+    if (!d || d->m <= 0 || d->n_local <= 0 || d->K_total <= 0 || d->T <= 0) {
+        set_error("nmfx_engine: m, n_local, K_total, T must be positive");
+        return NMFX_ERR_INVALID;
+    }
+    if (d->divergence == NMFX_DIV_AB && d->alpha == 0 && d->beta == 0) {   // nmf.m:120-122
+        set_error("alpha = 0 and beta = 0 is not supported at this time.");
+        return NMFX_ERR_INVALID;
+    }
+    if (d->divergence < 0 || d->divergence > NMFX_DIV_EUCLIDEAN_NOCOST) {
+        set_error("nmfx_engine: unknown divergence %d", d->divergence);
+        return NMFX_ERR_INVALID;
+    }
+    if (d->T > 1 && d->n_local < d->T) {
+        set_error("nmfx_engine: context_len %d exceeds the number of columns %ld", d->T, (long)d->n_local);
+        return NMFX_ERR_INVALID;
+    }
+    e->m = d->m;
+    e->n = d->n_local;
+    e->hL = d->halo_left; e->hR = d->halo_right;
+    e->nvalid = (d->halo_left || d->halo_right) ? d->n_valid : d->n_local;
+    if (e->hL < 0 || e->hR < 0 || e->nvalid < d->n_local || e->nvalid > d->n_local + d->halo_right) {
+        set_error("nmfx_engine: inconsistent halo description");
+        return NMFX_ERR_INVALID;
+    }
+    if ((e->hL || e->hR) && d->algorithm != 1) {
+        set_error("nmfx_engine: halos are only meaningful for cnmf");
+        return NMFX_ERR_INVALID;
+    }
+    e->K = d->K_total;
+    e->K_valid = (d->K_valid > 0 && d->K_valid < d->K_total) ? d->K_valid : 0;
+    if (e->K_valid && d->algorithm == 1) { set_error("nmfx_engine: K padding is not defined for cnmf"); return NMFX_ERR_INVALID; }
+    e->T = d->T;
+    e->KT = d->K_total * d->T;
+    e->div = d->divergence;
+    e->device = d->device;
+    e->st = static_cast<hipStream_t>(d->stream);
+    e->prof.st = e->st;
+    e->rank0 = 1;
+    e->algo = d->algorithm;
+    e->alpha = d->divergence == NMFX_DIV_AB ? d->alpha : 1.0;
+    e->beta = d->divergence == NMFX_DIV_AB ? d->beta : 1.0;
+    if (e->algo < 0 || e->algo > 3) { set_error("nmfx_engine: unknown algorithm %d", e->algo); return NMFX_ERR_INVALID; }
+    if (e->algo == 3 && e->div == NMFX_DIV_AB && e->alpha != 0) {
+        // constrainednmf.m:229 `W' * V.^alpha .* V_hat.^(beta-1) * A'` multiplies a K x n by an m x n matrix element-wise: MATLAB
+        // raises a dimension error there (unless K == m), so there is no reference behaviour to reproduce
+        set_error("constrainednmf: the alpha-beta update with alpha ~= 0 is ill-formed in the reference (constrainednmf.m:229); use alpha = 0 (dual form), euclidean, kl or is");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (e->algo != 1 && e->T != 1) {
+        set_error("nmfx_engine: algorithms nmf / lnmf / constrainednmf require T == 1");
+        return NMFX_ERR_INVALID;
+    }
+    if (e->algo == 2 && e->div != NMFX_DIV_KL) {
+        set_error("nmfx_engine: lnmf is defined for the KL divergence only (lnmf.m:69,76,81)");
+        return NMFX_ERR_INVALID;
+    }
+    // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
+    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps and two accumulator sets per pass: K <= 128
+    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 128;
+    const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
+                          e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
+    if (d->path == 2 && !eligible && e->algo != 1) {   // cnmf: see the fused shift-sum passes below
+        set_error("nmfx_engine: fused path requested but the problem is not eligible (nmf / lnmf / constrainednmf rules, kl or euclidean, K a multiple of 32 up to 256)");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    e->fused = eligible && d->path != 1;
+    if (!e->fused) e->dual = false;
+    static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
+    // the transposed copy of V (euclidean paths) is a luxury: only where the device clearly has the room for it next to V
+    // itself (V may or may not be allocated yet at this point: 2.5 x its size + 1 GiB must be free either way)
+    bool room_vt = true;
+    {
+        size_t free_b = 0, total_b = 0;
+        DeviceGuard dg_;
+        if (hipSetDevice(d->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            room_vt = (double)free_b >= 2.5 * 4.0 * (double)e->m * (double)e->n + (double)(1ull << 30);
+        (void)hipGetLastError();
+    }
+    e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt && room_vt;
+    // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
+    // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
+    e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
+    static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
+    e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
+    e->fusedT_kl = !e->fused && e->algo == 1 && e->div == NMFX_DIV_KL && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 &&
+                   e->hL == 0 && e->hR == 0 && d->path != 1 && !no_fusedT;
+    if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl) {
+        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or unsharded kl, T > 1, an instantiated (K, T) pair)");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
+    e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
+    static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
+    e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
+    {   // euclidean cnmf on the fused passes, unsharded: the Q product of the H step on a transposed copy of V (see nmfx_engine_hstep)
+        static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;
+        static const int vtq_env = getenv("NMFX_VTQ_BLOCK") ? atoi(getenv("NMFX_VTQ_BLOCK")) : 0;   // dev switch: 128 | 256
+        e->vtq_block = vtq_env ? vtq_env : 128;   // C4 (K*T = 512): four 128-wide blocks, two workgroups per CU, 0.526 ms; two 256-wide blocks 0.549; the two-operand GEMM 0.585
+        e->use_vtq = e->fusedT && e->qgemm && e->hL == 0 && e->hR == 0 && !no_vt && room_vt && e->KT % e->vtq_block == 0 && fused_supported(e->vtq_block);
+    }
+    e->nsplit_w = e->isplit_h = 1;
+    if (e->fused) {
+        e->nsplit_w = fused_split((e->m + 127) / 128, e->n, e->K, &e->cps_w);
+        e->isplit_h = fused_split((e->n + 127) / 128, e->m, e->K, &e->cps_h);
+    }
+    return NMFX_OK;
+}
+
+inline int norm_mode(const nmfx_engine *e) { return e->algo == 3 ? 0 : e->algo; }   // w_normalize: 0 L2 columns, 1 cnmf slabs, 2 L1 (lnmf)
+inline int mdiv(const nmfx_engine *e) { return e->div == NMFX_DIV_EUCLIDEAN_NOCOST ? NMFX_DIV_EUCLIDEAN : e->div; }
+
+// element maps (V, V_hat) -> numerator operand A, denominator operand B   (nmf.m:149-156, cnmf.m:191-192)
+void num_view(const nmfx_engine *e, OpView &v) {
+    v.p = e->V;
+    v.p2 = nullptr;
+    v.func = NMFX_PRO_NONE;
+    if (mdiv(e) == NMFX_DIV_KL) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO; }
+    if (mdiv(e) == NMFX_DIV_IS) { v.p2 = e->Vhat; v.func = NMFX_PRO_RATIO_SQ; }
+    if (mdiv(e) == NMFX_DIV_AB) {   // nmf.m:159-163: V.^(a-1).*V_hat.^b (dual, a == 0)  |  V.^a.*V_hat.^(b-1)
+        v.p2 = e->Vhat; v.func = NMFX_PRO_POWPROD;
+        if (e->alpha == 0) { v.e1 = (float)(e->alpha - 1); v.e2 = (float)e->beta; }
+        else { v.e1 = (float)e->alpha; v.e2 = (float)(e->beta - 1); }
+    }
+}
+void den_view(const nmfx_engine *e, OpView &v) {
+    v.p = e->Vhat;
+    v.p2 = nullptr;
+    v.func = NMFX_PRO_NONE;
+    if (mdiv(e) == NMFX_DIV_IS) { v.p = e->Vhat; v.p2 = e->Vhat; v.func = NMFX_PRO_RECIP2; }
+    if (mdiv(e) == NMFX_DIV_AB) {   // V.^(a+b-1) (dual)  |  V_hat.^(a+b-1)
+        v.p = e->alpha == 0 ? e->V : e->Vhat; v.p2 = v.p; v.func = NMFX_PRO_POWPROD;
+        v.e1 = (float)(e->alpha + e->beta - 1); v.e2 = 0.f;
+    }
+}
+inline float outer_exp(const nmfx_engine *e) {   // the .^(1/alpha) (.^(1/beta) in the dual form) around both gradients, nmf.m:159-163
+    if (mdiv(e) != NMFX_DIV_AB) return 1.0f;
+    return (float)(1.0 / (e->alpha == 0 ? e->beta : e->alpha));
+}
+
+// V_hat = sum_t W_t * rshift_t(H)    (RFD.m:31 / 36-38) ; optionally fused with the cost reduction
+nmfx_status recon(nmfx_engine *e, bool with_cost, bool store = true) {
+    Scope s(e, with_cost ? TAG_RECON_COST : TAG_RECON);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->m; g.N = e->n + e->hR; g.Kc = e->KT;   // V_hat also on the right-halo columns: the H step of the last T-1 local columns needs it
+    g.A = OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
+    g.C = e->Vhat; g.ldc = e->m;
+    g.cost_ncols = e->hR ? e->n : 0;
+    g.splitk = 1;
+    if (with_cost) {
+        g.epi = EPI_COST; g.store_c = store ? 1 : 0; g.cost_div = mdiv(e); g.Vref = e->V; g.ldv = e->m; g.cost_partials = e->cost_partials;
+        g.cost_alpha = (float)e->alpha; g.cost_beta = (float)e->beta;
+        long blocks = 0;
+        nmfx_status rc = launch_gemm(e->st, g, &blocks);
+        e->n_cost_used = (int)blocks;
+        return rc;
+    }
+    g.epi = EPI_STORE;
+    return launch_gemm(e->st, g);
+}
+
+// out (m x KT) = X * H_stack'   with X given by view x   (nmf.m:149 V*H', cnmf.m:191)
+nmfx_status x_times_ht(nmfx_engine *e, OpView x, float *out, int tag) {
+    Scope s(e, tag);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->m; g.N = e->KT; g.Kc = e->n;
+    x.ld = e->m; x.mode = VIEW_RC; x.blk = 0; x.tstride = 0; x.lim = 0;
+    g.A = x;
+    if (e->T == 1) g.B = OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+    else g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
+    g.C = out; g.ldc = e->m; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+// out (K x n) = sum_t W_t' * lshift_t(X)    (nmf.m:180 W'*V, cnmf.m:217-226)
+nmfx_status wt_times_x(nmfx_engine *e, OpView x, float *out, int tag) {
+    Scope s(e, tag);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = e->K; g.N = e->n; g.Kc = (long)e->T * e->m;
+    if (e->T == 1) {
+        g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        x.ld = e->m; x.mode = VIEW_KC; x.blk = 0; x.tstride = 0; x.lim = 0;
+    } else {
+        g.A = OpView{e->W, nullptr, e->m, VIEW_WSTACK_KC, (int)e->m, e->m * e->K, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        x.ld = e->m; x.mode = VIEW_XSHIFT_KC; x.blk = (int)e->m; x.tstride = 0; x.lim = (int)e->nvalid;
+    }
+    g.B = x;
+    g.C = out; g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+
+// C (M x N) = A (M x Kc) * B (Kc x N) with plain views; small K x K products of the euclidean Gram form
+nmfx_status small_gemm(nmfx_engine *e, long M, long N, long Kc, OpView A, OpView B, float *C, long ldc) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.Kc = Kc; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes);
+}
+
+nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form = false) {
+    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (e->cost_dst2) e->cost_dst2_done = true;
+    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+    if (useH) {   // constrainednmf.m:251 charges Z_sparsity on |Z|, not on H = Z*A
+        if (e->algo == 3) TRY(row_reduce(e->st, e->Z, e->K, e->K, e->nz, 2, e->l1H, e->rr_scratch));
+        else TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    }
+    double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
+    if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
+    if (e->fused && e->dual) {
+        // fused IS: partials hold sum(V./V_hat - log(V./V_hat)); nmf.m:212 subtracts 1 per element.  Fused alpha-beta: partials hold
+        // sum(V.^a.*V_hat.^b - b/(a+b)*V_hat.^(a+b)); nmf.m:214 subtracts (a*sum(V.^(a+b)) + b*m*n) / (a+b) inside the scaled sum
+        const double cnt = (double)e->m * (double)e->n;
+        double pa = 0.0, pb = -cnt;
+        if (mdiv(e) == NMFX_DIV_AB) {
+            const double ab = e->alpha + e->beta;
+            if (ab != 0) { pa = -e->alpha / ab; pb = -e->beta * cnt / ab; }
+            else { pa = 0.0; pb = -((e->alpha + 2.0 * e->beta) * cnt) / ab; }   // nmf.m:214 divides by alpha + beta: +-Inf cost, like the reference
+        }
+        return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
+                           e->lamH, e->cost, nullptr, nullptr, 0, nullptr, mdiv(e) == NMFX_DIV_AB ? e->sumVab : nullptr, pa, pb, e->cost_dst2);
+    }
+    // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
+    const bool tail = e->fused && kl_closed_form && e->tail_with_cost;
+    return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
+                       e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV, nullptr, 0.0, 0.0,
+                       e->cost_dst2, tail ? e->rowsum : nullptr, tail ? e->packed + (size_t)e->m * e->KT : nullptr, e->K);
+}
+
+
+}  // namespace
+
+namespace nmfx {
+// grid.y of a fused pass over `blocks` 128-row blocks: enough workgroups for 256 CUs while every slice keeps whole 64-column tiles
+int fused_split(long blocks, long extent, int K, long *c_per_split) {
+    const long target = K <= 128 ? 512 : 256;   // K <= 128 kernels fit two workgroups per CU
+    const long tiles = (extent + 63) / 64;
+    long s = 1;
+    while (blocks * s < target && s * 2 <= tiles) s *= 2;   // every split keeps at least one 64-wide tile
+    const long per = (tiles + s - 1) / s;                   // tiles per split; trailing splits that would be empty are dropped
+    *c_per_split = per * 64;
+    return (int)((tiles + per - 1) / per);
+}
+}  // namespace nmfx
+
+namespace {
+
+// fused W-step pass (K2) or cost-only pass over rows [row0, row0 + rows) of the local shard.  N of those rows goes to `out`
+// as a contiguous rows x K block; cost partials are appended at e->chunk_parts.
+nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out) {
+    long cps = 0;
+    const long blocks = (rows + 127) / 128;
+    const int split = fused_split(blocks, e->n, e->K, &cps);
+    if ((size_t)split * rows * e->K > (size_t)std::max(e->nsplit_w, 2) * e->m * e->K || e->chunk_parts + blocks * split > e->n_cost_partials) {
+        set_error("fused W-step: row chunk too small for the workspace");
+        return NMFX_ERR_INVALID;
+    }
+    FusedParams f;
+    memset(&f, 0, sizeof(f));
+    f.X = e->W + row0; f.xs_r = 1; f.xs_k = e->m;
+    f.Y = e->H; f.D = e->V + row0; f.ldd = e->m; f.R = rows; f.Cn = e->n; f.K = e->K;
+    f.c_per_split = cps;
+    f.out = split == 1 ? out : e->slabs;
+    f.slab_stride = rows * (long)e->K; f.os_r = 1; f.os_k = rows;
+    f.cost_partials = e->cost_partials + e->chunk_parts;
+    int func = e->div == NMFX_DIV_KL ? 3 : 1;
+    float *out2 = nullptr;
+    if (e->dual) {   // IS / alpha-beta: the denominators come out of the same pass, into the second half of `packed`
+        if (rows != e->m) { set_error("fused IS / alpha-beta W step: row chunks are not supported"); return NMFX_ERR_UNSUPPORTED; }
+        func = mdiv(e) == NMFX_DIV_IS ? 4 : 5;
+        out2 = out + (size_t)e->m * e->K;
+        f.out2 = split == 1 ? out2 : e->slabs2;
+        f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = 1.0f;
+        if (e->Valpha) f.D = e->Valpha + row0;
+    }
+    {
+        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
+    }
+    e->chunk_parts += (int)(blocks * split);
+    if (do_g2 && split > 1) {
+        Scope s(e, TAG_SMALL);
+        TRY(reduce_slabs(e->st, e->slabs, split, f.slab_stride, f.slab_stride, out, 0));
+        if (e->dual) TRY(reduce_slabs(e->st, e->slabs2, split, f.slab_stride, f.slab_stride, out2, 0));
+    }
+    return NMFX_OK;
+}
+// after the last row chunk: rowsum(H) (KL: also the W-step denominator, nmf.m:153) and the cost of the CURRENT (W, H)
+nmfx_status fused_wpass_finish(nmfx_engine *e) {
+    Scope s(e, TAG_SMALL);
+    const bool kl = e->div == NMFX_DIV_KL;
+    if (kl) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+    TRY(cost_from_partials(e, e->chunk_parts, kl));
+    e->cost_valid = true;
+    return NMFX_OK;
+}
+nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
+    e->chunk_parts = 0;
+    e->tail_with_cost = do_g2;   // a W-step partial: the cost finisher also fills the fp32 tail [rowsum(H)] of `packed`
+    TRY(fused_wpass_rows(e, do_g2, 0, e->m, e->packed));
+    return fused_wpass_finish(e);
+}
+
+// cnmf fused passes (fused_kernel TT > 1) over the local columns: do_g2 -> N_all = V * H_stack' into `out` (m x KT), else the residual cost
+// partials of the CURRENT (W, H).  H's T-1 columns to the left of the shard are its halo, or zeros (Hpad) on the first / only shard.
+enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3 };
+nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-1 zero columns (lag-form Gram products only)]
+    if (e->hpad_valid) return NMFX_OK;      // H changed since the last pass (init, H step)
+    Scope s(e, TAG_SMALL);
+    TRY(pad_left(e->st, e->H, e->K, e->n, e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));
+    e->hpad_valid = true;
+    return NMFX_OK;
+}
+nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out) {
+    const bool do_g2 = mode == FT_NUM;
+    const float *Hy = e->H;
+    if (e->hL < e->T - 1) {
+        TRY(ensure_hpad(e));
+        Hy = e->Hpad + (size_t)e->K * (e->T - 1);
+    }
+    FusedParams f;
+    memset(&f, 0, sizeof(f));
+    f.X = e->W; f.xs_r = 1; f.xs_k = e->m; f.xs_t = e->m * (long)e->K; f.T = e->T;
+    f.Y = Hy; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->KT;
+    f.D = (mode == FT_NUM && e->fusedT_kl) ? e->Vhat : e->V;      // KL: the numerators contract R = V./V_hat (left in the V_hat buffer by the S pass)
+    if (mode == FT_S_KL) f.Rout = e->Vhat;
+    f.c_per_split = e->cps_T;
+    const long mKT = e->m * (long)e->KT;
+    f.out = e->nsplit_T == 1 ? out : e->slabsT;
+    f.slab_stride = mKT; f.os_r = 1; f.os_k = e->m; f.os_t = e->m * (long)e->K;
+    f.cost_partials = do_g2 ? nullptr : e->cost_partials;
+    const int func = mode == FT_NUM ? 0 : (mode == FT_COST_EUC ? 1 : 3);
+    {
+        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        TRY(launch_fused(e->st, f, e->nsplit_T, true, func, do_g2, 0));
+    }
+    if (do_g2 && e->nsplit_T > 1) {
+        Scope s(e, TAG_SMALL);
+        TRY(reduce_slabs(e->st, e->slabsT, e->nsplit_T, mKT, mKT, out, 0));
+    }
+    if (!do_g2) e->n_cost_used = (int)((e->m + 127) / 128) * e->nsplit_T;
+    return NMFX_OK;
+}
+// KL cnmf on the fused passes: the cost of the CURRENT (W, H) from the S pass's partials, sum(V.*log(V./V_hat)), plus the closed form
+// sum(V_hat) - sum(V) = sum_{t,k} colsum(W_t)_k * sum_{j < n-t} H(k, j) - sum(V)    (the rshift of RFD.m:37 drops the last t columns of H)
+nmfx_status fusedT_kl_cost(nmfx_engine *e) {
+    Scope s(e, TAG_SMALL);
+    TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+    TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, 0));
+    TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+    const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+    if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+    if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+    TRY(finish_cost(e->st, e->cost_partials, e->n_cost_used, 1.0, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K, e->lamH, e->cost,
+                    e->colsum, e->Pvec, e->KT, e->sumV_g, nullptr, 0.0, 0.0, e->cost_dst2));
+    e->cost_valid = true;
+    return NMFX_OK;
+}
+
+nmfx_status refresh_w_derived(nmfx_engine *e, bool have_colsum = false) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
+    TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
+    if (e->div == NMFX_DIV_KL && !have_colsum) {   // (after a W update the update kernel has already left colsum(W) in Gpvec)
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->Gpvec));   // T == 1: colsum(W) is the H-step denominator as is
+    }
+    return NMFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nmfx_last_error(void) { return g_err; }
+int32_t nmfx_version(void) { return NMFX_VERSION; }
+int32_t nmfx_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cnt;
+}
+
+nmfx_status nmfx_engine_workspace_bytes(const nmfx_engine_desc *d, size_t *bytes) {
+    nmfx_engine tmp{};
+    TRY(fill_from_desc(&tmp, d));
+    *bytes = layout(&tmp, nullptr).total;
+    return NMFX_OK;
+}
+nmfx_status nmfx_engine_packed_count(const nmfx_engine_desc *d, size_t *count) {
+    nmfx_engine tmp{};
+    TRY(fill_from_desc(&tmp, d));
+    *count = layout(&tmp, nullptr).packed_count;
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float *W, float *H, void *workspace, size_t workspace_bytes,
+                               float *packed, nmfx_engine **out) {
+    if (!out || !V || !W || !H || !workspace || !packed) { set_error("nmfx_engine_create: null pointer"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(check_device(d ? d->device : 0));
+    nmfx_engine *e = new nmfx_engine{};
+    nmfx_status s = fill_from_desc(e, d);
+    if (s != NMFX_OK) { delete e; return s; }
+    e->V = V; e->W = W; e->Hext = H; e->H = H + (size_t)e->K * e->hL; e->packed = packed;
+    // the transposed copy of V is optional: it is used when the workspace the caller brought has the room for it (nmfx_engine_workspace_bytes
+    // asks for it when the device looked roomy at that moment; a caller that allocated less simply gets the path without it)
+    if ((e->use_vt || e->use_vtq) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = false;
+    else if (!e->use_vt && !e->use_vtq) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
+        nmfx_engine probe = *e;
+        probe.use_vt = probe.fused && probe.div == NMFX_DIV_EUCLIDEAN && getenv("NMFX_NO_VT") == nullptr;
+        probe.use_vtq = probe.fusedT && probe.qgemm && probe.hL == 0 && probe.hR == 0 && getenv("NMFX_NO_VT") == nullptr && probe.KT % probe.vtq_block == 0 && fused_supported(probe.vtq_block);
+        if ((probe.use_vt || probe.use_vtq) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; }
+    }
+    Layout L = layout(e, workspace);
+    if (L.total > workspace_bytes) {
+        set_error("nmfx_engine_create: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        delete e;
+        return NMFX_ERR_INVALID;
+    }
+    std::vector<float> lw(e->K, 0.f), lh(e->K, 0.f);
+    std::vector<uint8_t> fw(e->K, 0), fh(e->K, 0);
+    e->all_fixW = e->all_fixH = true;
+    for (int k = 0; k < e->K; ++k) {
+        if (d->lamW_col) lw[k] = d->lamW_col[k];
+        if (d->lamH_row) lh[k] = d->lamH_row[k];
+        if (d->fixW_col) fw[k] = d->fixW_col[k] ? 1 : 0;
+        if (d->fixH_row) fh[k] = d->fixH_row[k] ? 1 : 0;
+        e->any_lamW |= lw[k] != 0.f;
+        e->any_lamH |= lh[k] != 0.f;
+        e->all_fixW &= fw[k] != 0;
+        e->all_fixH &= fh[k] != 0;
+    }
+    hipError_t he = hipMemcpyAsync(e->lamW, lw.data(), sizeof(float) * e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->lamH, lh.data(), sizeof(float) * e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->fixW, fw.data(), e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipMemcpyAsync(e->fixH, fh.data(), e->K, hipMemcpyHostToDevice, e->st);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->st);  // host vectors go out of scope
+    if (he != hipSuccess) { set_error("nmfx_engine_create: %s", hipGetErrorString(he)); delete e; return NMFX_ERR_HIP; }
+    *out = e;
+    return NMFX_OK;
+}
+
+void nmfx_engine_destroy(nmfx_engine *e) {
+    if (!e) return;
+    if (e->seg_dev) (void)hipFree(e->seg_dev);
+    e->prof.release();
+    delete e;
+}
+
+// constrainednmf (algorithm 3): segments of label-sorted columns and the device cluster matrix Z (K x nz, column-major).
+// seg_host[0] = 0 < seg_host[1] < ... < seg_host[nz] = n_local; call before nmfx_engine_init.
+nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *seg_host, int64_t nz, float *Z_dev) {
+    if (!e || e->algo != 3) { set_error("nmfx_engine_set_constraint: engine was not created with algorithm 3"); return NMFX_ERR_INVALID; }
+    if (!seg_host || !Z_dev || nz <= 0 || nz > e->n) { set_error("nmfx_engine_set_constraint: bad arguments"); return NMFX_ERR_INVALID; }
+    if (seg_host[0] != 0 || seg_host[nz] != e->n) { set_error("nmfx_engine_set_constraint: segments must cover [0, n)"); return NMFX_ERR_INVALID; }
+    for (int64_t c = 0; c < nz; ++c)
+        if (seg_host[c + 1] <= seg_host[c]) { set_error("nmfx_engine_set_constraint: empty segment %ld", (long)c); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->seg_dev) { (void)hipFree(e->seg_dev); e->seg_dev = nullptr; }
+    std::vector<long> sg(seg_host, seg_host + nz + 1);
+    NMFX_HIP(hipMalloc(&e->seg_dev, sizeof(long) * (nz + 1)));
+    NMFX_HIP(hipMemcpyAsync(e->seg_dev, sg.data(), sizeof(long) * (nz + 1), hipMemcpyHostToDevice, e->st));
+    NMFX_HIP(hipStreamSynchronize(e->st));
+    e->Z = Z_dev; e->nz = nz;
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 = is_rank0; return NMFX_OK; }
+
+// nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
+nmfx_status nmfx_engine_init(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    e->hpad_valid = false;
+    if (e->algo == 3) {
+        if (!e->Z) { set_error("nmfx_engine_init: constrainednmf needs nmfx_engine_set_constraint first"); return NMFX_ERR_INVALID; }
+        TRY(z_update(e->st, e->Z, e->H, nullptr, nullptr, nullptr, e->K, e->nz, e->seg_dev, nullptr, nullptr, 1.0f, 1));   // H = Z*A, constrainednmf.m:177
+    }
+    {
+        Scope s(e, TAG_SMALL);
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out, e->K_valid));
+        if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
+        if (e->fused) {
+            e->cost_valid = false;
+            if (e->VT) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+            if (e->div == NMFX_DIV_KL) {   // sum(V_local), once
+                TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
+                TRY(sum_vec(e->st, e->colV, e->n, e->sumV));
+            }
+            if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
+                TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
+                TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
+                if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+            }
+            return refresh_w_derived(e);
+        }
+    }
+    if (e->gram) {                 // no V_hat state on the Gram path
+        if (e->use_vtq) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+        return NMFX_OK;
+    }
+    if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = false;
+        TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV_g));
+        return sum_vec(e->st, e->colV_g, e->n, e->sumV_g);
+    }
+    return recon(e, false);
+}
+
+// local sums of the W step: packed = [N | P]  or  [N | Pvec]        nmf.m:149-164 / cnmf.m:187-192
+static nmfx_status fused_wstep_tail(nmfx_engine *e);
+static nmfx_status generic_wstep_partial(nmfx_engine *e);
+nmfx_status nmfx_engine_wstep_partial(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) {
+        // one pass over V: N = (V./(W*H)) * H' (KL) or V*H' (euclidean), and the cost of the current (W, H) as a by-product
+        e->w_chunks = 1;
+        TRY(fused_wpass(e, true));
+        return fused_wstep_tail(e);
+    }
+    return generic_wstep_partial(e);
+}
+
+// what follows the last row chunk of a fused W-step partial: the small tail of `packed`
+static nmfx_status fused_wstep_tail(nmfx_engine *e) {
+    const size_t mKT = (size_t)e->m * e->KT;
+    if (e->dual) return NMFX_OK;   // [N | P] is complete: both halves came out of the pass
+    if (e->div == NMFX_DIV_KL) {
+        // rowsum(H) was formed by fused_wpass_finish, whose cost finisher has also written it into the tail of `packed` (tail_with_cost)
+    } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
+        Scope s(e, TAG_GRAM);
+        TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
+    }
+    return NMFX_OK;
+}
+
+// row-chunked form of the fused W-step partial (overlap of the all-reduce with compute on column shards): chunk c of nchunks
+// computes rows [c*m/nchunks, (c+1)*m/nchunks) of N into the contiguous block packed + c*(m/nchunks)*K; after the last chunk the
+// tail ([rowsum(H)] or [H*H']) and the lagged cost are ready.  wstep_finish reads the chunked layout.
+nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (!e->fused || e->dual) { set_error("nmfx_engine_wstep_partial_chunk: fused kl / euclidean path only"); return NMFX_ERR_UNSUPPORTED; }
+    if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % (128L * nchunks) != 0) { set_error("nmfx_engine_wstep_partial_chunk: m must split into nchunks multiples of 128 rows"); return NMFX_ERR_INVALID; }
+    const long rows = e->m / nchunks;
+    if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; }
+    TRY(fused_wpass_rows(e, true, rows * chunk, rows, e->packed + (size_t)chunk * rows * e->K));
+    if (chunk + 1 < nchunks) return NMFX_OK;
+    e->tail_with_cost = true;
+    TRY(fused_wpass_finish(e));
+    return fused_wstep_tail(e);
+}
+// element range of `packed` that becomes final with chunk c (the last one carries the tail): what the caller all-reduces
+nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchunks, size_t *offset, size_t *count) {
+    if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % nchunks != 0) { set_error("nmfx_engine_packed_chunk: bad chunk"); return NMFX_ERR_INVALID; }
+    const size_t per = (size_t)(e->m / nchunks) * e->KT, mKT = (size_t)e->m * e->KT;
+    size_t tail = 0;
+    if (e->fused) tail = e->dual ? mKT : (e->div == NMFX_DIV_EUCLIDEAN ? (size_t)e->K * e->K : (size_t)e->KT);
+    else if (nchunks != 1) { set_error("nmfx_engine_packed_chunk: only the fused path chunks its W step"); return NMFX_ERR_UNSUPPORTED; }
+    else tail = e->gram ? (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? mKT : (size_t)e->KT);
+    *offset = per * chunk;
+    *count = per + (chunk + 1 == nchunks ? tail : 0);
+    return NMFX_OK;
+}
+
+static nmfx_status generic_wstep_partial(nmfx_engine *e) {
+    const size_t mKT = (size_t)e->m * e->KT;
+    if (e->fusedT_kl) {   // S pass: R = V./V_hat into the V_hat buffer + the (lagged) cost of the state this iteration starts from
+        TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
+        TRY(fusedT_kl_cost(e));
+    }
+    if (e->all_fixW) return NMFX_OK;
+    OpView a{}, b{};
+    num_view(e, a);
+    if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
+    else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
+    if (e->lagram) {   // Hs*Hs' from the T lag Grams L_d = sum_u H(:,u) H(:,u+d)' (K x T*K, contraction n, on the zero-padded copy) + boundary terms
+        TRY(ensure_hpad(e));
+        Scope s(e, TAG_GRAM);
+        const float *Hc = e->Hpad + (size_t)e->K * (e->T - 1);
+        TRY(small_gemm(e, e->K, e->KT, e->n, OpView{Hc, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{Hc + (size_t)e->K * (e->T - 1), nullptr, (long)e->K, VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->T - 1}, e->Llag, e->K));
+        TRY(gram_from_lags(e->st, e->Llag, e->H, e->K, e->T, e->n, e->packed + mKT));
+    } else if (e->gram) {   // Hs*Hs' (KT x KT): what gets all-reduced instead of V_hat*Hs'
+        Scope s(e, TAG_GRAM);
+        OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
+        TRY(small_gemm(e, e->KT, e->KT, e->n, hs, hs, e->packed + mKT, e->KT));
+    } else if (div_has_matrix_den(e->div)) {
+        den_view(e, b);
+        TRY(x_times_ht(e, b, e->packed + mKT, TAG_WDEN));
+    } else {
+        Scope s(e, TAG_SMALL);
+        TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+        TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, e->hL));
+        TRY(d2f(e->st, e->Pvec, e->packed + mKT, e->KT));
+    }
+    return NMFX_OK;
+}
+
+// replicated part of the W step (after the all-reduce of packed): nmf.m:168-173 / cnmf.m:193-204
+nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) {
+        if (e->all_fixW) return NMFX_OK;
+        const size_t mK = (size_t)e->m * e->K;
+        WUpdateParams p{};
+        p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = 1;
+        p.n_chunks = e->w_chunks > 1 ? e->w_chunks : 1;   // row-chunked partial: N is stored as contiguous (m/chunks x K) blocks
+        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = 1.0f;
+        if (e->dual) {
+            p.P = e->packed + mK;       // nmf.m:155-156,162-163: the all-reduced denominators
+            p.inv_exp = outer_exp(e);
+        } else if (e->div == NMFX_DIV_KL) {
+            Scope s(e, TAG_SMALL);
+            p.Pvecf = e->packed + mK;   // the all-reduced rowsum(H), still fp32 as it travelled
+        } else {
+            Scope s(e, TAG_GRAM);   // P = W * (H*H')
+            TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
+            p.P = e->Pbuf;
+        }
+        Scope s(e, TAG_SMALL);
+        p.rule = e->algo == 2 ? 1 : 0;
+        // update, column normalisation (nmf.m:169 / lnmf.m:70) and, for KL, the column sums of the final W (H-step denominator) in ONE launch
+        p.fuse_norm = norm_mode(e) == 2 ? 2 : 1;
+        p.colsum_out = e->div == NMFX_DIV_KL ? e->Gpvec : nullptr;
+        TRY(w_update(e->st, p));
+        e->cost_valid = false;
+        return refresh_w_derived(e, true);
+    }
+    if (!e->all_fixW) {
+        Scope s(e, TAG_SMALL);
+        const size_t mKT = (size_t)e->m * e->KT;
+        WUpdateParams p{};
+        p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = e->T;
+        p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = outer_exp(e);
+        if (e->gram) {   // P_all = W_flat * (Hs*Hs')
+            TRY(small_gemm(e, e->m, e->KT, e->KT, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->packed + mKT, nullptr, (long)e->KT, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
+            p.P = e->Pbuf;
+        } else if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
+        else {
+            TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
+            p.Pvec = e->Pvec;
+        }
+        p.rule = e->algo == 2 ? 1 : 0;
+        TRY(w_update(e->st, p));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
+    }
+    if (e->gram || e->fusedT_kl) return NMFX_OK;
+    return recon(e, false);
+}
+
+nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e);
+// H step + V_hat refresh + local cost partial: nmf.m:176-218 / cnmf.m:207-251
+nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) {
+        if (e->all_fixH) return NMFX_OK;
+        if (e->div == NMFX_DIV_EUCLIDEAN) {   // W'*V_hat = (W'*W)*H   
+            Scope s(e, TAG_GRAM);
+            TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->GW, e->K));
+            TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                           OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Gp, e->K));
+        }
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = e->H; f.xs_r = e->K; f.xs_k = 1;
+        f.Y = e->WT; f.D = e->V; f.ldd = e->m; f.R = e->n; f.Cn = e->m; f.K = e->K;
+        f.c_per_split = e->cps_h;
+        const int func = e->dual ? (mdiv(e) == NMFX_DIV_IS ? 4 : 5) : (e->div == NMFX_DIV_KL ? 2 : 0);
+        const bool kl = e->div == NMFX_DIV_KL;
+        if (e->dual) {
+            f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = outer_exp(e);
+            if (e->Valpha) f.D = e->Valpha;
+        }
+        static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
+        if (func == 0 && e->VT && !euc_fused_h) {
+            // euclidean: the numerator W'*V has no first product.  The H-step form of the stationary kernel reads its V tile with the lanes
+            // ACROSS columns (16-byte pieces at stride m) and, with half the MFMA work per tile to hide that under, ran 0.61 ms at C2; the
+            // pipelined two-operand GEMM 0.60 ms (0.75 of peak).  V never changes, so a transposed copy made once turns the product into
+            // (V'*W)' on the W-STEP form -- lanes along the contiguous dimension, the pass V*H' already runs at 0.86 of peak:
+            //   stationary rows = columns j of V (rows of V'), streamed rows = rows i of W (the W' copy), out(k, j) at Gn[k + K*j]
+            FusedParams g;
+            memset(&g, 0, sizeof(g));
+            g.Y = e->WT; g.D = e->VT; g.ldd = e->n; g.R = e->n; g.Cn = e->m; g.K = e->K; g.c_per_split = e->cps_h;
+            g.out = e->isplit_h == 1 ? e->Gn : e->slabs; g.slab_stride = (long)e->K * e->n; g.os_r = e->K; g.os_k = 1;
+            {
+                Scope s(e, TAG_HNUM);
+                TRY(launch_fused(e->st, g, e->isplit_h, true, 0, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
+            if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, g.slab_stride, g.slab_stride, e->Gn, 0));
+            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, e->isplit_h, g.slab_stride));
+            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        } else if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
+            // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
+            // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
+            {
+                Scope s(e, TAG_HNUM);
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->K; g.N = e->n; g.Kc = e->m;
+                g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{e->V, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.C = e->Gn; g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
+            }
+            Scope s(e, TAG_SMALL);
+            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+        } else if (e->isplit_h == 1 && e->algo != 3) {
+            f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
+            f.sqrt_rule = e->algo == 2;
+            Scope s(e, TAG_FUSED_H);
+            TRY(launch_fused(e->st, f, 1, false, func, true, 1));
+        } else if (e->dual) {   // split over the rows of W, or constrainednmf: numerator and denominator slabs, then the generic update
+            f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.out2 = e->isplit_h == 1 ? e->Gp : e->slabs2;
+            f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
+            {
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            if (e->isplit_h > 1) {
+                TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+                TRY(reduce_slabs(e->st, e->slabs2, e->isplit_h, f.slab_stride, f.slab_stride, e->Gp, 0));
+            }
+            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
+        } else {
+            f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
+            {
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
+            }
+            Scope s(e, TAG_SMALL);
+            const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
+            if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f,
+                                       e->isplit_h, f.slab_stride));
+            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
+        }
+        e->cost_valid = false;
+        return NMFX_OK;
+    }
+    if (!e->all_fixH) {
+        OpView a{}, b{};
+        num_view(e, a);
+        if (e->lagram) TRY(ensure_hpad(e));   // the denominator below reads the padded copy of the CURRENT H
+        if (e->fusedT_kl) {   // R = V./V_hat with the W just updated
+            TRY(fusedT_pass(e, FT_S_KL, nullptr));
+            a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        }
+        e->hpad_valid = false;
+        if (e->qgemm) {
+            // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
+            // (K x n) GEMM with contraction T*m whose 64-row output starves the tiles
+            if (e->use_vtq && a.p == e->V && !a.p2 && a.func == NMFX_PRO_NONE && e->nvalid == e->n) {
+                // Q' = V' * W_flat on the W-step form of the stationary kernel (rows of V' stationary, rows of W_flat streamed as K-wide column
+                // blocks, one block per grid.z): its V tile is read along the contiguous dimension, which the two-operand GEMM (0.77 of peak
+                // here) and the H-step form cannot offer
+                {
+                    Scope s2(e, TAG_SMALL);
+                    TRY(transpose_f32(e->st, e->W, e->m, e->KT, e->WTf));
+                }
+                FusedParams q;
+                memset(&q, 0, sizeof(q));
+                const int kb = e->vtq_block;
+                q.Y = e->WTf; q.y_stride = e->KT; q.nz = e->KT / kb; q.yz_stride = kb; q.oz_stride = kb;
+                q.D = e->VT; q.ldd = e->n; q.R = e->n; q.Cn = e->m; q.K = kb;
+                long cps = 0;
+                const int split = fused_split(((e->n + 127) / 128) * q.nz, e->m, kb, &cps);
+                const bool can_split = split > 1 && e->gemm_scratch_bytes >= sizeof(float) * (size_t)split * e->KT * e->n;
+                q.c_per_split = can_split ? cps : (e->m + 63) / 64 * 64;
+                q.out = can_split ? e->gemm_scratch : e->Qbuf; q.slab_stride = (long)e->KT * e->n; q.os_r = e->KT; q.os_k = 1;
+                {
+                    Scope s2(e, TAG_HNUM);
+                    TRY(launch_fused(e->st, q, can_split ? split : 1, true, 0, true, 0));
+                }
+                if (can_split) { Scope s2(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->gemm_scratch, split, q.slab_stride, q.slab_stride, e->Qbuf, 0)); }
+            } else {
+                Scope s(e, TAG_HNUM);
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->KT; g.N = e->nvalid; g.Kc = e->m;
+                g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                a.ld = e->m; a.mode = VIEW_KC; a.blk = 0; a.tstride = 0; a.lim = 0;   // the numerator operand (V, V./V_hat, ...) un-shifted
+                g.B = a;
+                g.C = e->Qbuf; g.ldc = e->KT; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
+            }
+            Scope s(e, TAG_SMALL);
+            TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gn));
+        } else TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
+        if (e->gram) {
+            // sum_t W_t' * lshift_t(V_hat) = sum_t D_t * lshift_t(Hs),  D = W_flat' * W_flat  (cnmf.m:217-226 without V_hat)
+            Scope s(e, TAG_GRAM);
+            OpView wf{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+            TRY(small_gemm(e, e->KT, e->KT, e->m, wf, wf, e->CC, e->KT));
+            if (e->lagram) {
+                // by lag: E_d = sum_{t-t'=d} D_(t,t'), Gp = sum_d E_d * H(:, j+d) as ONE K x n GEMM with contraction (2T-1)*K over the padded H;
+                // the last T-1 columns (where lshift_t drops terms) term by term
+                TRY(lag_sum(e->st, e->CC, e->K, e->T, e->Elag));
+                const float *Hc = e->Hpad + (size_t)e->K * (e->T - 1);
+                TRY(small_gemm(e, e->K, e->n, (long)(2 * e->T - 1) * e->K, OpView{e->Elag, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                               OpView{Hc + (size_t)e->K * (e->T - 1), nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, 2 * (e->T - 1)}, e->Gp, e->K));
+                TRY(gp_tail(e->st, e->CC, e->H, e->K, e->T, e->n, e->Gp));
+            } else {
+            GemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.M = e->K; g.N = e->n; g.Kc = e->KT;   // columns j >= n - t are masked by the view (lshift zero fill), so N stays tileable
+            g.A = OpView{e->CC, nullptr, (long)e->KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+            g.B = OpView{e->H, nullptr, (long)e->K, VIEW_HSTACK_KC, e->K, e->nvalid, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
+            g.ldc = e->K; g.epi = EPI_STORE; g.splitk = 1;
+            const size_t Kn = (size_t)e->K * e->n;
+            if (e->T > 1 && gemm_pipe_eligible(g) && e->gemm_scratch_bytes >= Kn * e->T * sizeof(float)) {
+                // all T shifts in ONE launch (blockIdx.z = t, slab t), then a deterministic slab sum
+                g.zbatch = e->T; g.zA_off = e->K; g.zB_off = e->K; g.zB_lim = 1; g.zB_tstride = -1;
+                g.C = e->gemm_scratch; g.slab_stride = (long)Kn;
+                TRY(launch_gemm(e->st, g));
+                TRY(reduce_slabs(e->st, e->gemm_scratch, e->T, (long)Kn, (long)Kn, e->Gp, 0));
+            } else {
+                for (int t = 0; t < e->T; ++t) {
+                    GemmParams gt = g;
+                    gt.A.p = e->CC + (long)t * e->K;
+                    gt.B.p = e->H + (long)e->K * t; gt.B.tstride = e->nvalid - t; gt.B.lim = t;
+                    gt.C = e->Gp; gt.accumulate = t > 0;
+                    TRY(launch_gemm(e->st, gt));
+                }
+            }
+            }
+        } else if (div_has_matrix_den(e->div)) {
+            den_view(e, b);
+            TRY(wt_times_x(e, b, e->Gp, TAG_HDEN));
+        }
+        Scope s(e, TAG_SMALL);
+        if (!div_has_matrix_den(e->div)) {
+            TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+            TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
+        }
+        if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
+        else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
+    }
+    if (e->defer_hfinish) return NMFX_OK;   // the caller refreshes H's halos first, then calls nmfx_engine_hstep_finish
+    return nmfx_engine_hstep_finish(e);
+}
+
+// second half of the H step on the generic paths: V_hat refresh (+ cost) with the NEW H -- on a column shard the halo
+// columns of H must have been refreshed from the neighbours before this runs (V_hat near the shard edges depends on them)
+nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->fused) return NMFX_OK;
+    const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
+    if (e->fusedT_kl) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
+    else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
+    else TRY(recon(e, !nocost));
+    Scope s(e, TAG_SMALL);
+    e->cost_valid = true;
+    return cost_from_partials(e, nocost ? 0 : e->n_cost_used);
+}
+nmfx_status nmfx_engine_defer_hstep_finish(nmfx_engine *e, int32_t defer) { e->defer_hfinish = defer != 0; return NMFX_OK; }
+
+// make e->cost hold the cost of the CURRENT (W, H): free on the generic path (hstep already did it), one S = W*H pass on the
+// fused path unless the last wstep_partial just produced it
+nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    if (e->cost_valid) return NMFX_OK;
+    if (e->fused) return fused_wpass(e, false);
+    if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
+    set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
+    return NMFX_ERR_INVALID;
+}
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->fusedT ? 3 : (e->gram ? 2 : 0))); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 2 Gram form on the GEMM, 0 materialised V_hat
+
+nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
+nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
+    NMFX_HIP(hipMemcpyAsync(dst_dev, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    return NMFX_OK;
+}
+
+// the whole stretch between two all-reduces of a column-sharded run as ONE call: replicated W update, local H step, and (unless
+// `last`) the next iteration's W-step partial.  Not for cnmf shards, whose H step is split around the halo exchange.
+nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
+    if (e->hL || e->hR) { set_error("nmfx_engine_between_allreduces: not for shards with halos"); return NMFX_ERR_UNSUPPORTED; }
+    TRY(nmfx_engine_wstep_finish(e));
+    TRY(nmfx_engine_hstep(e));
+    if (!last) TRY(nmfx_engine_wstep_partial(e));
+    return NMFX_OK;
+}
+
+nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
+    const bool lag = e->fused || e->fusedT_kl;   // the cost of iteration i is a by-product of the first pass of iteration i+1
+    for (int it = 0; it < iters; ++it) {
+        // fused path: the W-step pass also produces the cost of the state it starts from, i.e. of iteration it-1; its finisher writes it
+        // straight into the caller's vector (no separate 8-byte copy)
+        e->cost_dst2 = (lag && it > 0 && dev_cost_out) ? dev_cost_out + it - 1 : nullptr;
+        nmfx_status ws_ = nmfx_engine_wstep_partial(e);
+        e->cost_dst2 = nullptr;
+        TRY(ws_);
+        TRY(nmfx_engine_wstep_finish(e));
+        // un-lagged paths: the cost of this iteration is finished inside the H step; its finisher writes the caller's slot too
+        e->cost_dst2 = (!lag && dev_cost_out) ? dev_cost_out + it : nullptr;
+        e->cost_dst2_done = false;
+        nmfx_status hs_ = nmfx_engine_hstep(e);
+        e->cost_dst2 = nullptr;
+        TRY(hs_);
+        if (!lag && dev_cost_out && !e->cost_dst2_done) NMFX_HIP(hipMemcpyAsync(dev_cost_out + it, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    }
+    if (lag && iters > 0 && dev_cost_out) {   // cost of the last iteration: one extra S = W*H pass
+        TRY(nmfx_engine_cost_pass(e));
+        NMFX_HIP(hipMemcpyAsync(dev_cost_out + iters - 1, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    }
+    return NMFX_OK;
+}
+
+// ---- profiling: hipEvent pairs around every launch group, on the engine's stream -----------------
+nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable) {   // 0 off | 1 every launch group | 2 the MFMA launch groups only
+    e->prof.skip_tag = enable == 2 ? (int)TAG_SMALL : -1;
+    e->prof.enable(enable != 0);
+    return NMFX_OK;
+}
+int32_t nmfx_engine_profile_ntags(void) { return TAG_COUNT; }
+const char *nmfx_engine_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < TAG_COUNT) ? kTagNames[tag] : ""; }
+// after the stream is synchronised: total ms and launch count per tag
+nmfx_status nmfx_engine_profile_read(nmfx_engine *e, double *ms_per_tag, int32_t *count_per_tag) {
+    return e->prof.read(TAG_COUNT, ms_per_tag, count_per_tag);
+}
+// algorithmic flops of ONE launch of the GEMM behind `tag` (2*M*N*Kc by formula) and its algorithmic HBM bytes
+nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, double *bytes) {
+    const double m = (double)e->m, n = (double)e->n, KT = (double)e->KT;
+    const double f = 2.0 * m * n * KT;
+    const bool two_in = mdiv(e) != NMFX_DIV_EUCLIDEAN;
+    double b = 0.0;
+    switch (tag) {
+    case TAG_RECON: b = 4.0 * (m * n + m * KT + e->K * n); break;
+    case TAG_RECON_COST: b = 4.0 * (2.0 * m * n + m * KT + e->K * n); break;
+    case TAG_WNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + e->K * n); break;
+    case TAG_WDEN: b = 4.0 * (m * n + m * KT + e->K * n); break;
+    case TAG_HNUM: b = 4.0 * ((two_in ? 2.0 : 1.0) * m * n + m * KT + 2.0 * e->K * n); break;
+    case TAG_HDEN: b = 4.0 * (m * n + m * KT + 2.0 * e->K * n); break;
+    // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
+    case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
+        const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
+        if (e->fusedT || e->fusedT_kl) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
+        if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
+        *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
+    }
+    case TAG_FUSED_H: *flops = (e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
+    default: *flops = 0; *bytes = 0; return NMFX_OK;
+    }
+    *flops = f;
+    *bytes = b;
+    return NMFX_OK;
+}
+
+// ---- kernel-level entry point (tests) -------------------------------------------------------------
+nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t Kc, const float *A, const float *A2,
+                          int64_t lda, int32_t proA, const float *B, const float *B2, int64_t ldb, int32_t proB, float *C, int64_t ldc,
+                          int32_t accumulate, void *workspace, size_t workspace_bytes) {
+    DeviceGuard dg_;
+    hipPointerAttribute_t attr;
+    if (!C || hipPointerGetAttributes(&attr, C) != hipSuccess) { (void)hipGetLastError(); set_error("nmfx_gemm_f32: C is not a device pointer"); return NMFX_ERR_INVALID; }
+    TRY(check_device(attr.device));      // the device the buffers live on, not device 0
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.Kc = Kc;
+    g.A = OpView{A, A2, (long)lda, opA == NMFX_OP_N ? VIEW_RC : VIEW_KC, 0, 0, 0, proA, 0.f, 0.f};
+    g.B = OpView{B, B2, (long)ldb, opB == NMFX_OP_N ? VIEW_KC : VIEW_RC, 0, 0, 0, proB, 0.f, 0.f};
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.epi = EPI_STORE; g.splitk = 1;
+    return gemm_auto(static_cast<hipStream_t>(stream), g, workspace, workspace_bytes);
+}
+
+}  // extern "C"

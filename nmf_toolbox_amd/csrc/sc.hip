@@ -1,0 +1,776 @@
+// nmfsc (nmfsc.m:57-245) and cnmfsc (cnmfsc.m:67-277): host-driven line searches over the fused / GEMM kernels and projfunc.
+#include "api_common.h"
+
+using namespace nmfx;
+
+namespace {
+
+// 0.5*||V - V_hat||^2 from the per-block partials of an EPI_COST GEMM (host double)
+// The line searches read every objective on the host (nmfsc.m:164,215 decide on it).  The finishing kernel publishes the value into a
+// pinned, device-mapped slot followed by a sequence number, and the host thread polls that number: no hipStreamSynchronize (its wake-up
+// cost ~0.1 ms per evaluation, 8 % of a config-5 iteration) and no device-to-host copy.
+struct PinnedSlot {   // 64 bytes per host thread, kept for the life of the process (freeing it from a thread_local destructor would race the runtime's own teardown)
+    double *host = nullptr, *dev = nullptr;
+    unsigned long long seq = 0;
+    nmfx_status get() {
+        if (host) return NMFX_OK;
+        NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocMapped));
+        memset(host, 0, 64);
+        NMFX_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0));
+        return NMFX_OK;
+    }
+};
+static thread_local PinnedSlot g_obj_slot;
+nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out, Comm *comm = nullptr) {
+    TRY(g_obj_slot.get());
+    PinnedSlot &sl = g_obj_slot;
+    const unsigned long long seq = ++sl.seq;
+    if (comm && comm->active()) {
+        TRY(publish_obj(st, partials, count, 0.5, nullptr, cost_dev, nullptr, 0));
+        TRY(comm->allreduce(cost_dev, 1, NMFX_F64, NMFX_REDUCE_SUM));   // column shards: the objective is a sum over ranks
+        TRY(publish_obj(st, nullptr, 0, 1.0, cost_dev, nullptr, sl.dev, seq));
+    } else TRY(publish_obj(st, partials, count, 0.5, nullptr, cost_dev, sl.dev, seq));
+    const volatile unsigned long long *flag = reinterpret_cast<const volatile unsigned long long *>(sl.host) + 1;
+    for (unsigned long spin = 1;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spin & 0x3fff) == 0) {   // a failed launch or a fault must not spin forever
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) { NMFX_HIP(hipStreamSynchronize(st)); break; }
+            if (q != hipErrorNotReady) { set_error("objective read-back: %s", hipGetErrorString(q)); return NMFX_ERR_HIP; }
+        }
+    }
+    *out = *reinterpret_cast<const volatile double *>(sl.host);
+    return NMFX_OK;
+}
+
+// nmfsc launch groups (bench.py --workload c5)
+enum ScTag { SC_OBJ = 0, SC_PROJ = 1, SC_HTERMS = 2, SC_WTERMS = 3, SC_SMALL = 4, SC_COUNT = 5 };
+static const char *const kScTagNames[SC_COUNT] = {"fused:objective pass (S=W*H -> 0.5||V-S||^2)", "projfunc (Hoyer projection of the rows of H)",
+                                                  "H-step terms (sparse H: fused residual pass dH = W'*(W*H-V) + objective; MU: W'*V, (W'*W)*H)", "W-step terms (MU: V*H', W*(H*H'); sparse W: fused residual pass)", "small kernels (transposes, updates)"};
+static thread_local Profiler g_sc_prof;
+
+// device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
+struct ScDev {
+    const float *V;      // m x n_local, already divided by the GLOBAL max (nmfsc.m:62)
+    float *W, *H;        // in/out
+    long n_total;        // global column count (L1s, nmfsc.m:102-106, is defined on whole rows of H)
+    Comm comm;
+    hipStream_t st;
+};
+
+// nmfsc.m:57-245
+nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullptr) {
+    if (!dev) TRY(validate_problem(p, r, true));
+    if (p->T != 1) { set_error("nmfsc: T must be 1"); return NMFX_ERR_INVALID; }
+    const long m = p->m, n = p->n;
+    // any K <= 256 runs on the fused kernels: K is rounded up to a multiple of 32 with zero columns of W / zero rows of H.  They add exact
+    // zeros to W*H, to every gradient and to every Gram product, stay zero under both update rules, and are kept away from the only two
+    // places that would resurrect them: projfunc (a zero vector does NOT project to zero) and the row-norm rescale of nmfsc.m:185-187 (0/0)
+    const int Kv = p->K_total;
+    const bool padK = p->path != 1 && Kv % 32 != 0 && Kv <= 256 && ((m >= 64 && n >= 64) || p->path == 2);
+    const int K = padK ? (Kv + 31) / 32 * 32 : Kv;
+    const size_t mn = (size_t)m * n, mK = (size_t)m * K, Kn = (size_t)K * n, mKv = (size_t)m * Kv, Kvn = (size_t)Kv * n;
+    Comm nocomm{};
+    Comm &comm = dev ? dev->comm : nocomm;
+    double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62
+    if (dev) { vmin = 0; vmax = 1; }
+    else if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    DeviceGuard dg_;
+    TRY(check_device(p->device));
+    hipStream_t st = dev ? dev->st : nullptr;
+    g_sc_prof.st = st;
+    if (g_sc_prof.on) { g_sc_prof.events.clear(); g_sc_prof.pool_used = 0; }
+    Profiler *pf = &g_sc_prof;
+    const long n_total = dev ? dev->n_total : n;
+    double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity;
+    double L1a = 0, L1s = 0;
+    if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // nmfsc.m:89-93
+    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n_total) - (std::sqrt((double)n_total) - 1) * sH; }   // nmfsc.m:102-106
+    const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
+
+    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch, pfv, pff, pfr;
+    const bool fast = p->path != 1 && fused_supported(K) && ((m >= 64 && n >= 64) || p->path == 2);   // ragged m / n: masked-edge kernels
+    if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
+    if (comm.active() && !fast) {
+        set_error("nmfsc on column shards runs on the fused kernels only: K <= 256, m and n_local >= 64");
+        return NMFX_ERR_UNSUPPORTED;
+    }
+    if (!dev) TRY(V.alloc(mn * 4));
+    if (!fast) TRY(Vh.alloc(mn * 4));
+    if (comm.active() && sH > 0) { TRY(pfv.alloc(Kn * 8)); TRY(pff.alloc(Kn)); TRY(pfr.alloc(sizeof(double) * 6 * K + 64)); }
+    TRY(W.alloc(mK * 4)); TRY(Wn.alloc(mK * 4)); TRY(Hk.alloc(Kn * 4)); TRY(HT.alloc(Kn * 4));
+    TRY(HnT.alloc(Kn * 4));
+    const size_t gmax = (Kn > mK ? Kn : mK) + (size_t)K * K;   // + K*K: [V*H' | H*H'] travel as ONE all-reduce on column shards
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));
+    TRY(stage.alloc(STAGE_ELEMS * 8));
+    const int nparts = (int)gemm_grid_blocks(m, n);
+    TRY(part.alloc(sizeof(double) * nparts)); TRY(costd.alloc(64 + sizeof(double) * K));
+    size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n), sb3 = gemm_scratch_bytes(K, n, m);
+    if (sb2 > sb) sb = sb2;
+    if (sb3 > sb) sb = sb3;
+    TRY(scratch.alloc(sb));
+    DevBuf hpk;   // Kv x n staging of the un-padded, row-interleaved H
+    if (padK) {
+        TRY(hpk.alloc(Kvn * 4));
+        NMFX_HIP(hipMemsetAsync(W.p, 0, mK * 4, st)); NMFX_HIP(hipMemsetAsync(Wn.p, 0, mK * 4, st));
+        NMFX_HIP(hipMemsetAsync(HT.p, 0, Kn * 4, st)); NMFX_HIP(hipMemsetAsync(HnT.p, 0, Kn * 4, st));   // the padding of every buffer that is only ever
+    }                                                                                                 // written through projfunc stays zero
+    if (!dev) {
+        TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
+        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKv, 1.0, stage, STAGE_ELEMS));   // the first Kv columns of the m x K array
+        if (padK) {
+            TRY(upload(st, p->H_init, p->dtype, hpk.as<float>(), Kvn, 1.0, stage, STAGE_ELEMS));
+            TRY(repack_rows(st, hpk.as<float>(), Kv, Hk.as<float>(), K, n));
+        } else TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    } else {
+        NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mKv * 4, hipMemcpyDeviceToDevice, st));
+        if (padK) TRY(repack_rows(st, dev->H, Kv, Hk.as<float>(), K, n));
+        else NMFX_HIP(hipMemcpyAsync(Hk.p, dev->H, Kn * 4, hipMemcpyDeviceToDevice, st));
+    }
+    const float *Vp = dev ? dev->V : V.as<float>();
+    float *Wd = W.as<float>(), *Wnew = Wn.as<float>(), *HTd = HT.as<float>(), *HnewT = HnT.as<float>();
+    // rows of H (stored as the columns of an n_local x K transposed copy) through projfunc; on column shards every reduction of
+    // projfunc.m:22-53 is a sum over ranks
+    auto project_H = [&](float *HxT) -> nmfx_status {
+        if (comm.active()) return projfunc_cols_dist(st, HxT, n, Kv, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>());
+        return projfunc_cols(st, HxT, n, Kv, L1s, 1.0, 1, nullptr);
+    };
+    // out = projection of (base + mu*dir), rows of H as the columns of the n x K transposed copies   (nmfsc.m:154-157)
+    // (dir64: the direction as doubles, small K; the step is formed in fp64 while loading)
+    auto step_project_H = [&](const float *baseT, const float *dirT, const double *dir64, double mu, float *outT) -> nmfx_status {
+        if (comm.active())
+            return projfunc_cols_dist(st, outT, n, Kv, n_total, L1s, 1.0, 1, comm, pfv.as<double>(), pff.as<unsigned char>(), pfr.as<double>(), dirT, mu, baseT, dir64);
+        PScope ps(pf, SC_PROJ);
+        return projfunc_cols(st, outT, n, Kv, L1s, 1.0, 1, nullptr, dirT, mu, baseT, dir64);
+    };
+    TRY(transpose_f32(st, Hk.as<float>(), K, n, HTd));
+    const bool resume = dev && p->sc_resume;   // W / H are the state a previous call left: already projected, nothing to initialise
+    if (sW > 0 && !resume) TRY(projfunc_cols(st, Wd, m, Kv, L1a, 1.0, 1, nullptr));     // nmfsc.m:94-96  (W is replicated: every rank projects the same columns)
+    if (sH > 0 && !resume) TRY(project_H(HTd));                                        // nmfsc.m:107-109
+
+    // V_hat = Wx * Hx (Hx given transposed, n x K) with the residual objective; returns 0.5*||V - V_hat||^2
+    auto recon_obj = [&](const float *Wx, const float *HxT, double *obj) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = m; g.N = n; g.Kc = K;
+        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{HxT, nullptr, n, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = Vh.as<float>(); g.ldc = m; g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = Vp; g.ldv = m;
+        g.cost_partials = part.as<double>(); g.splitk = 1;
+        long blocks = 0;
+        TRY(launch_gemm(st, g, &blocks));
+        return read_obj(st, part.as<double>(), (int)blocks, costd.as<double>(), obj);
+    };
+    // outT (n x K) = f(V, V_hat)' * W
+    auto xt_w = [&](const float *x, const float *x2, int func, float *outT) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = n; g.N = K; g.Kc = m;
+        g.A = OpView{x, x2, m, VIEW_KC, 0, 0, 0, func, 0.f, 0.f};
+        g.B = OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = outT; g.ldc = n; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+    // out (m x K) = f(V, V_hat) * H'
+    auto x_ht = [&](const float *x, const float *x2, int func, float *out) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = m; g.N = K; g.Kc = n;
+        g.A = OpView{x, x2, m, VIEW_RC, 0, 0, 0, func, 0.f, 0.f};
+        g.B = OpView{HTd, nullptr, n, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = out; g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+
+    // ---- fast path: the same algorithm on the fused kernels (V_hat never materialised) -----------------------------------
+    //   objective         0.5*||V - W*H||^2          fused cost-only pass (S = W*H in registers)
+    //   W'*V, V*H'        fused H-step / W-step passes with R = V
+    //   W'*V_hat, V_hat*H' (W'*W)*H and W*(H*H')     K x K Gram products
+    DevBuf WTb, slabs, Gb, Denb, KKb, fparts, g64h, g64w, s64;
+    const bool smallk = fast && Kv <= smallk_max();   // a handful of components: gradients + objective in fp64 (aux.hip::smallk_grad), handed to projfunc as doubles
+    // ... and small problems with any K (m*n*K <= 2^27 fp64 FMAs per evaluation), unless the fused kernels are asked for by name (path 2):
+    // R64 = W*H - V as doubles, both contractions on it in fp64 (aux.hip::resid64 / r64_wt / r64_ht).  What this buys is parity -- the Hoyer
+    // projection amplifies the accumulation noise of an fp32 MFMA contraction 10-100x on short vectors
+    const bool small64 = fast && !smallk && p->path != 2 && (double)m * (double)n_total * (double)Kv <= (double)(1 << 27);   // n_total: every rank of a sharded run must take the same path (the all-reduced buffers differ)
+    const bool use64 = smallk || small64;
+    const int nch_w64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((m + 255) / 256) * Kv)), (n + 63) / 64) : 1;
+    DevBuf r64b;
+    int nsplit_w = 1, isplit_h = 1;
+    long cps_w = n, cps_h = m;
+    if (fast) {
+        nsplit_w = fused_split((m + 127) / 128, n, K, &cps_w);
+        isplit_h = fused_split((n + 127) / 128, m, K, &cps_h);
+        TRY(WTb.alloc(mK * 4)); TRY(slabs.alloc(std::max((size_t)nsplit_w * mK, (size_t)isplit_h * Kn) * 4)); TRY(Gb.alloc(Kn * 4)); TRY(Denb.alloc(Kn * 4));
+        TRY(KKb.alloc((size_t)K * K * 4)); TRY(fparts.alloc(sizeof(double) * std::max<long>(std::max(((m + 127) / 128) * nsplit_w, ((n + 127) / 128) * isplit_h), smallk ? smallk_partials(m, n) : (small64 ? resid64_blocks(m, n) : 0))));
+        if (use64) { TRY(g64h.alloc(sizeof(double) * n * Kv)); TRY(g64w.alloc(sizeof(double) * m * Kv)); TRY(s64.alloc(sizeof(double) * (size_t)(smallk ? smallk_dw_chunks(m, n) : nch_w64) * m * Kv)); }
+        if (small64) TRY(r64b.alloc(sizeof(double) * mn));
+    }
+    // 0.5*||V - Wx*Hx||^2 with Hx given as K x n (column-major)
+    auto fast_obj = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        if (use64) {
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_OBJ);
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, nullptr, nullptr, fparts.as<double>(), &np_));
+                else TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, nullptr, fparts.as<double>(), &np_));
+            }
+            return read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm);
+        }
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
+        f.cost_partials = fparts.as<double>();
+        {
+            PScope ps(pf, SC_OBJ);
+            TRY(launch_fused(st, f, nsplit_w, true, 1, false, 0));
+        }
+        return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
+    };
+    // The gradients of the line-search branches in RESIDUAL form, one fused pass each (func 6: S = W*H in registers -> R = S - V -> second
+    // contraction): dH = W'*(W*H - V) (nmfsc.m:144-148) and dW = (W*H - V)*H' (nmfsc.m:194-200).  The Gram form pos - neg = (W'W)H - W'V
+    // subtracts two products rounded separately, and their difference goes to zero as the fit converges while they do not: it cost parity
+    // on small K (scripts/fuzz_campaign_sc.py: H off by 1.3e-5 at K = 3).  The same pass yields 0.5*||V - W*H||^2 of the point it is taken at.
+    // Den (K x n) = Wx' * (Wx*Hx - V); *obj = the objective at (Wx, Hx) when asked for
+    auto resid_h = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        if (use64) {   // g64h = dH' (n x Kv doubles)
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_HTERMS);
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, g64h.as<double>(), nullptr, nullptr, fparts.as<double>(), &np_));
+                else {
+                    TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, r64b.as<double>(), fparts.as<double>(), &np_));
+                    TRY(r64_wt(st, r64b.as<double>(), m, n, Wx, Kv, g64h.as<double>()));
+                }
+            }
+            return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
+        }
+        {
+            PScope ps(pf, SC_HTERMS);
+            TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = cps_h;
+            f.out = isplit_h == 1 ? Denb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
+            f.cost_partials = fparts.as<double>();
+            TRY(launch_fused(st, f, isplit_h, false, 6, true, 0));
+            if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Denb.as<float>(), 0));
+        }
+        if (!obj) return NMFX_OK;
+        return read_obj(st, fparts.as<double>(), (int)(((n + 127) / 128) * isplit_h), costd.as<double>(), obj, &comm);
+    };
+    // dW_ (m x K) = (Wx*Hx - V) * Hx', summed over the column shards; *obj as above
+    // (reduce = false: the sum over the column shards is left to the caller -- a speculative evaluation inside the H line search, see below)
+    auto resid_w = [&](const float *Wx, const float *Hx, float *dW_, double *obj, bool reduce = true) -> nmfx_status {
+        if (use64) {   // g64w = dW (m x Kv doubles)
+            int np_ = 0;
+            {
+                PScope ps(pf, SC_WTERMS);
+                if (smallk) TRY(smallk_grad(st, Kv, Vp, m, n, Wx, Hx, K, nullptr, g64w.as<double>(), s64.as<double>(), fparts.as<double>(), &np_));
+                else {
+                    TRY(resid64(st, Vp, m, n, Wx, Hx, Kv, K, r64b.as<double>(), fparts.as<double>(), &np_));
+                    TRY(r64_ht(st, r64b.as<double>(), m, n, Hx, Kv, K, s64.as<double>(), nch_w64, g64w.as<double>()));
+                }
+                if (comm.active() && reduce) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+            }
+            return obj ? read_obj(st, fparts.as<double>(), np_, costd.as<double>(), obj, &comm) : NMFX_OK;
+        }
+        {
+            PScope ps(pf, SC_WTERMS);
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
+            f.out = nsplit_w == 1 ? dW_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
+            f.cost_partials = fparts.as<double>();
+            TRY(launch_fused(st, f, nsplit_w, true, 6, true, 0));
+            if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, dW_, 0));
+            if (comm.active() && reduce) TRY(comm.allreduce(dW_, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
+        }
+        if (!obj) return NMFX_OK;
+        return read_obj(st, fparts.as<double>(), (int)(((m + 127) / 128) * nsplit_w), costd.as<double>(), obj, &comm);
+    };
+    auto kk_gemm = [&](long M_, long N_, long Kc_, OpView A_, OpView B_, float *C_, long ldc_) -> nmfx_status {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.M = M_; g.N = N_; g.Kc = Kc_; g.A = A_; g.B = B_; g.C = C_; g.ldc = ldc_; g.epi = EPI_STORE; g.splitk = 1;
+        return gemm_auto(st, g, scratch.p, sb);
+    };
+    // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
+    auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
+        PScope ps(pf, SC_HTERMS);
+        static const bool sc_fused_env = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
+        const bool sc_fused_terms = sc_fused_env || K % 64 != 0;   // the GEMM is only pipelined for tile-aligned outputs
+        if (sc_fused_terms) {
+        TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Hx; f.xs_r = K; f.xs_k = 1; f.Y = WTb.as<float>(); f.D = Vp; f.ldd = m; f.R = n; f.Cn = m; f.K = K; f.c_per_split = cps_h;
+        f.out = isplit_h == 1 ? Gb.as<float>() : slabs.as<float>(); f.slab_stride = (long)K * n; f.os_r = K; f.os_k = 1;
+        TRY(launch_fused(st, f, isplit_h, false, 0, true, 0));
+        if (isplit_h > 1) TRY(reduce_slabs(st, slabs.as<float>(), isplit_h, f.slab_stride, f.slab_stride, Gb.as<float>(), 0));
+        } else
+        // W'*V has no first product: the pipelined GEMM beats the register-stationary kernel on a plain contraction
+        TRY(kk_gemm(K, n, m, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Vp, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                    Gb.as<float>(), K));
+        TRY(kk_gemm(K, K, m, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+        return kk_gemm(K, n, K, OpView{KKb.as<float>(), nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{Hx, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, Denb.as<float>(), K);
+    };
+    // N (m x K) = V * Hx' and P (m x K) = Wx * (Hx*Hx'); N_ has room for K*K more floats: [N | Hx*Hx'] is what column shards sum
+    auto fast_w_terms = [&](const float *Wx, const float *Hx, float *N_, float *P_) -> nmfx_status {
+        PScope ps(pf, SC_WTERMS);
+        float *KK = N_ + mK;
+        // V*H' (N = K wide): the register-stationary kernel (R = V, two workgroups per CU at K <= 128) beats the split-K GEMM here
+        static const bool sc_fused_terms = getenv("NMFX_SC_GEMM_WTERMS") == nullptr;   // dev switch: A/B
+        if (sc_fused_terms) {
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
+        f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
+        TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
+        if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));
+        } else
+        TRY(kk_gemm(m, K, n, OpView{Vp, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                    N_, m));
+        TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KK, K));
+        if (comm.active()) TRY(comm.allreduce(N_, (long)(mK + (size_t)K * K), NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
+        return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
+                       OpView{KK, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
+    };
+    double stepH = p->sc_stepsize_H0 > 0 ? p->sc_stepsize_H0 : 1.0, stepW = p->sc_stepsize_W0 > 0 ? p->sc_stepsize_W0 : 1.0;   // nmfsc.m:133-134
+    if (fast) {
+        DevBuf Hcb;
+        TRY(Hcb.alloc(Kn * 4));
+        float *Hcur = Hk.as<float>(), *Hcand = Hcb.as<float>();
+        double *nrm2 = costd.as<double>() + 8;
+        TRY(transpose_f32(st, HTd, n, K, Hcur));
+        // the objective of (W, H) and the gradient dH the next sparse-H line search starts from come out of the same pass
+        const bool lsH = !fixH && sH > 0;
+        // With BOTH line searches active every objective evaluation is made by the residual pass of the OTHER factor: the try that is
+        // accepted (4 of 5 are) has then already produced the gradient the next line search starts from, and a 4*mnK pass per search is gone.
+        static const bool no_spec = getenv("NMFX_SC_NO_SPEC") != nullptr;   // dev switch (A/B runs)
+        const bool spec = lsH && !fixW && sW > 0 && !no_spec;
+        bool have_dW = false;   // G2 (g64w) = dW of the current (Wd, Hcur), not yet summed over the shards
+        bool have_dH = false;   // Denb = dH of the current (Wd, Hcur)
+        if (lsH && p->maxiter >= 1) { TRY(resid_h(Wd, Hcur, &r->cost[0])); have_dH = true; }
+        else TRY(fast_obj(Wd, Hcur, &r->cost[0]));                                              // nmfsc.m:138-139
+        int ncost = p->maxiter + 1, nH = 0, nW = 0;
+        bool early = false;
+        for (int it = 1; it <= p->maxiter && !early; ++it) {
+            double cur_obj = r->cost[it - 1];
+            if (!fixH) {
+                if (sH > 0) {
+                    if (!have_dH) TRY(resid_h(Wd, Hcur, nullptr));                              // dH = W'*V_hat - W'*V   nmfsc.m:144-148
+                    have_dH = false;
+                    if (!use64) {
+                        PScope ps(pf, SC_SMALL);
+                        TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));         // dH' (n x K): rows of H are contiguous there
+                    }
+                    const double begobj = cur_obj;                                              // nmfsc.m:149
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        TRY(step_project_H(HTd, use64 ? nullptr : G1.as<float>(), use64 ? g64h.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
+                        {
+                            PScope ps(pf, SC_SMALL);
+                            TRY(transpose_f32(st, HnewT, n, K, Hcand));
+                        }
+                        if (spec) TRY(resid_w(Wd, Hcand, G2.as<float>(), &newobj, false));          // nmfsc.m:160-161 (+ dW at the candidate)
+                        else TRY(fast_obj(Wd, Hcand, &newobj));
+                        if (newobj <= begobj) break;                                                // nmfsc.m:164
+                        stepH /= 2;                                                                 // nmfsc.m:169
+                        if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
+                    }
+                    if (r->tries_H) r->tries_H[nH] = tries;
+                    ++nH;
+                    if (early) { ncost = it; break; }
+                    stepH *= 1.2;                                                                   // nmfsc.m:178
+                    std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
+                    cur_obj = newobj;
+                    have_dW = spec;
+                } else {
+                    TRY(fast_h_terms(Wd, Hcur));                                                    // W'*V, W'*V_hat        nmfsc.m:144-145
+                    TRY(mu_plain(st, Hcur, Gb.as<float>(), Denb.as<float>(), (long)Kn));            // nmfsc.m:182
+                    TRY(transpose_f32(st, Hcur, K, n, HTd));
+                    TRY(col_reduce(st, HTd, n, n, Kv, 1, nrm2));                                    // nmfsc.m:185
+                    if (comm.active()) TRY(comm.allreduce(nrm2, Kv, NMFX_F64, NMFX_REDUCE_SUM));    // row norms of H span the shards
+                    TRY(scale_cols(st, HTd, n, Kv, nrm2, 1, 1));                                    // nmfsc.m:186
+                    TRY(scale_cols(st, Wd, m, Kv, nrm2, 1, 0));                                     // nmfsc.m:187
+                    TRY(transpose_f32(st, HTd, n, K, Hcur));
+                    cur_obj = NAN;
+                }
+            }
+            if (!fixW) {
+                if (sW > 0) {
+                    if (!have_dW) TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
+                    else if (comm.active()) {
+                        if (use64) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
+                        else TRY(comm.allreduce(G2.p, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));
+                    }
+                    have_dW = false;
+                    const bool spec_h = spec && it < p->maxiter;
+                    const double begobj = cur_obj;
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        {
+                            PScope ps(pf, SC_PROJ);
+                            TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, use64 ? nullptr : G2.as<float>(), -stepW, Wd, use64 ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
+                        }
+                        if (spec_h) TRY(resid_h(Wnew, Hcur, &newobj));                              // nmfsc.m:211-212 (+ dH at the candidate)
+                        else TRY(fast_obj(Wnew, Hcur, &newobj));
+                        if (newobj <= begobj) break;                                                // nmfsc.m:215
+                        stepW /= 2;
+                        if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
+                    }
+                    if (r->tries_W) r->tries_W[nW] = tries;
+                    ++nW;
+                    if (early) { ncost = it; break; }
+                    stepW *= 1.2;                                                                   // nmfsc.m:228
+                    std::swap(Wd, Wnew);                                                            // nmfsc.m:229
+                    cur_obj = newobj;
+                    have_dH = spec_h;
+                } else {
+                    TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                    // V*H', V_hat*H'       nmfsc.m:194-195
+                    PScope ps(pf, SC_SMALL);
+                    TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
+                    cur_obj = NAN;
+                }
+            }
+            if (cur_obj == cur_obj) r->cost[it] = cur_obj;                                          // same (W, H) as the accepted objective
+            else if (lsH && it < p->maxiter) { TRY(resid_h(Wd, Hcur, &r->cost[it])); have_dH = true; }   // + the next iteration's dH
+            else TRY(fast_obj(Wd, Hcur, &r->cost[it]));                                             // nmfsc.m:237-238
+            if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
+                ncost = it + 1;
+                break;
+            }
+        }
+        r->cost_len = ncost;
+        r->iters_run = ncost - 1;
+        r->stepsize_H = stepH; r->stepsize_W = stepW;
+        r->converged_early = early ? 1 : 0;
+        if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+        if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+        if (dev) {
+            NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mKv * 4, hipMemcpyDeviceToDevice, st));
+            if (padK) TRY(repack_rows(st, Hcur, K, dev->H, Kv, n));
+            else NMFX_HIP(hipMemcpyAsync(dev->H, Hcur, Kn * 4, hipMemcpyDeviceToDevice, st));
+            NMFX_HIP(hipStreamSynchronize(st));
+            return NMFX_OK;
+        }
+        TRY(download(st, Wd, p->dtype, r->W, mKv, stage, STAGE_ELEMS));
+        if (padK) {
+            TRY(repack_rows(st, Hcur, K, hpk.as<float>(), Kv, n));
+            TRY(download(st, hpk.as<float>(), p->dtype, r->H, Kvn, stage, STAGE_ELEMS));
+        } else TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+        return NMFX_OK;
+    }
+    TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
+    int ncost = p->maxiter + 1, nH = 0, nW = 0;
+    bool early = false;
+    r->converged_early = 0;
+    for (int it = 1; it <= p->maxiter && !early; ++it) {
+        if (!fixH) {
+            if (sH > 0) {
+                TRY(xt_w(Vp, Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));   // dH' = (V_hat - V)' * W   nmfsc.m:144-148
+                const double begobj = r->cost[it - 1];                                      // nmfsc.m:149
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    TRY(projfunc_cols(st, HnewT, n, Kv, L1s, 1.0, 1, nullptr, G1.as<float>(), -stepH, HTd));   // nmfsc.m:154-157 (step formed in fp64 while loading)
+                    double newobj;
+                    TRY(recon_obj(Wd, HnewT, &newobj));                                         // nmfsc.m:160-161
+                    if (newobj <= begobj) break;                                                // nmfsc.m:164
+                    stepH /= 2;                                                                 // nmfsc.m:169
+                    if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
+                }
+                if (r->tries_H) r->tries_H[nH] = tries;
+                ++nH;
+                if (early) { ncost = it; break; }
+                stepH *= 1.2;                                                                   // nmfsc.m:178
+                std::swap(HTd, HnewT);                                                          // nmfsc.m:179
+            } else {
+                TRY(xt_w(Vp, nullptr, NMFX_PRO_NONE, G1.as<float>()));               // (W'*V)'       nmfsc.m:144
+                TRY(xt_w(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // (W'*V_hat)'   nmfsc.m:145
+                TRY(mu_plain(st, HTd, G1.as<float>(), G2.as<float>(), (long)Kn));               // nmfsc.m:182
+                double *nrm2 = costd.as<double>() + 8;
+                TRY(col_reduce(st, HTd, n, n, K, 1, nrm2));                                     // nmfsc.m:185
+                TRY(scale_cols(st, HTd, n, K, nrm2, 1, 1));                                     // nmfsc.m:186
+                TRY(scale_cols(st, Wd, m, K, nrm2, 1, 0));                                      // nmfsc.m:187
+            }
+        }
+        if (!fixW) {
+            double begobj;
+            TRY(recon_obj(Wd, HTd, &begobj));                                                   // nmfsc.m:193,197
+            if (sW > 0) {
+                TRY(x_ht(Vp, Vh.as<float>(), NMFX_PRO_DIFF, G1.as<float>()));        // dW = (V_hat - V) * H'   nmfsc.m:194-200
+                int tries = 0;
+                for (;;) {
+                    ++tries;
+                    TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, G1.as<float>(), -stepW, Wd));   // nmfsc.m:205-208
+                    double newobj;
+                    TRY(recon_obj(Wnew, HTd, &newobj));                                         // nmfsc.m:211-212
+                    if (newobj <= begobj) break;                                                // nmfsc.m:215
+                    stepW /= 2;
+                    if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
+                }
+                if (r->tries_W) r->tries_W[nW] = tries;
+                ++nW;
+                if (early) { ncost = it; break; }
+                stepW *= 1.2;                                                                   // nmfsc.m:228
+                std::swap(Wd, Wnew);                                                            // nmfsc.m:229
+            } else {
+                TRY(x_ht(Vp, nullptr, NMFX_PRO_NONE, G1.as<float>()));               // nmfsc.m:194
+                TRY(x_ht(Vh.as<float>(), nullptr, NMFX_PRO_NONE, G2.as<float>()));              // nmfsc.m:195
+                TRY(mu_plain(st, Wd, G1.as<float>(), G2.as<float>(), (long)mK));                // nmfsc.m:232
+            }
+        }
+        TRY(recon_obj(Wd, HTd, &r->cost[it]));                                                  // nmfsc.m:237-238
+        if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
+            ncost = it + 1;
+            break;
+        }
+    }
+    r->cost_len = ncost;
+    r->iters_run = ncost - 1;
+    r->stepsize_H = stepH; r->stepsize_W = stepW;
+    r->converged_early = early ? 1 : 0;
+    if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+    if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+    TRY(transpose_f32(st, HTd, n, K, Hk.as<float>()));
+    if (dev) {
+        NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mK * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipMemcpyAsync(dev->H, Hk.p, Kn * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipStreamSynchronize(st));
+        return NMFX_OK;
+    }
+    TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
+    TRY(download(st, Hk.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    return NMFX_OK;
+}
+
+// cnmfsc.m:67-277 on the generic GEMM (materialised V_hat: its W branch updates V_hat incrementally, cnmfsc.m:262).
+// The reference's quirks are mirrored, see oracle/nmf_oracle.py::cnmfsc.
+nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
+    TRY(validate_problem(p, r, true));
+    const long m = p->m, n = p->n;
+    const int K = p->K_total, T = p->T, KT = K * T;
+    if (n < T) { set_error("cnmfsc: context_len exceeds the number of columns"); return NMFX_ERR_INVALID; }
+    const size_t mn = (size_t)m * n, mK = (size_t)m * K, mKT = (size_t)m * KT, Kn = (size_t)K * n;
+    double vmin = INFINITY, vmax = -INFINITY;   // cnmfsc.m:67-72
+    if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
+    DeviceGuard dg_;
+    TRY(check_device(p->device));
+    hipStream_t st = nullptr;
+    double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity, L1a = 0, L1s = 0;
+    if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // cnmfsc.m:100-104
+    if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
+    const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
+
+    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, stage, part, costd, scratch, rrs, g64, s64;
+    // sparse-W gradients in fp64 where that is cheap (aux.hip::resid_xht64): m*n*K fp64 FMAs per slice
+    const bool small64 = p->sc_W_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
+    const int nch64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((p->m + 255) / 256) * p->K_total)), (p->n + 63) / 64) : 1;
+    if (small64) { TRY(g64.alloc(sizeof(double) * (size_t)p->m * p->K_total)); TRY(s64.alloc(sizeof(double) * (size_t)nch64 * p->m * p->K_total)); }
+    DevBuf g64h;   // the same for the sparse-H gradient (aux.hip::resid_hgrad64): m*n*K*T fp64 FMAs
+    const bool small64h = p->sc_H_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total * (double)p->T <= (double)(1 << 27);
+    if (small64h) TRY(g64h.alloc(sizeof(double) * (size_t)p->n * p->K_total));
+    TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
+    TRY(HnT.alloc((size_t)p->K_total * p->n * 4));
+    TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
+    TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
+    const size_t gmax = std::max(Kn, mKT);
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
+    TRY(part.alloc(sizeof(double) * gemm_grid_blocks(m, n))); TRY(costd.alloc(64 + sizeof(double) * K));
+    size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
+    TRY(scratch.alloc(sb));
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));
+    TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->H_init, p->dtype, Hb.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    float *W0 = W0b.as<float>(), *W = Wb.as<float>(), *Wnew = Wnb.as<float>(), *H = Hb.as<float>(), *Hnew = Hnb.as<float>(), *HT = HTb.as<float>();
+    NMFX_HIP(hipMemcpyAsync(W, W0, mKT * 4, hipMemcpyDeviceToDevice, st));                     // W = W0   cnmfsc.m:94
+    if (sW > 0) TRY(projfunc_cols(st, W, m, KT, L1a, 1.0, 1, nullptr));                          // cnmfsc.m:105-109 (W only, not W0)
+    auto project_rows = [&](float *Hx) -> nmfx_status {   // rows of H (K x n) through the transposed copy
+        TRY(transpose_f32(st, Hx, K, n, HT));
+        TRY(projfunc_cols(st, HT, n, K, L1s, 1.0, 1, nullptr));
+        return transpose_f32(st, HT, n, K, Hx);
+    };
+    if (sH > 0) TRY(project_rows(H));                                                            // cnmfsc.m:121-123
+    auto gemm = [&](GemmParams &g, double *obj) -> nmfx_status {
+        g.splitk = 1;
+        if (!obj) { g.epi = EPI_STORE; return gemm_auto(st, g, scratch.p, sb); }
+        g.epi = EPI_COST; g.store_c = 1; g.cost_div = NMFX_DIV_EUCLIDEAN; g.Vref = V.as<float>(); g.ldv = m; g.cost_partials = part.as<double>();
+        long blocks = 0;
+        TRY(launch_gemm(st, g, &blocks));
+        return read_obj(st, part.as<double>(), (int)blocks, costd.as<double>(), obj);
+    };
+    // V_hat = RFD(Wx (m x K x T), Hx) and 0.5*||V - V_hat||^2
+    auto rfd = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = m; g.N = n; g.Kc = KT;
+        g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{Hx, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = Vh.as<float>(); g.ldc = m;
+        return gemm(g, obj);
+    };
+    // out (K x n) = sum_t Wx_t' * lshift_t(X)
+    // (X2 given: X is replaced by X2 - X element-wise while it is loaded -- the gradient in residual form, see run_nmfsc)
+    auto hgrad = [&](const float *Wx, const float *X, float *out, const float *X2 = nullptr) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = K; g.N = n; g.Kc = (long)T * m;
+        g.A = OpView{Wx, nullptr, m, VIEW_WSTACK_KC, (int)m, m * (long)K, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{X, X2, m, VIEW_XSHIFT_KC, (int)m, 0, (int)n, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = out; g.ldc = K;
+        return gemm(g, nullptr);
+    };
+    // out (m x K) = X * rshift_t(H)'
+    auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
+        GemmParams g; memset(&g, 0, sizeof(g));
+        g.M = m; g.N = K; g.Kc = n;
+        g.A = OpView{X, X2, m, VIEW_RC, 0, 0, 0, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
+        g.B = OpView{Hx, nullptr, (long)K, VIEW_HSTACK_RC, K, 0, t * K, NMFX_PRO_NONE, 0.f, 0.f};
+        g.C = out; g.ldc = m;
+        return gemm(g, nullptr);
+    };
+
+    double stepH = 1.0;
+    std::vector<double> stepW(T, 1.0);                                                           // cnmfsc.m:147-148
+    TRY(rfd(W, H, &r->cost[0]));                                                                 // cnmfsc.m:152-153
+    int ncost = p->maxiter + 1, nH = 0, nW = 0;
+    bool early = false;
+    double *nrm2 = costd.as<double>() + 8;
+    for (int it = 1; it <= p->maxiter && !early; ++it) {
+        if (!fixH) {
+            if (sH > 0) {
+                const double begobj = r->cost[it - 1];
+                int tries = 0;
+                TRY(transpose_f32(st, H, K, n, HT));                                                 // rows of H / dH contiguous: the projected vectors
+                if (small64h) TRY(resid_hgrad64(st, V.as<float>(), Vh.as<float>(), m, n, W0, K, T, g64h.as<double>()));   // dH' in fp64 (small problems)
+                else {
+                    TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));              // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
+                    TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
+                }
+                for (;;) {
+                    ++tries;
+                    TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, small64h ? nullptr : G1.as<float>(), -stepH, HT, small64h ? g64h.as<double>() : nullptr));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
+                    TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
+                    double newobj;
+                    TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181
+                    if (newobj <= begobj) break;
+                    stepH /= 2;
+                    if (stepH < 1e-200) { early = true; break; }                                     // cnmfsc.m:190-194
+                }
+                if (r->tries_H) r->tries_H[nH] = tries;
+                ++nH;
+                if (early) { ncost = it; break; }
+                stepH *= 1.2;
+                std::swap(H, Hnew);
+            } else {
+                TRY(hgrad(W0, V.as<float>(), G1.as<float>()));                                   // cnmfsc.m:160-165
+                TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));
+                TRY(mu_plus_eps(st, H, G1.as<float>(), G2.as<float>(), (long)Kn));                   // H .* (neg ./ (pos + eps))   cnmfsc.m:202
+                TRY(row_reduce(st, H, K, K, n, 1, nrm2, rrs.p));                                     // cnmfsc.m:205
+                TRY(transpose_f32(st, H, K, n, HT));
+                TRY(scale_cols(st, HT, n, K, nrm2, 1, 1));                                           // cnmfsc.m:206
+                TRY(transpose_f32(st, HT, n, K, H));
+                for (int t = 0; t < T; ++t) TRY(scale_cols(st, W0 + (size_t)t * mK, m, K, nrm2, 1, 0));   // cnmfsc.m:207-209
+            }
+        }
+        if (!fixW) {
+            double begobj;
+            TRY(rfd(W0, H, &begobj));                                                            // cnmfsc.m:215
+            for (int t = 0; t < T && !early; ++t) {
+                float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
+                if (sW > 0) {
+                    if (small64) TRY(resid_xht64(st, V.as<float>(), Vh.as<float>(), m, n, H, K, t, s64.as<double>(), nch64, g64.as<double>()));   // dW in fp64 (small problems)
+                    else TRY(xht(V.as<float>(), H, t, G2.as<float>(), Vh.as<float>()));          // dW = pos - neg = (V_hat - V) * Hs'   cnmfsc.m:221-224
+                    int tries = 0;
+                    double newobj = 0;
+                    for (;;) {
+                        ++tries;
+                        TRY(projfunc_cols(st, Wnew, m, K, L1a, 1.0, 1, nullptr, small64 ? nullptr : G2.as<float>(), -stepW[t], W0t, small64 ? g64.as<double>() : nullptr));   // cnmfsc.m:229-233 (step formed in fp64 while loading)
+                        GemmParams g; memset(&g, 0, sizeof(g));                                      // RFD(Wnew, H) with a 2-D Wnew: plain Wnew*H  (cnmfsc.m:235)
+                        g.M = m; g.N = n; g.Kc = K;
+                        g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                        g.B = OpView{H, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                        g.C = Vh.as<float>(); g.ldc = m;
+                        TRY(gemm(g, &newobj));
+                        if (newobj <= begobj) break;
+                        stepW[t] /= 2;
+                        if (stepW[t] < 1e-200) { early = true; break; }                              // cnmfsc.m:245-249
+                    }
+                    if (r->tries_W) r->tries_W[nW] = tries;
+                    ++nW;
+                    if (early) { ncost = it; break; }
+                    stepW[t] *= 1.2;
+                    NMFX_HIP(hipMemcpyAsync(Wt, Wnew, mK * 4, hipMemcpyDeviceToDevice, st));         // W(:,:,t) = Wnew
+                    begobj = newobj;                                                                 // next t: 0.5*||V - V_hat||^2 of the V_hat left here
+                } else {
+                    TRY(xht(V.as<float>(), H, t, G1.as<float>()));                               // neg = V * Hs'
+                    TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
+                    NMFX_HIP(hipMemcpyAsync(Wt, W0t, mK * 4, hipMemcpyDeviceToDevice, st));
+                    TRY(mu_plain(st, Wt, G1.as<float>(), G2.as<float>(), (long)mK));                 // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
+                    TRY(axpy_f32(st, (long)mK, -1.0f, W0t, Wt, Wnew));                               // dW = W_t - W0_t
+                    GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
+                    g.M = m; g.N = n; g.Kc = K;
+                    g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                    // rshift_t(H) as a view whose base lies t columns BEFORE H: every element it may touch (column r - t >= 0) is inside H, but the
+                    // base itself is not -- chunks outside the view must load from inside the allocation (safe), or the launch faults when H
+                    // happens to start a mapping (found by scripts/fuzz_campaign_sc.py)
+                    g.B = OpView{H - (long)K * t, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, -t, NMFX_PRO_NONE, 0.f, 0.f, 0, (long)K * t};
+                    g.C = Vh.as<float>(); g.ldc = m; g.accumulate = 1; g.clamp0 = 1; g.epi = EPI_STORE; g.splitk = 1;
+                    TRY(launch_gemm(st, g));
+                }
+            }
+            if (early) break;
+        }
+        NMFX_HIP(hipMemcpyAsync(W0, W, mKT * 4, hipMemcpyDeviceToDevice, st));                   // W0 = W   cnmfsc.m:266
+        TRY(rfd(W0, H, &r->cost[it]));                                                           // cnmfsc.m:269-270
+        if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // cnmfsc.m:273-276
+            ncost = it + 1;
+            break;
+        }
+    }
+    r->cost_len = ncost;
+    r->iters_run = ncost - 1;
+    r->stepsize_H = stepH; r->stepsize_W = stepW[0];
+    r->converged_early = early ? 1 : 0;
+    if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
+    if (r->tries_W) for (int i = nW; i < p->maxiter * T; ++i) r->tries_W[i] = 0;
+    TRY(download(st, W, p->dtype, r->W, mKT, stage, STAGE_ELEMS));
+    TRY(download(st, H, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    return NMFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
+nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,
+                           nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r) {
+    if (!p || !r || !V_dev || !W_dev || !H_dev || !r->cost) { set_error("nmfx_nmfsc_dev: null argument"); return NMFX_ERR_INVALID; }
+    if (p->m <= 0 || p->n <= 0 || p->K_total <= 0 || p->maxiter <= 0 || n_total < p->n) { set_error("nmfx_nmfsc_dev: bad sizes"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    ScDev d{};
+    d.V = V_dev; d.W = W_dev; d.H = H_dev; d.n_total = n_total; d.st = static_cast<hipStream_t>(stream);
+    d.comm.fn = allreduce; d.comm.ctx = allreduce_ctx; d.comm.st = d.st;
+    return run_nmfsc(p, r, &d);
+}
+nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
+
+nmfx_status nmfx_nmfsc_profile(int32_t enable) {
+    g_sc_prof.enable(enable != 0);
+    if (!enable) g_sc_prof.release();
+    return NMFX_OK;
+}
+int32_t nmfx_nmfsc_profile_ntags(void) { return SC_COUNT; }
+const char *nmfx_nmfsc_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < SC_COUNT) ? kScTagNames[tag] : ""; }
+nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag) { return g_sc_prof.read(SC_COUNT, ms_per_tag, count_per_tag); }
+
+}  // extern "C"
