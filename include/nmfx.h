@@ -161,6 +161,11 @@ nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s
 nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
                               const float *dir_dev, double mu, int32_t *usediters_dev);
 
+/* Measurement hook for the blocking calls (bench.py --api blocking): wall seconds the last nmfx_nmf / nmfx_cnmf / nmfx_lnmf /
+ * nmfx_constrainednmf on the calling thread spent moving the host arrays in (host-side fp64 -> fp32 conversion on threads + DMA through
+ * two pinned buffers), iterating, and moving the results out; and the bytes of host arrays read / written.  Any pointer may be NULL. */
+nmfx_status nmfx_last_call_timing(double *ingest_s, double *iterate_s, double *egress_s, double *host_bytes_in, double *host_bytes_out);
+
 const char *nmfx_last_error(void);
 int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */
 int32_t nmfx_version(void);

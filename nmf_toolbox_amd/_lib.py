@@ -24,7 +24,7 @@ EXPORTS = [
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
-    "nmfx_engine_between_allreduces", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read",
+    "nmfx_engine_between_allreduces", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing",
 ]
 
 
@@ -123,6 +123,7 @@ def load():
     lib.nmfx_engine_tag_work.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.nmfx_gemm_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t]
+    lib.nmfx_last_call_timing.argtypes = [C.POINTER(C.c_double)] * 5
     _lib = lib
     return lib
 
@@ -134,3 +135,10 @@ def check(status):
 
 def device_count():
     return int(load().nmfx_device_count())
+
+
+def last_call_timing():
+    """seconds / bytes of the last blocking factorisation on this thread: dict(ingest_s, iterate_s, egress_s, host_bytes_in, host_bytes_out)"""
+    v = [C.c_double() for _ in range(5)]
+    check(load().nmfx_last_call_timing(*[C.byref(x) for x in v]))
+    return dict(zip(("ingest_s", "iterate_s", "egress_s", "host_bytes_in", "host_bytes_out"), (x.value for x in v)))

@@ -172,11 +172,13 @@ struct DevBuf {
 
 inline size_t dsize(int dtype) { return dtype == NMFX_F64 ? 8 : 4; }
 
-constexpr size_t STAGE_ELEMS = (size_t)8 << 20;  // 64 MiB of doubles
-
-// host (f32/f64) -> device fp32 (out = in / divide_by) and back, converted on the device through a staging buffer (host_io.hip)
-nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by, DevBuf &stage, size_t stage_elems);
-nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count, DevBuf &stage, size_t stage_elems);
+// host (f32 / f64, pageable) <-> device fp32 through two pinned staging buffers, conversion on host threads (host_io.hip); upload: out = in / divide_by
+nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by);
+nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count);
+void host_minmax(const void *host, int dtype, size_t count, double *vmin, double *vmax);
+// per-thread account of the last blocking call (nmfx_last_call_timing)
+struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0; };
+IoStats &io_stats();
 nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true);
 
 }  // namespace nmfx

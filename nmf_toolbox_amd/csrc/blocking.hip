@@ -1,5 +1,7 @@
 // Blocking host-buffer entry points of the C ABI (what the MEX gateway binds): nmf / cnmf / lnmf / constrainednmf on one GPU or
 // column-sharded over the GPUs of this process, ReconstructFromDecomposition, SortDictionary, projfunc.
+#include <chrono>
+
 #include "api_common.h"
 
 using namespace nmfx;
@@ -48,31 +50,35 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
     TRY(nmfx_engine_packed_count(&d, &packed_count));
     const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
-    DevBuf V, W, H, Z, ws, packed, stage;
+    DevBuf V, W, H, Z, ws, packed;
     TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(ws.alloc(ws_bytes)); TRY(packed.alloc(packed_count * 4));
-    TRY(stage.alloc(STAGE_ELEMS * 8));
     hipStream_t st = nullptr;
-    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0, stage, STAGE_ELEMS));
+    IoStats &io = io_stats();
+    io = IoStats{};
+    const auto t0 = std::chrono::steady_clock::now();
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0));
     const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
     DevBuf tmp;   // K x cols staging of the un-padded row-interleaved arrays (H, Z)
     if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
-    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0, stage, STAGE_ELEMS));   // the first K columns of the m x K_pad array
+    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0));   // the first K columns of the m x K_pad array
     if (pad) NMFX_HIP(hipMemsetAsync(W.as<float>() + mKt, 0, (mKT - mKt) * 4, st));
     if (algorithm != 3) {
         if (pad) {
-            TRY(upload(st, p->H_init, p->dtype, tmp.as<float>(), Ktn, 1.0, stage, STAGE_ELEMS));
+            TRY(upload(st, p->H_init, p->dtype, tmp.as<float>(), Ktn, 1.0));
             TRY(repack_rows(st, tmp.as<float>(), Kt, H.as<float>(), K, p->n));
-        } else TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+        } else TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0));
     } else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
         TRY(Z.alloc((size_t)K * nz * 4));
         if (pad) {
-            TRY(upload(st, Z_init, p->dtype, tmp.as<float>(), (size_t)Kt * nz, 1.0, stage, STAGE_ELEMS));
+            TRY(upload(st, Z_init, p->dtype, tmp.as<float>(), (size_t)Kt * nz, 1.0));
             TRY(repack_rows(st, tmp.as<float>(), Kt, Z.as<float>(), K, nz));
-        } else TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0, stage, STAGE_ELEMS));
+        } else TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0));
     }
     nmfx_engine *e = nullptr;
     TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
     nmfx_status s = algorithm == 3 ? nmfx_engine_set_constraint(e, seg, nz, Z.as<float>()) : NMFX_OK;
+    NMFX_HIP(hipStreamSynchronize(st));   // (nmfx_engine_create has drained the stream already: this only closes the ingest clock)
+    const auto t1 = std::chrono::steady_clock::now();
     if (s == NMFX_OK) s = nmfx_engine_init(e);
     int it = 0;
     r->iters_run = 0;
@@ -114,17 +120,21 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
         r->cost_len = p->maxiter;
     }
-    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS);
+    const auto t2 = std::chrono::steady_clock::now();   // (the last cost read-back has synchronised the iterations)
+    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt);
     if (s == NMFX_OK && pad) {
         s = repack_rows(st, H.as<float>(), K, tmp.as<float>(), Kt, p->n);
-        if (s == NMFX_OK) s = download(st, tmp.as<float>(), p->dtype, r->H, Ktn, stage, STAGE_ELEMS);
+        if (s == NMFX_OK) s = download(st, tmp.as<float>(), p->dtype, r->H, Ktn);
         if (s == NMFX_OK && algorithm == 3) s = repack_rows(st, Z.as<float>(), K, tmp.as<float>(), Kt, nz);
-        if (s == NMFX_OK && algorithm == 3) s = download(st, tmp.as<float>(), p->dtype, Z_out, (size_t)Kt * nz, stage, STAGE_ELEMS);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, tmp.as<float>(), p->dtype, Z_out, (size_t)Kt * nz);
     } else {
-        if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS);
-        if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz, stage, STAGE_ELEMS);
+        if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn);
+        if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz);
     }
     nmfx_engine_destroy(e);
+    const auto t3 = std::chrono::steady_clock::now();
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    io.ingest_s = sec(t0, t1); io.iterate_s = sec(t1, t2); io.egress_s = sec(t2, t3);
     return s;
 }
 
@@ -253,20 +263,19 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         TRY(nmfx_engine_packed_count(&d, &pc));
         if (g == 0) packed_count = pc;
         else if (pc != packed_count) { set_error("n_gpus: shards disagree on the packed layout"); return NMFX_ERR_INVALID; }
-        DevBuf stage, tmp;
+        DevBuf tmp;
         TRY(M.V[g].alloc((size_t)m * nl * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nl * 4)); TRY(M.ws[g].alloc(wsb));
-        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64)); TRY(stage.alloc(STAGE_ELEMS * 8));
-        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
+        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64));        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
         const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
-        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * nl, 1.0, stage, STAGE_ELEMS));
-        TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0, stage, STAGE_ELEMS));
+        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * nl, 1.0));
+        TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0));
         if (pad) {
             NMFX_HIP(hipMemsetAsync(M.W[g].as<float>() + mKt, 0, (mK - mKt) * 4, M.st[g]));
             TRY(tmp.alloc((size_t)Kt * nl * 4));
-            TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0, stage, STAGE_ELEMS));
+            TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0));
             TRY(repack_rows(M.st[g], tmp.as<float>(), Kt, M.H[g].as<float>(), K, nl));
             NMFX_HIP(hipStreamSynchronize(M.st[g]));
-        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nl, 1.0, stage, STAGE_ELEMS));
+        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nl, 1.0));
         TRY(nmfx_engine_create(&d, M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb, M.packed[g].as<float>(), &M.eng[g]));
         TRY(nmfx_engine_set_rank0(M.eng[g], g == 0));
         const int kd = nmfx_engine_is_fused(M.eng[g]);
@@ -319,15 +328,14 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         const long nl = M.lo[g + 1] - M.lo[g];
-        DevBuf stage, tmp;
-        TRY(stage.alloc(STAGE_ELEMS * 8));
-        if (g == 0) TRY(download(M.st[g], M.W[g].as<float>(), p->dtype, r->W, mKt, stage, STAGE_ELEMS));
+        DevBuf tmp;
+        if (g == 0) TRY(download(M.st[g], M.W[g].as<float>(), p->dtype, r->W, mKt));
         char *Hh = static_cast<char *>(r->H) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
         if (pad) {
             TRY(tmp.alloc((size_t)Kt * nl * 4));
             TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, tmp.as<float>(), Kt, nl));
-            TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl, stage, STAGE_ELEMS));
-        } else TRY(download(M.st[g], M.H[g].as<float>(), p->dtype, Hh, (size_t)K * nl, stage, STAGE_ELEMS));
+            TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl));
+        } else TRY(download(M.st[g], M.H[g].as<float>(), p->dtype, Hh, (size_t)K * nl));
     }
     return NMFX_OK;
 }
@@ -349,11 +357,10 @@ nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t
     DeviceGuard dg_;
     TRY(check_device(device));
     const size_t mn = (size_t)m * n, mKT = (size_t)m * K * T, Kn = (size_t)K * n;
-    DevBuf Wd, Hd, Vd, stage;
-    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
-    hipStream_t st = nullptr;
-    TRY(upload(st, W, dtype, Wd.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
-    TRY(upload(st, H, dtype, Hd.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    DevBuf Wd, Hd, Vd;
+    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4));    hipStream_t st = nullptr;
+    TRY(upload(st, W, dtype, Wd.as<float>(), mKT, 1.0));
+    TRY(upload(st, H, dtype, Hd.as<float>(), Kn, 1.0));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.M = m; g.N = n; g.Kc = (long)K * T;
@@ -362,7 +369,7 @@ nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t
     else g.B = OpView{Hd.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
     g.C = Vd.as<float>(); g.ldc = m; g.epi = EPI_STORE; g.splitk = 1;
     TRY(launch_gemm(st, g));
-    return download(st, Vd.as<float>(), dtype, V_hat, mn, stage, STAGE_ELEMS);
+    return download(st, Vd.as<float>(), dtype, V_hat, mn);
 }
 
 // [W_sorted, H_sorted] = SortDictionary(W, H): basis columns by increasing centre of mass (SortDictionary.m:33-47), computed in the

@@ -1,33 +1,166 @@
-// Host <-> device staging of the blocking (MATLAB-facing) entry points: fp32 / fp64 host buffers in, fp32 on the device.
+// Host <-> device staging of the blocking (MATLAB-facing) entry points: fp32 / fp64 host buffers in pageable memory on one side, fp32
+// in HBM on the other.
+//
+// The caller's arrays (a MATLAB mxArray, a NumPy array) are pageable, 8 GiB of doubles at BASELINE config 3, and the device wants
+// floats.  So the conversion runs on the HOST, in threads, while the data is copied into one of two pinned staging buffers, and the DMA
+// engine moves fp32 -- half the PCIe bytes of the doubles -- out of the other one at the same time:
+//
+//     chunk c   : host threads   V[c] (f64, pageable) --(float)(x / s)--> pinned[c & 1]     (memory-bandwidth bound, ~T cores)
+//     chunk c-1 : DMA            pinned[(c-1) & 1] ----------------------> HBM              (hipMemcpyAsync, returns at once)
+//
+// One event per buffer says when its DMA has drained; nothing else synchronises, and no kernel runs.  The values are the same the
+// device-side conversion produced before: IEEE double division, then round-to-nearest to float.
+// Downloads mirror it (DMA of chunk c into one buffer while the threads widen chunk c-1 out of the other).
+#include <atomic>
+#include <mutex>
+#include <thread>
+
 #include "api_common.h"
 
 namespace nmfx {
 
-// host (f32/f64) -> device fp32, converted on the device through a staging buffer; out = in / divide_by
-nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by, DevBuf &stage, size_t stage_elems) {
-    const char *h = static_cast<const char *>(host);
-    for (size_t off = 0; off < count; off += stage_elems) {
-        size_t c = count - off < stage_elems ? count - off : stage_elems;
-        NMFX_HIP(hipMemcpyAsync(stage.p, h + off * dsize(dtype), c * dsize(dtype), hipMemcpyHostToDevice, st));
-        TRY(cvt_to_f32(st, stage.p, dtype, dev + off, (long)c, divide_by));
-        NMFX_HIP(hipStreamSynchronize(st));
-    }
-    return NMFX_OK;
-}
-nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count, DevBuf &stage, size_t stage_elems) {
-    char *h = static_cast<char *>(host);
-    if (dtype == NMFX_F32) {
-        NMFX_HIP(hipMemcpyAsync(h, dev, count * 4, hipMemcpyDeviceToHost, st));
-        NMFX_HIP(hipStreamSynchronize(st));
+namespace {
+
+constexpr size_t CHUNK_ELEMS = (size_t)16 << 20;   // 64 MiB of floats per pinned buffer (128 MiB of the caller's doubles)
+constexpr size_t MIN_PER_THREAD = (size_t)1 << 18;
+
+// two pinned, portable staging buffers per process, allocated on first use and kept (pinning 128 MiB costs tens of ms; a MATLAB session
+// calls nmf() many times).  One transfer at a time uses them.
+struct PinnedPool {
+    std::mutex mu;
+    float *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[NMFX_MAX_GPUS][2] = {};   // an event belongs to the device it was created on: one pair per device that ever transfers
+    int pend_dev[2] = {-1, -1};             // device whose DMA last used buffer b (-1: idle)
+    nmfx_status get(int *dev_out) {
+        int dev = 0;
+        NMFX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= NMFX_MAX_GPUS) { set_error("host staging: device %d out of range", dev); return NMFX_ERR_INVALID; }
+        for (int b = 0; b < 2; ++b) {
+            if (!buf[b]) NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&buf[b]), CHUNK_ELEMS * sizeof(float), hipHostMallocPortable));
+            if (!ev[dev][b]) NMFX_HIP(hipEventCreateWithFlags(&ev[dev][b], hipEventDisableTiming));
+        }
+        *dev_out = dev;
         return NMFX_OK;
     }
-    for (size_t off = 0; off < count; off += stage_elems) {
-        size_t c = count - off < stage_elems ? count - off : stage_elems;
-        TRY(cvt_to_f64(st, dev + off, stage.as<double>(), (long)c));
-        NMFX_HIP(hipMemcpyAsync(h + off * 8, stage.p, c * 8, hipMemcpyDeviceToHost, st));
-        NMFX_HIP(hipStreamSynchronize(st));
+    nmfx_status wait(int b) {   // the DMA that last used buffer b has drained
+        if (pend_dev[b] >= 0) { NMFX_HIP(hipEventSynchronize(ev[pend_dev[b]][b])); pend_dev[b] = -1; }
+        return NMFX_OK;
     }
+    nmfx_status mark(int b, int dev, hipStream_t st) {
+        NMFX_HIP(hipEventRecord(ev[dev][b], st));
+        pend_dev[b] = dev;
+        return NMFX_OK;
+    }
+};
+PinnedPool g_pool;
+
+int io_threads() {
+    static const int n = [] {
+        const char *e = getenv("NMFX_IO_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return t < 1 ? 1 : (t > 32 ? 32 : t);
+    }();
+    return n;
+}
+
+// run f(lo, hi) over [0, n) on up to io_threads() threads (the calling thread takes the first slice)
+template <class F> void parallel_for(size_t n, F f) {
+    int T = (int)std::min<size_t>((size_t)io_threads(), n / MIN_PER_THREAD + 1);
+    if (T <= 1) { f((size_t)0, n); return; }
+    const size_t per = ((n + T - 1) / T + 15) & ~(size_t)15;
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (int t = 1; t < T; ++t) {
+        const size_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1));
+        if (lo < hi) th.emplace_back([=] { f(lo, hi); });
+    }
+    f((size_t)0, std::min(n, per));
+    for (auto &x : th) x.join();
+}
+
+void narrow(const void *src, int dtype, size_t off, float *dst, size_t n, double s) {
+    if (dtype == NMFX_F64) {
+        const double *p = static_cast<const double *>(src) + off;
+        if (s == 1.0) parallel_for(n, [=](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) dst[i] = (float)p[i]; });
+        else parallel_for(n, [=](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) dst[i] = (float)(p[i] / s); });
+    } else {
+        const float *p = static_cast<const float *>(src) + off;
+        if (s == 1.0) parallel_for(n, [=](size_t lo, size_t hi) { memcpy(dst + lo, p + lo, (hi - lo) * sizeof(float)); });
+        else parallel_for(n, [=](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) dst[i] = (float)((double)p[i] / s); });
+    }
+}
+
+void widen(const float *src, int dtype, void *dst, size_t off, size_t n) {
+    if (dtype == NMFX_F64) {
+        double *p = static_cast<double *>(dst) + off;
+        parallel_for(n, [=](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) p[i] = (double)src[i]; });
+    } else {
+        float *p = static_cast<float *>(dst) + off;
+        parallel_for(n, [=](size_t lo, size_t hi) { memcpy(p + lo, src + lo, (hi - lo) * sizeof(float)); });
+    }
+}
+
+thread_local IoStats g_io;
+
+}  // namespace
+
+IoStats &io_stats() { return g_io; }
+
+// host (f32 / f64, pageable) -> device fp32, out = in / divide_by.  Returns once the last chunk is QUEUED on `st`; the caller's buffer is
+// no longer referenced at that point (the DMA reads the pinned copies), and work queued on `st` afterwards sees the data.
+nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    int cur = 0;
+    TRY(g_pool.get(&cur));
+    for (size_t off = 0, c = 0; off < count; off += CHUNK_ELEMS, ++c) {
+        const int b = (int)(c & 1);
+        const size_t n = std::min(CHUNK_ELEMS, count - off);
+        TRY(g_pool.wait(b));
+        narrow(host, dtype, off, g_pool.buf[b], n, divide_by);
+        NMFX_HIP(hipMemcpyAsync(dev + off, g_pool.buf[b], n * sizeof(float), hipMemcpyHostToDevice, st));
+        TRY(g_pool.mark(b, cur, st));
+    }
+    g_io.h2d_bytes_host += (double)count * (double)dsize(dtype);
+    g_io.h2d_bytes_pcie += (double)count * 4.0;
     return NMFX_OK;
+}
+
+// device fp32 -> host (f32 / f64); complete when it returns
+nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    int cur = 0;
+    TRY(g_pool.get(&cur));
+    size_t prev_off = 0, prev_n = 0;
+    int prev_b = -1;
+    for (size_t off = 0, c = 0; off < count; off += CHUNK_ELEMS, ++c) {
+        const int b = (int)(c & 1);
+        const size_t n = std::min(CHUNK_ELEMS, count - off);
+        TRY(g_pool.wait(b));
+        NMFX_HIP(hipMemcpyAsync(g_pool.buf[b], dev + off, n * sizeof(float), hipMemcpyDeviceToHost, st));
+        TRY(g_pool.mark(b, cur, st));
+        if (prev_b >= 0) { TRY(g_pool.wait(prev_b)); widen(g_pool.buf[prev_b], dtype, host, prev_off, prev_n); }
+        prev_b = b; prev_off = off; prev_n = n;
+    }
+    if (prev_b >= 0) { TRY(g_pool.wait(prev_b)); widen(g_pool.buf[prev_b], dtype, host, prev_off, prev_n); }
+    g_io.d2h_bytes_host += (double)count * (double)dsize(dtype);
+    return NMFX_OK;
+}
+
+// min / max of a host array (nmfsc.m:57-62: the sign check and the global rescale), on the same threads
+void host_minmax(const void *host, int dtype, size_t count, double *vmin, double *vmax) {
+    const int T = io_threads();
+    std::vector<double> lo_(T + 1, INFINITY), hi_(T + 1, -INFINITY);
+    std::atomic<int> slot{0};
+    auto body = [&](size_t lo, size_t hi) {
+        double mn = INFINITY, mx = -INFINITY;
+        if (dtype == NMFX_F64) { const double *p = static_cast<const double *>(host); for (size_t i = lo; i < hi; ++i) { if (p[i] < mn) mn = p[i]; if (p[i] > mx) mx = p[i]; } }
+        else { const float *p = static_cast<const float *>(host); for (size_t i = lo; i < hi; ++i) { if (p[i] < mn) mn = p[i]; if (p[i] > mx) mx = p[i]; } }
+        const int s = slot.fetch_add(1);
+        lo_[s] = mn; hi_[s] = mx;
+    };
+    parallel_for(count, body);
+    *vmin = INFINITY; *vmax = -INFINITY;
+    for (int s = 0; s <= T; ++s) { if (lo_[s] < *vmin) *vmin = lo_[s]; if (hi_[s] > *vmax) *vmax = hi_[s]; }
 }
 
 nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init) {
@@ -53,3 +186,19 @@ nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool n
 }
 
 }  // namespace nmfx
+
+extern "C" {
+
+// Measurement hook (bench.py --api blocking): seconds the last blocking factorisation on this thread spent moving data in, iterating, and
+// moving results out, and the bytes it took from / returned to host arrays.
+nmfx_status nmfx_last_call_timing(double *ingest_s, double *iterate_s, double *egress_s, double *host_bytes_in, double *host_bytes_out) {
+    const nmfx::IoStats &s = nmfx::io_stats();
+    if (ingest_s) *ingest_s = s.ingest_s;
+    if (iterate_s) *iterate_s = s.iterate_s;
+    if (egress_s) *egress_s = s.egress_s;
+    if (host_bytes_in) *host_bytes_in = s.h2d_bytes_host;
+    if (host_bytes_out) *host_bytes_out = s.d2h_bytes_host;
+    return NMFX_OK;
+}
+
+}  // extern "C"

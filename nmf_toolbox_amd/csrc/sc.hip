@@ -74,8 +74,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     Comm &comm = dev ? dev->comm : nocomm;
     double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62
     if (dev) { vmin = 0; vmax = 1; }
-    else if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
-    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    else host_minmax(p->V, p->dtype, mn, &vmin, &vmax);
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
     DeviceGuard dg_;
     TRY(check_device(p->device));
@@ -90,7 +89,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n_total) - (std::sqrt((double)n_total) - 1) * sH; }   // nmfsc.m:102-106
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
-    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, stage, part, costd, scratch, pfv, pff, pfr;
+    DevBuf V, W, Hk, HT, HnT, G1, G2, Vh, Wn, part, costd, scratch, pfv, pff, pfr;
     const bool fast = p->path != 1 && fused_supported(K) && ((m >= 64 && n >= 64) || p->path == 2);   // ragged m / n: masked-edge kernels
     if (p->path == 2 && !fast) { set_error("nmfsc: fused path requested but shape not eligible"); return NMFX_ERR_UNSUPPORTED; }
     if (comm.active() && !fast) {
@@ -104,7 +103,6 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     TRY(HnT.alloc(Kn * 4));
     const size_t gmax = (Kn > mK ? Kn : mK) + (size_t)K * K;   // + K*K: [V*H' | H*H'] travel as ONE all-reduce on column shards
     TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));
-    TRY(stage.alloc(STAGE_ELEMS * 8));
     const int nparts = (int)gemm_grid_blocks(m, n);
     TRY(part.alloc(sizeof(double) * nparts)); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = gemm_scratch_bytes(n, K, m), sb2 = gemm_scratch_bytes(m, K, n), sb3 = gemm_scratch_bytes(K, n, m);
@@ -118,12 +116,12 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         NMFX_HIP(hipMemsetAsync(HT.p, 0, Kn * 4, st)); NMFX_HIP(hipMemsetAsync(HnT.p, 0, Kn * 4, st));   // the padding of every buffer that is only ever
     }                                                                                                 // written through projfunc stays zero
     if (!dev) {
-        TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));   // V = V / max(V(:))
-        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKv, 1.0, stage, STAGE_ELEMS));   // the first Kv columns of the m x K array
+        TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax));   // V = V / max(V(:))
+        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKv, 1.0));   // the first Kv columns of the m x K array
         if (padK) {
-            TRY(upload(st, p->H_init, p->dtype, hpk.as<float>(), Kvn, 1.0, stage, STAGE_ELEMS));
+            TRY(upload(st, p->H_init, p->dtype, hpk.as<float>(), Kvn, 1.0));
             TRY(repack_rows(st, hpk.as<float>(), Kv, Hk.as<float>(), K, n));
-        } else TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+        } else TRY(upload(st, p->H_init, p->dtype, Hk.as<float>(), Kn, 1.0));
     } else {
         NMFX_HIP(hipMemcpyAsync(W.p, dev->W, mKv * 4, hipMemcpyDeviceToDevice, st));
         if (padK) TRY(repack_rows(st, dev->H, Kv, Hk.as<float>(), K, n));
@@ -461,11 +459,11 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             NMFX_HIP(hipStreamSynchronize(st));
             return NMFX_OK;
         }
-        TRY(download(st, Wd, p->dtype, r->W, mKv, stage, STAGE_ELEMS));
+        TRY(download(st, Wd, p->dtype, r->W, mKv));
         if (padK) {
             TRY(repack_rows(st, Hcur, K, hpk.as<float>(), Kv, n));
-            TRY(download(st, hpk.as<float>(), p->dtype, r->H, Kvn, stage, STAGE_ELEMS));
-        } else TRY(download(st, Hcur, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+            TRY(download(st, hpk.as<float>(), p->dtype, r->H, Kvn));
+        } else TRY(download(st, Hcur, p->dtype, r->H, Kn));
         return NMFX_OK;
     }
     TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
@@ -547,8 +545,8 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         NMFX_HIP(hipStreamSynchronize(st));
         return NMFX_OK;
     }
-    TRY(download(st, Wd, p->dtype, r->W, mK, stage, STAGE_ELEMS));
-    TRY(download(st, Hk.as<float>(), p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    TRY(download(st, Wd, p->dtype, r->W, mK));
+    TRY(download(st, Hk.as<float>(), p->dtype, r->H, Kn));
     return NMFX_OK;
 }
 
@@ -561,8 +559,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (n < T) { set_error("cnmfsc: context_len exceeds the number of columns"); return NMFX_ERR_INVALID; }
     const size_t mn = (size_t)m * n, mK = (size_t)m * K, mKT = (size_t)m * KT, Kn = (size_t)K * n;
     double vmin = INFINITY, vmax = -INFINITY;   // cnmfsc.m:67-72
-    if (p->dtype == NMFX_F64) { const double *v = static_cast<const double *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
-    else { const float *v = static_cast<const float *>(p->V); for (size_t i = 0; i < mn; ++i) { if (v[i] < vmin) vmin = v[i]; if (v[i] > vmax) vmax = v[i]; } }
+    host_minmax(p->V, p->dtype, mn, &vmin, &vmax);
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
     DeviceGuard dg_;
     TRY(check_device(p->device));
@@ -572,7 +569,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
     const bool fixW = p->W_fixed && p->W_fixed[0], fixH = p->H_fixed && p->H_fixed[0];
 
-    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, stage, part, costd, scratch, rrs, g64, s64;
+    DevBuf V, Vh, W0b, Wb, Wnb, Hb, Hnb, HTb, HnT, G1, G2, part, costd, scratch, rrs, g64, s64;
     // sparse-W gradients in fp64 where that is cheap (aux.hip::resid_xht64): m*n*K fp64 FMAs per slice
     const bool small64 = p->sc_W_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
     const int nch64 = small64 ? (int)std::min<long>(std::max<long>(1, 1024 / (((p->m + 255) / 256) * p->K_total)), (p->n + 63) / 64) : 1;
@@ -585,13 +582,12 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
     TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
     const size_t gmax = std::max(Kn, mKT);
-    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4)); TRY(stage.alloc(STAGE_ELEMS * 8));
-    TRY(part.alloc(sizeof(double) * gemm_grid_blocks(m, n))); TRY(costd.alloc(64 + sizeof(double) * K));
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * gemm_grid_blocks(m, n))); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
     TRY(scratch.alloc(sb));
-    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax, stage, STAGE_ELEMS));
-    TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0, stage, STAGE_ELEMS));
-    TRY(upload(st, p->H_init, p->dtype, Hb.as<float>(), Kn, 1.0, stage, STAGE_ELEMS));
+    TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax));
+    TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0));
+    TRY(upload(st, p->H_init, p->dtype, Hb.as<float>(), Kn, 1.0));
     float *W0 = W0b.as<float>(), *W = Wb.as<float>(), *Wnew = Wnb.as<float>(), *H = Hb.as<float>(), *Hnew = Hnb.as<float>(), *HT = HTb.as<float>();
     NMFX_HIP(hipMemcpyAsync(W, W0, mKT * 4, hipMemcpyDeviceToDevice, st));                     // W = W0   cnmfsc.m:94
     if (sW > 0) TRY(projfunc_cols(st, W, m, KT, L1a, 1.0, 1, nullptr));                          // cnmfsc.m:105-109 (W only, not W0)
@@ -742,8 +738,8 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     r->converged_early = early ? 1 : 0;
     if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
     if (r->tries_W) for (int i = nW; i < p->maxiter * T; ++i) r->tries_W[i] = 0;
-    TRY(download(st, W, p->dtype, r->W, mKT, stage, STAGE_ELEMS));
-    TRY(download(st, H, p->dtype, r->H, Kn, stage, STAGE_ELEMS));
+    TRY(download(st, W, p->dtype, r->W, mKT));
+    TRY(download(st, H, p->dtype, r->H, Kn));
     return NMFX_OK;
 }
 

@@ -123,6 +123,19 @@ def _fptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _as_data(V):
+    """V as the library takes it: float32 or float64 (anything else is widened to float64, like MATLAB's double), column-major.
+    A column-major array of either type is passed as is -- no copy of an 8 GiB matrix just to hand it over."""
+    V = np.asarray(V)
+    if V.dtype != np.float32 and V.dtype != np.float64:
+        V = V.astype(np.float64)
+    return V
+
+
+def _f_order(a, dtype):
+    return a if (a.dtype == dtype and a.flags.f_contiguous) else np.asfortranarray(a, dtype=dtype)
+
+
 def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     m, n = V.shape
     S = len(Ks)
@@ -136,12 +149,14 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     for w in W3:
         if w.shape[2] != T:
             raise ValueError("W_init has context length %d, expected %d" % (w.shape[2], T))
-    W_all = np.asfortranarray(np.concatenate(W3, axis=1), dtype=np.float64)   # cell2mat(1xS) -> along dim 2 (nmf.m:136)
-    H_all = np.asfortranarray(np.concatenate(H, axis=0), dtype=np.float64)    # cell2mat(Sx1) -> along dim 1 (nmf.m:137)
-    Vf = np.asfortranarray(V, dtype=np.float64)
+    # the three arrays travel in V's own precision (float32 data stays float32: half the host traffic, same device arithmetic)
+    dt = V.dtype
+    W_all = _f_order(W3[0] if S == 1 else np.concatenate(W3, axis=1), dt)   # cell2mat(1xS) -> along dim 2 (nmf.m:136)
+    H_all = _f_order(H[0] if S == 1 else np.concatenate(H, axis=0), dt)     # cell2mat(Sx1) -> along dim 1 (nmf.m:137)
+    Vf = _f_order(V, dt)
     maxiter = int(cfg["maxiter"])
-    Wout = np.zeros((m, K, T), order="F")
-    Hout = np.zeros((K, n), order="F")
+    Wout = np.zeros((m, K, T), order="F", dtype=dt)
+    Hout = np.zeros((K, n), order="F", dtype=dt)
     cost = np.zeros(maxiter)
     Ks_a = np.asarray(Ks, dtype=np.int32)
     lw = np.asarray(cfg["W_sparsity"], dtype=np.float64)
@@ -149,7 +164,7 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     fw = np.asarray(cfg["W_fixed"], dtype=np.uint8)
     fh = np.asarray(cfg["H_fixed"], dtype=np.uint8)
     p = _lib.Problem()
-    p.m, p.n, p.K_total, p.T, p.dtype = m, n, K, T, _lib.F64
+    p.m, p.n, p.K_total, p.T, p.dtype = m, n, K, T, (_lib.F32 if dt == np.float32 else _lib.F64)
     p.V, p.W_init, p.H_init = _fptr(Vf), _fptr(W_all), _fptr(H_all)
     p.divergence, p.alpha, p.beta = divergence, float(cfg["alpha"]), float(cfg["beta"])
     p.num_sources, p.K_s = S, _fptr(Ks_a)
@@ -177,7 +192,7 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
 
 def nmf(V, num_basis_elems, config=None, device=0):
     """[W, H, cost] = nmf(V, num_basis_elems, config)  -- nmf.m:1."""
-    V = np.asarray(V, dtype=np.float64)
+    V = _as_data(V)
     if V.ndim != 2:
         raise ValueError("V must be a matrix")
     Ks = [int(k) for k in (num_basis_elems if _is_cell(num_basis_elems) else [num_basis_elems])]   # nmf.m:114-117
@@ -194,7 +209,7 @@ def nmf(V, num_basis_elems, config=None, device=0):
 
 def cnmf(V, num_basis_elems, context_len, config=None, device=0):
     """[W, H, cost] = cnmf(V, num_basis_elems, context_len, config)  -- cnmf.m:1."""
-    V = np.asarray(V, dtype=np.float64)
+    V = _as_data(V)
     if V.ndim != 2:
         raise ValueError("V must be a matrix")
     T = int(context_len)

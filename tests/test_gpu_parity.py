@@ -145,6 +145,28 @@ def test_reconstruct(gpu_lib):
     assert rel_fro(gpu_lib.ReconstructFromDecomposition([W0[:, :2], W0[:, 2:]], [H0[:2], H0[2:]]), O.reconstruct_from_decomposition(W0, H0)) < 1e-6
 
 
+def test_host_staging_crosses_chunk_boundaries(gpu_lib):
+    """the pinned double-buffer staging of the blocking calls (csrc/host_io.hip: 16 Mi elements per chunk, conversion on host threads):
+    arrays of 2.1 chunks in and out, both host precisions; K = 1 so V_hat = w*h' is exact in fp32 up to one rounding"""
+    rs = np.random.RandomState(5)
+    m, n = 4100, 8300                                            # 34.0 M elements
+    w, h = rs.rand(m, 1), rs.rand(1, n)
+    Vh = gpu_lib.ReconstructFromDecomposition(w, h)
+    ref = w.astype(np.float32).astype(np.float64) @ h.astype(np.float32).astype(np.float64)
+    assert Vh.shape == (m, n) and np.abs(Vh - ref).max() <= 1.2e-7 * ref.max()
+    # nmf on a float32, column-major V is taken as is (no float64 detour) and equals the run on the same values widened to float64
+    V32 = np.asfortranarray(np.fmax(rs.rand(4096, 4400), 2.0 ** -52).astype(np.float32))   # 18.0 M elements: two chunks
+    W0, H0 = np.fmax(rs.rand(4096, 32), 2.0 ** -52), np.fmax(rs.rand(32, 4400), 2.0 ** -52)
+    cfg = dict(divergence="kl", W_init=W0.astype(np.float32), H_init=H0.astype(np.float32), maxiter=2)
+    Wa, Ha, ca = gpu_lib.nmf(V32, 32, cfg)
+    Wb, Hb, cb = gpu_lib.nmf(V32.astype(np.float64), 32, dict(cfg, W_init=W0.astype(np.float32).astype(np.float64), H_init=H0.astype(np.float32).astype(np.float64)))
+    assert Wa.dtype == np.float32 and Wb.dtype == np.float64
+    assert np.array_equal(Wa.astype(np.float64), Wb) and np.array_equal(Ha.astype(np.float64), Hb) and np.array_equal(ca, cb)
+    from nmf_toolbox_amd import _lib
+    tm = _lib.last_call_timing()
+    assert tm["host_bytes_in"] == 8.0 * (V32.size + W0.size + H0.size) and tm["ingest_s"] > 0 and tm["iterate_s"] > 0 and tm["egress_s"] > 0
+
+
 # ---- fused kernels (S = W*H never stored): eligible shapes, both split and un-split epilogues -----------------------
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
 @pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10),
