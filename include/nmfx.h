@@ -255,8 +255,8 @@ nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_
 
 /* Measurement hooks (bench.py): when enabled, every launch group of an iteration is bracketed by a hipEvent
  * pair on the engine's stream; after synchronising, read total ms and launch count per tag.
- * enable: 0 off | 1 every launch group | 2 only the MFMA launch groups (fused passes, GEMMs) -- the dozen small-kernel groups of an
- * iteration are left unbracketed (an event pair costs ~5 us of stream time). */
+ * enable: 0 off | 1 every launch group | 2 only the big passes (fused passes, m*n*K GEMMs) -- the small-kernel groups and the K x K
+ * products of an iteration are left unbracketed (an event pair costs ~5 us of stream time). */
 nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable);
 int32_t nmfx_engine_profile_ntags(void);
 const char *nmfx_engine_profile_tag_name(int32_t tag);

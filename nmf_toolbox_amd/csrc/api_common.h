@@ -50,7 +50,7 @@ struct ProfEvent {
 // hipEvent pairs around launch groups, on the stream the kernels run on (bench.py's per-kernel durations)
 struct Profiler {
     bool on = false;
-    int skip_tag = -1;         // coarse mode: launch groups with this tag (the small kernels) are not bracketed -- an event pair costs ~5 us of
+    unsigned skip_mask = 0;    // coarse mode: launch groups whose tag bit is set (small kernels, K x K products) are not bracketed -- an event pair costs ~5 us of
                                // stream time, 14 pairs per iteration are 4 % of a 2.2 ms iteration on an 8-GPU shard
     hipStream_t st = nullptr;
     std::vector<ProfEvent> events;
@@ -72,7 +72,7 @@ struct PScope {
     Profiler *p;
     int idx;
     PScope(Profiler *p_, int tag) : p(p_), idx(-1) {
-        if (!p || !p->on || tag == p->skip_tag) return;
+        if (!p || !p->on || (tag >= 0 && tag < 32 && ((p->skip_mask >> tag) & 1u))) return;
         auto get = [&]() {
             if (p->pool_used == p->pool.size()) {
                 hipEvent_t ev;

@@ -101,7 +101,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
         e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
         size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
-        e->gemm_scratch_bytes = euc ? std::max(std::max(g1, g2), g3) : 0;
+        e->gemm_scratch_bytes = euc ? std::max(std::max(std::max(g1, g2), g3), std::max(gram_rc_scratch_bytes(e->K, e->K, e->n), gram_rc_scratch_bytes(e->K, e->K, e->m))) : 0;
         e->gemm_scratch = e->gemm_scratch_bytes ? f.take<float>(e->gemm_scratch_bytes / sizeof(float)) : nullptr;
         e->lamW = f.take<float>(e->K); e->lamH = f.take<float>(e->K);
         e->fixW = f.take<uint8_t>(e->K); e->fixH = f.take<uint8_t>(e->K);
@@ -261,6 +261,27 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     return NMFX_OK;
 }
 
+// X*X' (K x K) for X = K x len with contiguous columns, on the W-step form of the stationary kernel: D = X plays V (K "rows"), the columns of X
+// are streamed through LDS by DMA exactly like the columns of H in the W step -- out(k, r) = sum_c X(r, c) X(k, c)
+inline int gram_mode() { static const int m = getenv("NMFX_GRAM") ? atoi(getenv("NMFX_GRAM")) : 2; return m; }   // dev switch: 0 general GEMM, 1 gram_rc, 2 stationary kernel
+nmfx_status gram_fused(nmfx_engine *e, const float *X, long len, float *G) {
+    const int K = e->K;
+    const long blocks = (K + 127) / 128, tiles = (len + 63) / 64;
+    long s = 1;
+    static const long gs_cap = getenv("NMFX_GRAM_WGS") ? atol(getenv("NMFX_GRAM_WGS")) : 256;   // dev switch
+    while (blocks * s * 2 <= gs_cap && s * 4 <= tiles) s *= 2;          // one workgroup per CU, at least two tiles each
+    const long per = (tiles + s - 1) / s;
+    const int split = (int)((tiles + per - 1) / per);
+    if (split > 1 && sizeof(float) * (size_t)split * K * K > e->gemm_scratch_bytes) { set_error("gram_fused: scratch too small"); return NMFX_ERR_INVALID; }
+    FusedParams g;
+    memset(&g, 0, sizeof(g));
+    g.Y = X; g.D = X; g.ldd = K; g.R = K; g.Cn = len; g.K = K; g.c_per_split = per * 64;
+    g.out = split == 1 ? G : e->gemm_scratch; g.slab_stride = (long)K * K; g.os_r = K; g.os_k = 1;
+    TRY(launch_fused(e->st, g, split, true, 0, true, 0));
+    if (split > 1) TRY(reduce_slabs(e->st, e->gemm_scratch, split, g.slab_stride, g.slab_stride, G, 0));
+    return NMFX_OK;
+}
+inline bool small_mm_on() { static const bool off = getenv("NMFX_NO_SMALLMM") != nullptr; return !off; }   // dev switch (A/B runs): the K x K products on the general GEMM
 inline int norm_mode(const nmfx_engine *e) { return e->algo == 3 ? 0 : e->algo; }   // w_normalize: 0 L2 columns, 1 cnmf slabs, 2 L1 (lnmf)
 inline int mdiv(const nmfx_engine *e) { return e->div == NMFX_DIV_EUCLIDEAN_NOCOST ? NMFX_DIV_EUCLIDEAN : e->div; }
 
@@ -690,6 +711,9 @@ static nmfx_status fused_wstep_tail(nmfx_engine *e) {
         // rowsum(H) was formed by fused_wpass_finish, whose cost finisher has also written it into the tail of `packed` (tail_with_cost)
     } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
         Scope s(e, TAG_GRAM);
+        if (small_mm_on() && gram_mode() == 2) TRY(gram_fused(e, e->H, e->n, e->packed + mKT));
+        else if (small_mm_on() && gram_mode() == 1) TRY(gram_rc(e->st, e->H, e->K, e->K, e->H, e->K, e->K, e->n, e->packed + mKT, e->gemm_scratch, e->gemm_scratch_bytes));
+        else
         TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                        OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
     }
@@ -821,10 +845,17 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) {
         if (e->all_fixH) return NMFX_OK;
-        if (e->div == NMFX_DIV_EUCLIDEAN) {   // W'*V_hat = (W'*W)*H   
+        // euclidean: W'*V_hat = (W'*W)*H.  W'*W from the transposed copy of W (rows of W contiguous: every MFMA operand one coalesced load);
+        // the product with H is folded into the H update (small_mm.hip), except for constrainednmf, whose update sums over label segments first
+        const bool hug = e->div == NMFX_DIV_EUCLIDEAN && e->algo != 3 && small_mm_on() && h_update_gram_supported(e->K);
+        if (e->div == NMFX_DIV_EUCLIDEAN) {
             Scope s(e, TAG_GRAM);
+            if (small_mm_on() && gram_mode() == 2) TRY(gram_fused(e, e->WT, e->m, e->GW));
+            else if (small_mm_on() && gram_mode() == 1) TRY(gram_rc(e->st, e->WT, e->K, e->K, e->WT, e->K, e->K, e->m, e->GW, e->gemm_scratch, e->gemm_scratch_bytes));
+            else
             TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                            OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->GW, e->K));
+            if (!hug)
             TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                            OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Gp, e->K));
         }
@@ -856,10 +887,14 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             }
             Scope s(e, TAG_SMALL);
             const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
+            if (hug) {
+                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, g.slab_stride, e->K, e->n, e->lamH, e->fixH));
+            } else {
             if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, g.slab_stride, g.slab_stride, e->Gn, 0));
             if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, e->isplit_h, g.slab_stride));
             else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
             else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+            }
         } else if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
             // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
@@ -874,9 +909,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
             }
             Scope s(e, TAG_SMALL);
-            if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+            if (hug) { TRY(h_update_gram(e->st, e->H, e->GW, e->Gn, 1, 0, e->K, e->n, e->lamH, e->fixH)); }
+            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
             else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
-        } else if (e->isplit_h == 1 && e->algo != 3) {
+        } else if (e->isplit_h == 1 && e->algo != 3 && !hug) {
             f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
@@ -903,11 +939,15 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             }
             Scope s(e, TAG_SMALL);
             const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
-            if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
-            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f,
-                                       e->isplit_h, f.slab_stride));
-            else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
-            else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
+            if (hug) {
+                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, f.slab_stride, e->K, e->n, e->lamH, e->fixH));
+            } else {
+                if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
+                if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f,
+                                           e->isplit_h, f.slab_stride));
+                else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
+                else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
+            }
         }
         e->cost_valid = false;
         return NMFX_OK;
@@ -1087,7 +1127,7 @@ nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_
 
 // ---- profiling: hipEvent pairs around every launch group, on the engine's stream -----------------
 nmfx_status nmfx_engine_profile(nmfx_engine *e, int32_t enable) {   // 0 off | 1 every launch group | 2 the MFMA launch groups only
-    e->prof.skip_tag = enable == 2 ? (int)TAG_SMALL : -1;
+    e->prof.skip_mask = enable == 2 ? ((1u << TAG_SMALL) | (1u << TAG_GRAM)) : 0u;   // level 2: the big passes only
     e->prof.enable(enable != 0);
     return NMFX_OK;
 }

@@ -135,6 +135,14 @@ bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of 
 // func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128) | 6 R=S-V + euclidean cost (do_g2, slabs out);  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
+// ---- small products of the Gram form (small_mm.hip) ----------------------------------------------------------------------
+size_t gram_rc_scratch_bytes(int K1, int K2, long n);
+nmfx_status gram_rc(hipStream_t st, const float *A, long lda, int K1, const float *B, long ldb, int K2, long n, float *C, void *scratch, size_t scratch_bytes,
+                    long b_tshift = 0, int b_tblk = 0);
+bool h_update_gram_supported(int K);
+nmfx_status h_update_gram(hipStream_t st, float *H, const float *G, const float *Gn, int n_slabs, long slab_stride, int K, long n, const float *lam,
+                          const uint8_t *fix);
+
 // ---- small kernels (aux.hip) ----------------------------------------------------------------
 nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out,
                          int accumulate);
