@@ -245,6 +245,17 @@ nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost);
 /* enqueue an 8-byte device-to-device copy of that cost into dst_dev on the engine's stream */
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev);
 nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0);
+/* Where the cost of iteration i becomes available: 0 after hstep(i); 1 after wstep_partial(i+1) (fused KL passes: a by-product of the next
+ * W-step pass); 2 after wstep_finish(i+1) (euclidean fused path: the cost in Gram form, 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')>, out of the
+ * column sums the W update forms anyway -- nmf.m:149-150's diagonal terms -- so the W-step pass needs no W*H product; when the residual gets too
+ * small for fp32 to resolve that difference (cost < 5 % of 0.5*||V||^2) a device-side flag switches the explicit residual pass back on). */
+int32_t nmfx_engine_cost_lag(nmfx_engine *e);
+/* Column shards + Gram-form cost: the mode decision needs the GLOBAL ||V||^2 and must be identical on every rank.  After nmfx_engine_init,
+ * nmfx_engine_sumvv_local copies this shard's ||V_local||^2 (fp64) to dst_dev (0.0 when the engine has no such mode); the caller sums it over the
+ * ranks (one 8-byte all-reduce, once) and hands the result back with nmfx_engine_sumvv_set_global.  Until then a sharded engine -- one that was told
+ * its rank with nmfx_engine_set_rank0 -- keeps the explicit cost pass. */
+nmfx_status nmfx_engine_sumvv_local(nmfx_engine *e, double *dst_dev);
+nmfx_status nmfx_engine_sumvv_set_global(nmfx_engine *e, const double *src_dev);
 /* algorithm 3 only, before nmfx_engine_init: host segments[0..nz] (see nmfx_constrainednmf) and the DEVICE cluster matrix Z (K x nz) */
 nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *segments_host, int64_t nz, float *Z_dev);
 /* column shards without halos: everything between two all-reduces of `packed` in one call -- wstep_finish, hstep and, unless

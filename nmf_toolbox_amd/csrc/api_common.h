@@ -150,6 +150,19 @@ struct nmfx_engine {
     bool use_vtq;             // ... whose Q = W_flat'*V runs as (V'*W_flat)' on the W-step-form kernel, K-wide column blocks in grid.z
     int vtq_block;
     double *sumV, *colV;      // KL closed-form cost term: sum(V) (once) via per-column sums
+    // euclidean cost in Gram form (fused nmf path): 0.5*||V - W*H||^2 = 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')> -- every term is something the W
+    // step computes anyway (the two inner products are the "diagonal" column sums of nmf.m:149-150), so the W-step pass needs no first product
+    // W*H at all: half its MFMA work.  fp32 products resolve that difference of large numbers to the contract only while the residual is
+    // not small against V (measured: absolute error <= 3e-9*||V||^2); a device-side flag, set once cost < GRAM_COST_RATIO_MIN * 0.5*||V||^2,
+    // turns the explicit residual pass back on (conditional launch) -- deterministic, no host round trip, identical on every rank.
+    bool gram_cost;           // the engine can run in this mode (euclidean, fused, W not all fixed)
+    bool wstep_gram;          // the W step in flight runs in this mode (set by wstep_partial, read by wstep_finish)
+    bool classic;             // host-side latch: the flag has been seen set (or the caller chunks the W step): the one-pass kernel with the cost inside again
+    bool dist_seen, sumvv_global_set;   // column shards: the decision needs the GLOBAL ||V||^2 (nmfx_engine_sumvv_ptr); without it the mode stays off
+    double *sumVV;            // device [2]: ||V_local||^2, ||V_global||^2
+    double *dndp;             // device [2*K]: column sums dn = cs(W.*P), dp = cs(W.*N) of the last W update
+    int *exact_flag;          // device
+    int *exact_flag_host;     // host-mapped mirror (owned: hipHostMalloc)
     // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
     float *Z;
     long nz;

@@ -366,6 +366,23 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     const int k = c % p.K;
     float *w = p.W + p.m * c;
     if (p.fixW && p.fixW[k]) {
+        if (p.dndp && !p.stats_in) {   // fixed column: untouched, but <W, N> and <W, P> of the Gram-form cost run over every column
+            const float *pp = p.P ? p.P + p.m * c : nullptr;
+            const float pv = p.Pvec ? (float)p.Pvec[c] : (p.Pvecf ? p.Pvecf[c] : 0.0f);
+            const int nch = p.n_chunks > 1 ? p.n_chunks : 1;
+            const long cr = p.m / nch, KT = (long)p.K * p.T;
+            double dn = 0.0, dp = 0.0;
+            for (long i = threadIdx.x; i < p.m; i += 256) {
+                const long ch = i / cr;
+                const double wi = (double)w[i];
+                dn += wi * (double)(pp ? pp[i] : pv);
+                dp += wi * (double)p.N[ch * cr * KT + cr * c + (i - ch * cr)];
+            }
+            dn = block_sum<4>(dn, red);
+            dp = block_sum<4>(dp, red);
+            if (threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
+        }
+        if (p.stats_only) return;
         if (p.fuse_norm != 0 && p.colsum_out) {   // fixed column: untouched, but its sum is still part of the H-step denominator
             double cs = 0.0;
             for (long i = threadIdx.x; i < p.m; i += 256) cs += (double)w[i];
@@ -394,6 +411,8 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     if (vec) {
         const long c4n = cr / 4;
         const float4 pvv = make_float4(pv, pv, pv, pv);
+        if (p.stats_in) { dn = p.dndp[c]; dp = p.dndp[KT + c]; }
+        else {
         for (int ch = 0; ch < nch; ++ch) {
             const float4 *w4 = reinterpret_cast<const float4 *>(w + ch * cr), *n4 = reinterpret_cast<const float4 *>(p.N + ch * cr * KT + cr * c);
             const float4 *p4 = reinterpret_cast<const float4 *>(pp ? pp + ch * cr : nullptr);
@@ -405,6 +424,9 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         }
         dn = block_sum<4>(dn, red);
         dp = block_sum<4>(dp, red);
+        if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
+        if (p.stats_only) return;
+        }
         const float fdn = (float)dn, fdp = (float)dp;
         for (int ch = 0; ch < nch; ++ch) {
             float4 *w4 = reinterpret_cast<float4 *>(w + ch * cr);
@@ -421,6 +443,8 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         }
     } else {
         auto nat = [&](long i) { const long ch = i / cr; return p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
+        if (p.stats_in) { dn = p.dndp[c]; dp = p.dndp[KT + c]; }
+        else {
         for (long i = threadIdx.x; i < p.m; i += 256) {
             const float wi = w[i];
             dn += (double)wi * (double)(pp ? pp[i] : pv);
@@ -428,6 +452,9 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         }
         dn = block_sum<4>(dn, red);
         dp = block_sum<4>(dp, red);
+        if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
+        if (p.stats_only) return;
+        }
         const float fdn = (float)dn, fdp = (float)dp;
         for (long i = threadIdx.x; i < p.m; i += 256) {
             const float wn = upd(w[i], nat(i), pp ? pp[i] : pv, fdn, fdp);
@@ -462,6 +489,51 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
 }
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
     hipLaunchKernelGGL(w_update_kernel, dim3(p.K * p.T), dim3(256), 0, st, p);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+// ---- euclidean cost in Gram form -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_decide_kernel(const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag) {
+    __shared__ double red[4];
+    double sn = 0.0, sp = 0.0;
+    for (int c = threadIdx.x; c < nc; c += 256) { sn += dndp[c]; sp += dndp[nc + c]; }
+    sn = block_sum<4>(sn, red);
+    sp = block_sum<4>(sp, red);
+    if (threadIdx.x == 0 && *exact_flag == 0) {
+        const double half_vv = 0.5 * sumVV[1], data = half_vv - sp + 0.5 * sn;
+        if (!(data >= ratio_min * half_vv)) {   // (NaN lands here too)
+            *exact_flag = 1;
+            if (host_flag) __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag) {
+    hipLaunchKernelGGL(gram_decide_kernel, dim3(1), dim3(256), 0, st, dndp, nc, sumVV, ratio_min, exact_flag, host_flag);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+__global__ __launch_bounds__(256) void gram_cost_finish_kernel(const double *dndp, int nc, const double *sumVV, int rank0, const int *exact_flag, const double *partials,
+                                                               int nparts, const double *l1W, int nW, const float *lamW, const double *l1H, int K, const float *lamH,
+                                                               double *out, double *out2) {
+    __shared__ double red[4];
+    const bool exact = *exact_flag != 0;
+    double s = 0.0, t = 0.0;
+    if (exact) { for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i]; }
+    else if (rank0) { for (int c = threadIdx.x; c < nc; c += 256) s += 0.5 * dndp[c] - dndp[nc + c]; }
+    s = block_sum<4>(s, red);
+    if (l1W) for (int c = threadIdx.x; c < nW; c += 256) t += (double)lamW[c % K] * l1W[c];
+    if (l1H) for (int k = threadIdx.x; k < K; k += 256) t += (double)lamH[k] * l1H[k];
+    t = block_sum<4>(t, red);
+    if (threadIdx.x == 0) {
+        const double cst = (exact ? 0.5 * s : 0.5 * sumVV[0] + s) + t;
+        *out = cst;
+        if (out2) *out2 = cst;
+    }
+}
+nmfx_status gram_cost_finish(hipStream_t st, const double *dndp, int nc, const double *sumVV, int rank0, const int *exact_flag, const double *partials, int nparts,
+                             const double *l1W, int nW, const float *lamW, const double *l1H, int K, const float *lamH, double *out, double *out2) {
+    hipLaunchKernelGGL(gram_cost_finish_kernel, dim3(1), dim3(256), 0, st, dndp, nc, sumVV, rank0, exact_flag, partials, nparts, l1W, nW, lamW, l1H, K, lamH, out, out2);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -95,16 +95,39 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         return r->cost[idx] < r->cost[idx - 1] && r->cost[idx - 1] - r->cost[idx] < p->tolerance;
     };
     bool stopped = false;
-    const bool lag = e && (e->fused || e->fusedT_kl);
-    for (it = 0; s == NMFX_OK && it < p->maxiter; ++it) {
+    const int lagk = e ? nmfx_engine_cost_lag(e) : 0;   // where cost(it-1) turns up: 1 after wstep_partial(it), 2 after wstep_finish(it), 0: cost(it) after hstep(it)
+    const bool lag = lagk != 0;
+    DevBuf Wbak, dcost;
+    if (s == NMFX_OK && p->tolerance < 0) {
+        // stop rule disabled (NMFX extension): nothing is decided on the host, so nothing is read back per iteration -- the costs land in a device
+        // vector and come home once
+        s = dcost.alloc(sizeof(double) * p->maxiter);
+        if (s == NMFX_OK) s = nmfx_engine_iterate(e, p->maxiter, dcost.as<double>());
+        if (s == NMFX_OK && hipMemcpy(r->cost, dcost.p, sizeof(double) * p->maxiter, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cost readback failed"); s = NMFX_ERR_HIP; }
+        if (s == NMFX_OK) r->iters_run = p->maxiter;
+        it = p->maxiter;
+        stopped = true;   // (nothing left to finish below)
+    }
+    if (s == NMFX_OK && lagk == 2 && !stopped) s = Wbak.alloc(mKT * 4);
+    for (it = stopped ? p->maxiter : 0; s == NMFX_OK && it < p->maxiter; ++it) {
         if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
-        if (lag && it > 0) {
+        if (lagk == 1 && it > 0) {
             // the fused W-step pass of iteration it also yields cost(it-1); W and H are untouched until wstep_finish, so
             // stopping here returns exactly the state of iteration it-1 (the numerators just computed are discarded)
             if ((s = read_cost(it - 1)) != NMFX_OK) break;
             if (stop(it - 1)) { stopped = true; break; }
         }
+        // Gram-form cost: cost(it-1) comes out of the W update itself, which has then already moved W -- keep the old W to hand back on a stop
+        if (lagk == 2 && it > 0 && hipMemcpyAsync(Wbak.p, W.p, mKT * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("W backup failed"); s = NMFX_ERR_HIP; break; }
         if ((s = nmfx_engine_wstep_finish(e)) != NMFX_OK) break;
+        if (lagk == 2 && it > 0) {
+            if ((s = read_cost(it - 1)) != NMFX_OK) break;
+            if (stop(it - 1)) {
+                if (hipMemcpyAsync(W.p, Wbak.p, mKT * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("W restore failed"); s = NMFX_ERR_HIP; }
+                stopped = true;
+                break;
+            }
+        }
         if ((s = nmfx_engine_hstep(e)) != NMFX_OK) break;
         if (!lag) {
             if ((s = read_cost(it)) != NMFX_OK) break;
@@ -283,7 +306,26 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         else if (kd != kind) { set_error("n_gpus: shards picked different kernel paths; pass path = 1"); return NMFX_ERR_UNSUPPORTED; }
         TRY(nmfx_engine_init(M.eng[g]));
     }
-    const bool lag = kind == 1;
+    const int lagk = nmfx_engine_cost_lag(M.eng[0]);   // 1: cost(it-1) after wstep_partial(it); 2: after wstep_finish(it) (Gram-form cost); 0: cost(it) after hstep(it)
+    const bool lag = lagk != 0;
+    {   // Gram-form cost: every shard's mode decision uses the GLOBAL ||V||^2
+        double vv = 0.0, part = 0.0;
+        for (int g = 0; g < N; ++g) {
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            TRY(nmfx_engine_sumvv_local(M.eng[g], M.costh[g].as<double>()));
+            NMFX_HIP(hipMemcpyAsync(&part, M.costh[g].p, sizeof(double), hipMemcpyDeviceToHost, M.st[g]));
+            NMFX_HIP(hipStreamSynchronize(M.st[g]));
+            vv += part;
+        }
+        for (int g = 0; g < N; ++g) {
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            NMFX_HIP(hipMemcpyAsync(M.costh[g].p, &vv, sizeof(double), hipMemcpyHostToDevice, M.st[g]));
+            TRY(nmfx_engine_sumvv_set_global(M.eng[g], M.costh[g].as<double>()));
+            NMFX_HIP(hipStreamSynchronize(M.st[g]));   // vv is a stack variable
+        }
+    }
+    DevBuf Wbak;   // Gram-form cost + stop rule: device 0's W as it was before the update that produced cost(it-1)
+    if (lagk == 2 && p->tolerance >= 0) { NMFX_HIP(hipSetDevice(M.dev[0])); TRY(Wbak.alloc(mK * 4)); }
     std::vector<double> hc(N);
     auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
         for (int g = 0; g < N; ++g) {
@@ -305,12 +347,23 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     bool stopped = false;
     for (int it = 0; it < p->maxiter; ++it) {
         for (int g = 0; g < N; ++g) TRY(nmfx_engine_wstep_partial(M.eng[g]));
-        if (lag && it > 0) {
+        if (lagk == 1 && it > 0) {
             TRY(read_cost(it - 1));
             if (stop(it - 1)) { stopped = true; break; }
         }
         TRY(multi_allreduce(M, packed_count));
-        for (int g = 0; g < N; ++g) { TRY(nmfx_engine_wstep_finish(M.eng[g])); TRY(nmfx_engine_hstep(M.eng[g])); }
+        if (lagk == 2 && it > 0 && Wbak.p) { NMFX_HIP(hipSetDevice(M.dev[0])); NMFX_HIP(hipMemcpyAsync(Wbak.p, M.W[0].p, mK * 4, hipMemcpyDeviceToDevice, M.st[0])); }
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_wstep_finish(M.eng[g]));
+        if (lagk == 2 && it > 0 && p->tolerance >= 0) {
+            TRY(read_cost(it - 1));
+            if (stop(it - 1)) {   // the W that is handed back (device 0's replica) as it was when iteration it-1 ended; H has not moved yet
+                NMFX_HIP(hipSetDevice(M.dev[0]));
+                NMFX_HIP(hipMemcpyAsync(M.W[0].p, Wbak.p, mK * 4, hipMemcpyDeviceToDevice, M.st[0]));
+                stopped = true;
+                break;
+            }
+        } else if (lagk == 2 && it > 0) TRY(read_cost(it - 1));
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_hstep(M.eng[g]));
         if (!lag) {
             TRY(read_cost(it));
             if (stop(it)) { stopped = true; break; }

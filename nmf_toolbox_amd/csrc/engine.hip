@@ -114,6 +114,9 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumV = f.take<double>(1);
         e->sumVab = f.take<double>(1);
         e->colV = f.take<double>(e->n);
+        e->sumVV = f.take<double>(2);
+        e->dndp = f.take<double>(2 * (size_t)e->K);
+        e->exact_flag = f.take<int>(16);
         L.total = f.off;
         L.packed_count = e->dual ? 2 * mKT : (euc ? mKT + (size_t)e->K * e->K : mKT + (size_t)e->KT);
         return L;
@@ -219,6 +222,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     e->fused = eligible && d->path != 1;
     if (!e->fused) e->dual = false;
+    static const bool exact_cost_env = getenv("NMFX_EXACT_COST") != nullptr;   // dev switch (A/B runs): always the explicit residual inside the W-step pass
+    e->gram_cost = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !e->dual && !exact_cost_env;
     static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
     // the transposed copy of V (euclidean paths) is a luxury: only where the device clearly has the room for it next to V
     // itself (V may or may not be allocated yet at this point: 2.5 x its size + 1 GiB must be free either way)
@@ -426,9 +431,20 @@ int fused_split(long blocks, long extent, int K, long *c_per_split) {
 
 namespace {
 
+constexpr double GRAM_COST_RATIO_MIN = 0.05;   // cost / (0.5*||V||^2) below which the explicit residual pass takes over (error bound there: 3e-9*2/0.05 = 1.2e-7 relative)
+// is THIS W step in Gram-cost mode?  Host-side and the same on every rank: capability, not latched to classic, and (on shards) the global norm known
+inline bool gram_active(nmfx_engine *e) {
+    if (!e->gram_cost || e->classic) return false;
+    if (e->dist_seen && !e->sumvv_global_set) return false;
+    if (__atomic_load_n(e->exact_flag_host, __ATOMIC_ACQUIRE) != 0) { e->classic = true; return false; }   // lazily seen: from now on the one-pass kernel with the cost inside
+    return true;
+}
+
 // fused W-step pass (K2) or cost-only pass over rows [row0, row0 + rows) of the local shard.  N of those rows goes to `out`
 // as a contiguous rows x K block; cost partials are appended at e->chunk_parts.
-nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out) {
+// no_cost: euclidean numerators only (R = V, no first product): the cost comes in Gram form from the W update that follows.
+// run_if: conditional cost-only launch (see FusedParams.run_if)
+nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, float *out, bool no_cost = false, const int *run_if = nullptr) {
     long cps = 0;
     const long blocks = (rows + 127) / 128;
     const int split = fused_split(blocks, e->n, e->K, &cps);
@@ -444,7 +460,8 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
     f.out = split == 1 ? out : e->slabs;
     f.slab_stride = rows * (long)e->K; f.os_r = 1; f.os_k = rows;
     f.cost_partials = e->cost_partials + e->chunk_parts;
-    int func = e->div == NMFX_DIV_KL ? 3 : 1;
+    f.run_if = run_if;
+    int func = e->div == NMFX_DIV_KL ? 3 : (no_cost ? 0 : 1);
     float *out2 = nullptr;
     if (e->dual) {   // IS / alpha-beta: the denominators come out of the same pass, into the second half of `packed`
         if (rows != e->m) { set_error("fused IS / alpha-beta W step: row chunks are not supported"); return NMFX_ERR_UNSUPPORTED; }
@@ -455,7 +472,7 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
         if (e->Valpha) f.D = e->Valpha + row0;
     }
     {
-        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));   // (a conditional launch is a no-op most of the time: not worth an event pair)
         TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
     }
     e->chunk_parts += (int)(blocks * split);
@@ -478,6 +495,11 @@ nmfx_status fused_wpass_finish(nmfx_engine *e) {
 nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
     e->chunk_parts = 0;
     e->tail_with_cost = do_g2;   // a W-step partial: the cost finisher also fills the fp32 tail [rowsum(H)] of `packed`
+    e->wstep_gram = do_g2 && gram_active(e);
+    if (e->wstep_gram) {         // numerators only; the cost of the state this step starts from follows in wstep_finish (Gram form)
+        e->cost_valid = false;
+        return fused_wpass_rows(e, true, 0, e->m, e->packed, true);
+    }
     TRY(fused_wpass_rows(e, do_g2, 0, e->m, e->packed));
     return fused_wpass_finish(e);
 }
@@ -614,6 +636,12 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     if (he == hipSuccess) he = hipMemcpyAsync(e->fixH, fh.data(), e->K, hipMemcpyHostToDevice, e->st);
     if (he == hipSuccess) he = hipStreamSynchronize(e->st);  // host vectors go out of scope
     if (he != hipSuccess) { set_error("nmfx_engine_create: %s", hipGetErrorString(he)); delete e; return NMFX_ERR_HIP; }
+    if (e->all_fixW) e->gram_cost = false;   // no W update, no column statistics
+    if (e->gram_cost) {
+        he = hipHostMalloc(reinterpret_cast<void **>(&e->exact_flag_host), 64, hipHostMallocMapped | hipHostMallocPortable);
+        if (he != hipSuccess) { (void)hipGetLastError(); e->exact_flag_host = nullptr; e->gram_cost = false; }
+        else *e->exact_flag_host = 0;
+    }
     *out = e;
     return NMFX_OK;
 }
@@ -621,6 +649,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
 void nmfx_engine_destroy(nmfx_engine *e) {
     if (!e) return;
     if (e->seg_dev) (void)hipFree(e->seg_dev);
+    if (e->exact_flag_host) (void)hipHostFree(e->exact_flag_host);
     e->prof.release();
     delete e;
 }
@@ -644,7 +673,23 @@ nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *seg_host, 
     return NMFX_OK;
 }
 
-nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 = is_rank0; return NMFX_OK; }
+nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0) { e->rank0 = is_rank0; e->dist_seen = true; return NMFX_OK; }   // (only sharded callers say which rank they are)
+// Column shards + Gram-form cost: the mode decision needs the GLOBAL ||V||^2 and must be identical on every rank.  After nmfx_engine_init,
+// nmfx_engine_sumvv_local copies this shard's ||V_local||^2 (fp64) to dst_dev (0.0 when the engine has no such mode); the caller sums over the
+// ranks (one 8-byte all-reduce, once) and hands the result back with nmfx_engine_sumvv_set_global.  Until then a sharded engine keeps the explicit pass.
+nmfx_status nmfx_engine_sumvv_local(nmfx_engine *e, double *dst_dev) {
+    if (e->gram_cost) NMFX_HIP(hipMemcpyAsync(dst_dev, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    else NMFX_HIP(hipMemsetAsync(dst_dev, 0, sizeof(double), e->st));
+    return NMFX_OK;
+}
+nmfx_status nmfx_engine_sumvv_set_global(nmfx_engine *e, const double *src_dev) {
+    if (e->gram_cost) NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, src_dev, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+    e->sumvv_global_set = true;
+    return NMFX_OK;
+}
+// 0: the cost of iteration i is ready after hstep(i); 1: after wstep_partial(i+1); 2: after wstep_finish(i+1) (read it there; engines of kind 2
+// may also deliver it at point 1 -- reading at point 2 is always right for them)
+int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl) ? 1 : 0); }
 
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
 nmfx_status nmfx_engine_init(nmfx_engine *e) {
@@ -666,6 +711,14 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             if (e->div == NMFX_DIV_KL) {   // sum(V_local), once
                 TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumV));
+            }
+            if (e->gram_cost) {            // ||V_local||^2, once; the global norm defaults to it (one shard)
+                TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 1, e->colV));
+                TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
+                NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+                NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
+                *e->exact_flag_host = 0;
+                e->classic = false;
             }
             if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
                 TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
@@ -729,7 +782,12 @@ nmfx_status nmfx_engine_wstep_partial_chunk(nmfx_engine *e, int32_t chunk, int32
     if (!e->fused || e->dual) { set_error("nmfx_engine_wstep_partial_chunk: fused kl / euclidean path only"); return NMFX_ERR_UNSUPPORTED; }
     if (nchunks < 1 || chunk < 0 || chunk >= nchunks || e->m % (128L * nchunks) != 0) { set_error("nmfx_engine_wstep_partial_chunk: m must split into nchunks multiples of 128 rows"); return NMFX_ERR_INVALID; }
     const long rows = e->m / nchunks;
-    if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; }
+    if (chunk == 0) { e->chunk_parts = 0; e->w_chunks = nchunks; e->cost_valid = false; e->wstep_gram = false; }
+    if (chunk == 0 && e->gram_cost && !e->classic) {   // row chunks carry their cost inside: the Gram-form mode is switched off for good (every rank chunks alike)
+        static const int one = 1;
+        NMFX_HIP(hipMemcpyAsync(e->exact_flag, &one, sizeof(int), hipMemcpyHostToDevice, e->st));
+        e->classic = true;
+    }
     TRY(fused_wpass_rows(e, true, rows * chunk, rows, e->packed + (size_t)chunk * rows * e->K));
     if (chunk + 1 < nchunks) return NMFX_OK;
     e->tail_with_cost = true;
@@ -806,11 +864,37 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
                            OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
             p.P = e->Pbuf;
         }
-        Scope s(e, TAG_SMALL);
         p.rule = e->algo == 2 ? 1 : 0;
         // update, column normalisation (nmf.m:169 / lnmf.m:70) and, for KL, the column sums of the final W (H-step denominator) in ONE launch
         p.fuse_norm = norm_mode(e) == 2 ? 2 : 1;
         p.colsum_out = e->div == NMFX_DIV_KL ? e->Gpvec : nullptr;
+        if (e->wstep_gram) {
+            // Gram-form cost of the state this W step started from (W, H untouched so far).  Column statistics first, then the decision, then -- only
+            // once the residual has become too small for fp32 to resolve it this way -- the explicit residual pass, and only then the update.
+            const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+            {
+                Scope s(e, TAG_SMALL);
+                if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 2, e->l1W));
+                if (useH) {
+                    if (e->algo == 3) TRY(row_reduce(e->st, e->Z, e->K, e->K, e->nz, 2, e->l1H, e->rr_scratch));
+                    else TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+                }
+                p.dndp = e->dndp; p.stats_only = 1;
+                TRY(w_update(e->st, p));
+                TRY(gram_decide(e->st, e->dndp, e->K, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host));
+            }
+            e->chunk_parts = 0;
+            TRY(fused_wpass_rows(e, false, 0, e->m, nullptr, false, e->exact_flag));   // returns at once while the flag is clear
+            Scope s(e, TAG_SMALL);
+            TRY(gram_cost_finish(e->st, e->dndp, e->K, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->chunk_parts, useW ? e->l1W : nullptr, e->K, e->lamW,
+                                 useH ? e->l1H : nullptr, e->K, e->lamH, e->cost, e->cost_dst2));
+            if (e->cost_dst2) e->cost_dst2_done = true;
+            p.stats_only = 0; p.stats_in = 1;
+            TRY(w_update(e->st, p));
+            e->cost_valid = false;
+            return refresh_w_derived(e, true);
+        }
+        Scope s(e, TAG_SMALL);
         TRY(w_update(e->st, p));
         e->cost_valid = false;
         return refresh_w_derived(e, true);
@@ -1107,9 +1191,11 @@ nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_
         // straight into the caller's vector (no separate 8-byte copy)
         e->cost_dst2 = (lag && it > 0 && dev_cost_out) ? dev_cost_out + it - 1 : nullptr;
         nmfx_status ws_ = nmfx_engine_wstep_partial(e);
+        if (!e->wstep_gram) e->cost_dst2 = nullptr;   // Gram-form cost: the finisher runs inside wstep_finish
+        TRY(ws_);
+        ws_ = nmfx_engine_wstep_finish(e);
         e->cost_dst2 = nullptr;
         TRY(ws_);
-        TRY(nmfx_engine_wstep_finish(e));
         // un-lagged paths: the cost of this iteration is finished inside the H step; its finisher writes the caller's slot too
         e->cost_dst2 = (!lag && dev_cost_out) ? dev_cost_out + it : nullptr;
         e->cost_dst2_done = false;
@@ -1155,6 +1241,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
         if (e->fusedT || e->fusedT_kl) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
+        if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
     case TAG_FUSED_H: *flops = (e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;

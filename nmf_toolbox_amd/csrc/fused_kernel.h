@@ -41,6 +41,7 @@ template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, int PROBE = 0, bool R
 __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)) void fused_kernel(const FusedParams p) {   // K <= 128 fits two workgroups per CU (256 VGPRs, 2 x 68 KB LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(TT == 1 || (D_RC && EPI == 0 && (K / TT) % 32 == 0 && K % TT == 0), "TT > 1: W-step form, K/TT a multiple of 32");
+    if (p.run_if && *p.run_if == 0) return;   // conditional launch (the explicit cost pass behind the Gram-form cost): uniform, one scalar load
     constexpr int KH = K / TT;             // floats per column of H
     constexpr int LDY = KH + 4;            // LDS row stride (one column of H per row)
     constexpr int NKB = K / 32;

@@ -129,6 +129,7 @@ struct FusedParams {
     const float *lam;     // [K] or nullptr
     const uint8_t *fix;   // [K] or nullptr
     int sqrt_rule;        // EPI 1: H <- sqrt(H .* G)   (lnmf.m:76) instead of the ratio update
+    const int *run_if;    // when set: every workgroup returns at once unless *run_if != 0 (a device-side decision, no host round trip)
 };
 bool fused_supported(int K);
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
@@ -169,8 +170,18 @@ struct WUpdateParams {
     int fuse_norm;       // 0: leave the columns un-normalised (w_normalize follows).  1 / 2 (T == 1 only): also apply nmf.m:169 (L2) / lnmf.m:70 (L1)
                          // to the column in a third sweep of the same workgroup -- one launch and one pass over W fewer
     double *colsum_out;  // with fuse_norm != 0: [K] column sums of the FINAL W, fixed columns included (KL H-step denominator, nmf.m:184), or nullptr
+    double *dndp;        // [2*K*T] or nullptr: dn[c] = sum_i W.*P and dp[c] = sum_i W.*N of column c (fixed columns included).  stats_only: the kernel
+    int stats_only;      // writes them and returns (w_stats); stats_in: it reads them instead of summing (the update half of a split W update)
+    int stats_in;
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
+// Euclidean cost in Gram form, from the column statistics of the W update:  0.5*||V - W*H||^2 = 0.5*sumVV - sum(dp) + 0.5*sum(dn).
+// gram_decide: sets *exact_flag (sticky; mirrored into the host-mapped *host_flag when given) once that value drops below ratio_min * 0.5*sumVV[1]
+// -- below it fp32 products no longer resolve the cost to the contract and the explicit residual pass takes over (launched with run_if = exact_flag).
+nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag);
+// cost = (*exact_flag ? 0.5*sum(partials) : 0.5*sumVV[0] + (rank0 ? 0.5*sum(dn) - sum(dp) : 0)) + lambda terms     -> out, out2
+nmfx_status gram_cost_finish(hipStream_t st, const double *dndp, int nc, const double *sumVV, int rank0, const int *exact_flag, const double *partials, int nparts,
+                             const double *l1W, int nW, const float *lamW, const double *l1H, int K, const float *lamH, double *out, double *out2);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
                         double *f_out, int kvalid = 0);
 constexpr int NMFX_MAX_GPUS = 16;

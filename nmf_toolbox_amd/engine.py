@@ -55,6 +55,7 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
     i+1; the last one needs backend.cost_pass().
     """
     lag = bool(getattr(backend, "cost_lags", False))
+    lagk = int(getattr(backend, "cost_lag", 1 if lag else 0))   # 2: the lagged cost comes out of wstep_finish (Gram-form cost), not of wstep_partial
 
     def emit(idx):
         backend._copy_cost(cost_out[idx:idx + 1])
@@ -66,7 +67,7 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
             # one host call per iteration next to the collective: [wstep_finish, hstep, next wstep_partial] is a single C entry point
             if it == 0:
                 backend.wstep_partial()
-            if lag and it > 0 and cost_out is not None:
+            if lagk == 1 and it > 0 and cost_out is not None:
                 emit(it - 1)
             ev = getattr(backend, "comm_events", None)
             if ev is not None:
@@ -77,6 +78,8 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
                 b.record()
                 ev.append((a, b))
             backend.between_allreduces(it == iters - 1)
+            if lagk == 2 and it > 0 and cost_out is not None:
+                emit(it - 1)                                  # (the next wstep_partial inside between_allreduces leaves the engine's cost alone in this mode)
             if not lag and cost_out is not None:
                 emit(it)
             continue
@@ -88,12 +91,12 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
                 backend.wstep_partial_chunk(c, nch)
                 works.append(dist.all_reduce(backend.packed_chunk(c, nch), group=group, async_op=True))
             if lag and it > 0 and cost_out is not None:
-                emit(it - 1)
+                emit(it - 1)                                  # (row chunks carry their cost inside the pass: always available here)
             for w in works:
                 w.wait()
         else:
             backend.wstep_partial()
-            if lag and it > 0 and cost_out is not None:
+            if lagk == 1 and it > 0 and cost_out is not None:
                 emit(it - 1)
             ev = getattr(backend, "comm_events", None)        # measurement hook: how long the compute stream stalls on the exchange
             if ev is not None:
@@ -104,6 +107,8 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
                 b.record()
                 ev.append((a, b))
         backend.wstep_finish()
+        if lagk == 2 and nch == 1 and it > 0 and cost_out is not None:
+            emit(it - 1)
         backend.hstep()
         if getattr(backend, "has_halos", False):
             backend.exchange_halos()                          # cnmf only: T-1 columns of H to each neighbour ...
@@ -169,7 +174,8 @@ class Engine:
         _lib.check(self.lib.nmfx_engine_set_rank0(self.h, 1 if self.rank == 0 else 0))
         self._cost_t = torch.zeros(1, dtype=torch.float64, device=self.V.device)
         self.path_kind = int(self.lib.nmfx_engine_is_fused(self.h))
-        self.cost_lags = self.path_kind in (1, 4)         # the cost of iteration i is a by-product of the first pass of iteration i+1
+        self.cost_lag = int(self.lib.nmfx_engine_cost_lag(self.h))   # cost of iteration i: 0 after hstep(i), 1 after wstep_partial(i+1), 2 after wstep_finish(i+1)
+        self.cost_lags = self.cost_lag != 0
         # row chunks of the W-step partial on column shards (all-reduce of chunk c overlapping the compute of chunk c+1): fused
         # path, m a multiple of 128*n_chunks.  Off (1) unless asked for: the K = 256 kernels fill every CU (one 512-VGPR wave per
         # SIMD, 256 workgroups), so a concurrent RCCL kernel can only run by displacing compute workgroups -- whether the overlap
@@ -190,6 +196,13 @@ class Engine:
 
     def init(self):
         _lib.check(self.lib.nmfx_engine_init(self.h))
+        # euclidean fused path: the cost in Gram form needs the GLOBAL ||V||^2 for its (rank-independent) mode decision: one 8-byte all-reduce, once
+        vv = self.torch.zeros(1, dtype=self.torch.float64, device=self.V.device)
+        _lib.check(self.lib.nmfx_engine_sumvv_local(self.h, vv.data_ptr()))
+        if self.dist is not None:
+            self.dist.all_reduce(vv, group=self.group)
+        _lib.check(self.lib.nmfx_engine_sumvv_set_global(self.h, vv.data_ptr()))
+        self.torch.cuda.current_stream(self.V.device).synchronize()    # vv goes out of scope
 
     # ---- the four phases (HIP kernels on this rank's shard) -------------------------------------
     def wstep_partial(self):

@@ -24,6 +24,15 @@ def _engines(torch, V, W0, H0, div, parts, path):
         _lib.check(e.lib.nmfx_engine_set_rank0(e.h, 1 if r == 0 else 0))
         e.init()
         engs.append(e)
+    # Gram-form cost of the euclidean fused path: its (rank-independent) mode decision wants the GLOBAL ||V||^2 -- what Engine.init all-reduces
+    # under torch.distributed is summed by hand here
+    vv = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in engs]
+    for e, t in zip(engs, vv):
+        _lib.check(e.lib.nmfx_engine_sumvv_local(e.h, t.data_ptr()))
+    tot = sum(vv)
+    for e in engs:
+        _lib.check(e.lib.nmfx_engine_sumvv_set_global(e.h, tot.data_ptr()))
+    torch.cuda.synchronize()
     return engs
 
 
@@ -31,6 +40,7 @@ def _run_emulated(torch, engs, iters, nch=1):
     """run_sharded_iterations with all_reduce == explicit sum over the engines of this process (nch > 1: row-chunked W step)"""
     costs = []
     lag = engs[0].cost_lags
+    lagk = engs[0].cost_lag          # 1: cost(it-1) is ready after wstep_partial(it); 2: after wstep_finish(it) (Gram-form cost)
 
     def total_cost():
         c = 0.0
@@ -57,10 +67,13 @@ def _run_emulated(torch, engs, iters, nch=1):
                 s += e.packed
             for e in engs:
                 e.packed.copy_(s)
-        if lag and it > 0:
+        if lag and it > 0 and (lagk == 1 or nch > 1):
             costs.append(total_cost())
         for e in engs:
             e.wstep_finish()
+        if lagk == 2 and nch == 1 and it > 0:
+            costs.append(total_cost())
+        for e in engs:
             e.hstep()
         if not lag:
             costs.append(total_cost())
@@ -220,6 +233,15 @@ def _cnmf_shard_engines(torch, V, W0, H0, div, T, parts, path=0):
         _lib.check(e.lib.nmfx_engine_set_rank0(e.h, 1 if r == 0 else 0))
         e.init()
         engs.append(e)
+    # Gram-form cost of the euclidean fused path: its (rank-independent) mode decision wants the GLOBAL ||V||^2 -- what Engine.init all-reduces
+    # under torch.distributed is summed by hand here
+    vv = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in engs]
+    for e, t in zip(engs, vv):
+        _lib.check(e.lib.nmfx_engine_sumvv_local(e.h, t.data_ptr()))
+    tot = sum(vv)
+    for e in engs:
+        _lib.check(e.lib.nmfx_engine_sumvv_set_global(e.h, tot.data_ptr()))
+    torch.cuda.synchronize()
     return engs
 
 
