@@ -204,6 +204,9 @@ typedef struct {
     int32_t K_valid;          /* 0 = all K_total components are real.  Otherwise components k >= K_valid are zero padding (zero
                                  columns of W / rows of H, marked fixed by the caller) that only rounds K up to a kernel-friendly
                                  size: they contribute exact zeros everywhere and are skipped by the initial normalisation */
+    int32_t flags;            /* bit 0: no transposed copy of V (euclidean paths keep V' = n x m next to V and run their H-step numerators on it; set the
+                                 bit to give those m*n*4 bytes back at ~10 % of the iteration rate).  Every rank of a sharded run must pass the same
+                                 flags: the kernel path, and with it the summation order, follows from the descriptor alone */
 } nmfx_engine_desc;
 
 /* bytes of device scratch the engine needs (caller allocates: torch tensor / hipMalloc) */

@@ -61,7 +61,7 @@ class EngineDesc(C.Structure):
         ("alpha", C.c_double), ("beta", C.c_double),
         ("lamW_col", C.c_void_p), ("lamH_row", C.c_void_p), ("fixW_col", C.c_void_p), ("fixH_row", C.c_void_p),
         ("device", C.c_int32), ("stream", C.c_void_p), ("col_offset", C.c_int64), ("path", C.c_int32),
-        ("halo_left", C.c_int32), ("halo_right", C.c_int32), ("n_valid", C.c_int64), ("algorithm", C.c_int32), ("K_valid", C.c_int32),
+        ("halo_left", C.c_int32), ("halo_right", C.c_int32), ("n_valid", C.c_int64), ("algorithm", C.c_int32), ("K_valid", C.c_int32), ("flags", C.c_int32),
     ]
 
 

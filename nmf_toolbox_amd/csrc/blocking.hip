@@ -51,7 +51,13 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     TRY(nmfx_engine_packed_count(&d, &packed_count));
     const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
     DevBuf V, W, H, Z, ws, packed;
-    TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(ws.alloc(ws_bytes)); TRY(packed.alloc(packed_count * 4));
+    TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(packed.alloc(packed_count * 4));
+    if (ws.alloc(ws_bytes) != NMFX_OK) {   // no room for the workspace with the transposed copy of V: the same problem without it (said in the descriptor, not guessed)
+        (void)hipGetLastError();
+        d.flags |= 1;
+        TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
+        TRY(ws.alloc(ws_bytes));
+    }
     hipStream_t st = nullptr;
     IoStats &io = io_stats();
     io = IoStats{};

@@ -139,6 +139,12 @@ Layout layout(nmfx_engine *e, void *ws) {
             if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
         }
     }
+    if (e->gram_cost) {   // (cnmf on the fused passes)
+        e->sumVV = c.take<double>(2);
+        e->dndp = c.take<double>(2 * (size_t)e->KT);
+        e->exact_flag = c.take<int>(16);
+        e->colV = c.take<double>(e->n);
+    }
     if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
     if (e->use_vtq) { e->VT = c.take<float>((size_t)e->m * e->n); e->WTf = c.take<float>(mKT); }
     if (e->fusedT_kl) {
@@ -225,16 +231,10 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     static const bool exact_cost_env = getenv("NMFX_EXACT_COST") != nullptr;   // dev switch (A/B runs): always the explicit residual inside the W-step pass
     e->gram_cost = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !e->dual && !exact_cost_env;
     static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
-    // the transposed copy of V (euclidean paths) is a luxury: only where the device clearly has the room for it next to V
-    // itself (V may or may not be allocated yet at this point: 2.5 x its size + 1 GiB must be free either way)
-    bool room_vt = true;
-    {
-        size_t free_b = 0, total_b = 0;
-        DeviceGuard dg_;
-        if (hipSetDevice(d->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            room_vt = (double)free_b >= 2.5 * 4.0 * (double)e->m * (double)e->n + (double)(1ull << 30);
-        (void)hipGetLastError();
-    }
+    // the transposed copy of V (euclidean paths) is asked for unless the caller says no (nmfx_engine_desc.flags bit 0): the choice of
+    // kernel -- and with it the summation order -- must not depend on how much memory happens to be free (run-to-run and rank-to-rank reproducibility).
+    // A caller that cannot allocate the workspace with the copy retries with the flag set (the blocking API does).
+    const bool room_vt = (d->flags & 1) == 0;
     e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt && room_vt;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
@@ -250,6 +250,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
     static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
     e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
+    // cnmf on the fused passes, unsharded: the same Gram-form cost (its explicit residual pass is a third of the iteration)
+    if (e->fusedT && e->div == NMFX_DIV_EUCLIDEAN && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && !exact_cost_env) e->gram_cost = true;
     static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
     e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
     {   // euclidean cnmf on the fused passes, unsharded: the Q product of the H step on a transposed copy of V (see nmfx_engine_hstep)
@@ -514,7 +516,7 @@ nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-
     e->hpad_valid = true;
     return NMFX_OK;
 }
-nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out) {
+nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if = nullptr) {
     const bool do_g2 = mode == FT_NUM;
     const float *Hy = e->H;
     if (e->hL < e->T - 1) {
@@ -532,9 +534,10 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out) {
     f.out = e->nsplit_T == 1 ? out : e->slabsT;
     f.slab_stride = mKT; f.os_r = 1; f.os_k = e->m; f.os_t = e->m * (long)e->K;
     f.cost_partials = do_g2 ? nullptr : e->cost_partials;
+    f.run_if = run_if;
     const int func = mode == FT_NUM ? 0 : (mode == FT_COST_EUC ? 1 : 3);
     {
-        Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+        Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));
         TRY(launch_fused(e->st, f, e->nsplit_T, true, func, do_g2, 0));
     }
     if (do_g2 && e->nsplit_T > 1) {
@@ -730,6 +733,16 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
     }
     if (e->gram) {                 // no V_hat state on the Gram path
         if (e->use_vtq) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+        if (e->gram_cost) {        // ||V||^2, once
+            Scope s(e, TAG_SMALL);
+            TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 1, e->colV));
+            TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
+            NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
+            NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
+            *e->exact_flag_host = 0;
+            e->classic = false;
+            e->cost_valid = false;
+        }
         return NMFX_OK;
     }
     if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
@@ -813,6 +826,8 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
         TRY(fusedT_kl_cost(e));
     }
+    e->wstep_gram = e->fusedT && e->gram_cost;   // the cost of the state this step starts from follows in wstep_finish (no host latch here: once the device flag
+                                                 // is set the conditional residual pass simply runs every time -- the same work the un-lagged cost pass was)
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
@@ -915,8 +930,22 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             p.Pvec = e->Pvec;
         }
         p.rule = e->algo == 2 ? 1 : 0;
+        if (e->wstep_gram) {   // Gram-form cost of the state this W step started from: statistics, decision, (conditional) residual pass, cost -- then the update
+            const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
+            if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
+            if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
+            p.dndp = e->dndp; p.stats_only = 1;
+            TRY(w_update(e->st, p));
+            TRY(gram_decide(e->st, e->dndp, e->KT, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host));
+            TRY(fusedT_pass(e, FT_COST_EUC, nullptr, e->exact_flag));
+            TRY(gram_cost_finish(e->st, e->dndp, e->KT, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->n_cost_used, useW ? e->l1W : nullptr, e->KT, e->lamW,
+                                 useH ? e->l1H : nullptr, e->K, e->lamH, e->cost, e->cost_dst2));
+            if (e->cost_dst2) e->cost_dst2_done = true;
+            p.stats_only = 0; p.stats_in = 1;
+        }
         TRY(w_update(e->st, p));
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
+        e->cost_valid = false;
     }
     if (e->gram || e->fusedT_kl) return NMFX_OK;
     return recon(e, false);
@@ -1146,6 +1175,7 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     if (e->fusedT_kl) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
     if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
     else TRY(recon(e, !nocost));
@@ -1163,6 +1193,12 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     if (e->cost_valid) return NMFX_OK;
     if (e->fused) return fused_wpass(e, false);
     if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
+    if (e->fusedT && e->gram_cost) {
+        TRY(fusedT_pass(e, FT_COST_EUC, nullptr));
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = true;
+        return cost_from_partials(e, e->n_cost_used);
+    }
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
@@ -1185,7 +1221,7 @@ nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
 }
 
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
-    const bool lag = e->fused || e->fusedT_kl;   // the cost of iteration i is a by-product of the first pass of iteration i+1
+    const bool lag = nmfx_engine_cost_lag(e) != 0;   // the cost of iteration i is a by-product of iteration i+1's W step
     for (int it = 0; it < iters; ++it) {
         // fused path: the W-step pass also produces the cost of the state it starts from, i.e. of iteration it-1; its finisher writes it
         // straight into the caller's vector (no separate 8-byte copy)

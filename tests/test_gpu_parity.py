@@ -167,6 +167,57 @@ def test_host_staging_crosses_chunk_boundaries(gpu_lib):
     assert tm["host_bytes_in"] == 8.0 * (V32.size + W0.size + H0.size) and tm["ingest_s"] > 0 and tm["iterate_s"] > 0 and tm["egress_s"] > 0
 
 
+@pytest.mark.parametrize("alg,div,path,K,T", [("nmf", "euclidean", 2, 64, 1), ("nmf", "euclidean", 2, 256, 1), ("nmf", "kl", 2, 128, 1), ("nmf", "is", 2, 64, 1),
+                                              ("nmf", "euclidean", 1, 64, 1), ("nmf", "kl", 1, 40, 1), ("nmf", "euclidean", 0, 320, 1),
+                                              ("cnmf", "euclidean", 0, 64, 4), ("cnmf", "kl", 0, 64, 4), ("cnmf", "is", 0, 16, 3), ("nmfsc", "euclidean", 2, 64, 1)])
+def test_run_to_run_determinism(gpu_lib, alg, div, path, K, T):
+    """SURVEY section 5's substitute for a race detector: the same inputs twice give bit-identical W, H and cost on every kernel path -- fused
+    (Gram-form cost, dual-map, KL), Gram form on the GEMM (K > 256), materialised V_hat, the cnmf shift-sum passes, nmfsc's line searches.
+    (Every reduction has a fixed order: split slabs are summed deterministically, nothing uses floating-point atomics.)"""
+    m, n = 384, 1280
+    V, W0, H0 = synth(m, n, K, T=(T if alg == "cnmf" else None))
+    runs = []
+    for _ in range(2):
+        if alg == "nmf":
+            out = gpu_lib.nmf(V, K, dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, nmfx_path=path))
+        elif alg == "cnmf":
+            out = gpu_lib.cnmf(V, K, T, dict(divergence=div, W_init=W0, H_init=H0, maxiter=5, tolerance=1e-12, nmfx_path=path))
+        else:
+            out = gpu_lib.nmfsc(V, K, dict(W_init=W0, H_init=H0, H_sparsity=0.5, W_sparsity=0.3, maxiter=4, tolerance=1e-12, nmfx_path=path))
+        runs.append(out)
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("noise", [1.0, 0.3, 0.1, 0.03, 0.01, 0.001, 0.0])
+def test_gram_form_cost_over_residual_levels(gpu_lib, noise):
+    """Euclidean fused path: the cost comes in Gram form, 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')>, out of the W update's column sums while the
+    residual is large enough for fp32 to resolve that difference, and from the explicit residual pass once it is not (device-side switch at
+    cost < 5 % of 0.5*||V||^2).  Planted data from pure noise (ratio 0.5) to an exact factorisation: every reported cost holds the 1e-6
+    contract, whichever mode produced it, and the stop rule fires where the oracle's does."""
+    from oracle import nmf_oracle as O
+    rs = np.random.RandomState(11)
+    m, n, K = 384, 1536, 64
+    Wt, Ht = rs.rand(m, K), rs.rand(K, n)
+    V = np.fmax(Wt @ Ht / K + noise * rs.rand(m, n), 2.0 ** -52)
+    W0 = np.fmax(Wt + 0.2 * rs.rand(m, K), 2.0 ** -52)
+    H0 = np.fmax(Ht / K * 4 + 0.2 * rs.rand(K, n), 2.0 ** -52)
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=14, tolerance=1e-12)
+    ref = O.nmf(V, K, cfg)
+    out = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=2))
+    _check(out, ref)
+    ratio = ref[2] / (0.5 * np.sum(V ** 2))
+    record_err(cost=np.max(np.abs(out[2] - ref[2]) / np.abs(ref[2])))
+    assert np.max(np.abs(out[2] - ref[2]) / np.abs(ref[2])) < 1e-6, (noise, ratio, out[2], ref[2])
+    # the same with the reference's default tolerance: same number of iterations, same state
+    cfg2 = dict(cfg, maxiter=60, tolerance=1e-3 * max(1.0, ref[2][-1]))
+    ref2 = O.nmf(V, K, cfg2)
+    out2 = gpu_lib.nmf(V, K, dict(cfg2, nmfx_path=2))
+    _check_stop(out2[2], ref2[2], cfg2["tolerance"])
+    if len(out2[2]) == len(ref2[2]):
+        _check(out2, ref2)
+
+
 # ---- fused kernels (S = W*H never stored): eligible shapes, both split and un-split epilogues -----------------------
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
 @pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 25), (384, 640, 128, 15), (128, 32768, 64, 4), (256, 512, 256, 10),

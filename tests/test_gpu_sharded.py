@@ -102,6 +102,28 @@ def test_two_shards_equal_oracle(gpu_lib, div, path, m, n, K):
 
 
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_shards_run_to_run_determinism(gpu_lib, div, nshards):
+    """the same column-sharded run twice: bit-identical W (on every shard), H and cost"""
+    import torch
+    from nmf_toolbox_amd.engine import shard_columns, torch_to_colmajor
+    m, n, K = 256, 8 * 72 * 2, 64
+    V, W0, H0 = synth(m, n, K)
+    parts = [shard_columns(n, nshards, r) for r in range(nshards)]
+    res = []
+    for _ in range(2):
+        engs = _engines(torch, V, W0, H0, div, parts, 2)
+        cost = _run_emulated(torch, engs, 6)
+        res.append(([e.W.clone() for e in engs], [e.H.clone() for e in engs], cost))
+        for e in engs:
+            e.close()
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.equal(a, b)
+    assert all(torch.equal(w, res[0][0][0]) for w in res[0][0])
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("div", ["kl", "euclidean"])
 @pytest.mark.parametrize("nch", [2, 4])
 def test_row_chunked_wstep_equals_oracle(gpu_lib, div, nch):
     """The W-step partial computed in row chunks (what lets the all-reduce of one chunk overlap the compute of the next) gives the
