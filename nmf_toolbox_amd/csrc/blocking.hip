@@ -182,6 +182,10 @@ struct MultiDev {
     DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
     long lo[NMFX_MAX_GPUS + 1];
     ~MultiDev() {
+        for (int g = 0; g < ndev; ++g) {   // an error path may leave work in flight that reads the peers' buffers: drain every stream before anything is freed
+            (void)hipSetDevice(dev[g]);
+            if (st[g]) (void)hipStreamSynchronize(st[g]);
+        }
         for (int g = 0; g < ndev; ++g) {
             (void)hipSetDevice(dev[g]);
             if (eng[g]) nmfx_engine_destroy(eng[g]);
@@ -403,9 +407,16 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
 
 extern "C" {
 
-nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 0) : run_mu(p, r, 0); }
-nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 1) : run_mu(p, r, 1); }
-nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return (p && p->n_gpus > 1) ? run_mu_multi(p, r, 2) : run_mu(p, r, 2); }
+// n_gpus / device_ids: a one-entry list names THE device (it overrides p->device); more entries shard the columns
+static nmfx_status dispatch_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
+    if (!p) return run_mu(p, r, algorithm);
+    if (p->n_gpus > 1) return run_mu_multi(p, r, algorithm);
+    if (p->n_gpus == 1 && p->device_ids) { nmfx_problem q = *p; q.device = p->device_ids[0]; return run_mu(&q, r, algorithm); }
+    return run_mu(p, r, algorithm);
+}
+nmfx_status nmfx_nmf(const nmfx_problem *p, nmfx_result *r) { return dispatch_mu(p, r, 0); }
+nmfx_status nmfx_cnmf(const nmfx_problem *p, nmfx_result *r) { return dispatch_mu(p, r, 1); }
+nmfx_status nmfx_lnmf(const nmfx_problem *p, nmfx_result *r) { return dispatch_mu(p, r, 2); }
 nmfx_status nmfx_constrainednmf(const nmfx_problem *p, const int64_t *segments, int64_t nz, const void *Z_init, nmfx_result *r, void *Z_out) {
     return run_mu(p, r, 3, segments, nz, Z_init, Z_out);
 }
@@ -467,6 +478,10 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
 nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
                               const float *dir_dev, double mu, int32_t *usediters_dev) {
     if (N <= 0 || count <= 0 || !X_dev) { set_error("nmfx_projfunc_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;   // launch on the device the vectors live on, whatever the caller's current device is
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, X_dev) != hipSuccess) { (void)hipGetLastError(); set_error("nmfx_projfunc_dev: X_dev is not a device pointer"); return NMFX_ERR_INVALID; }
+    TRY(check_device(attr.device));
     return projfunc_cols(static_cast<hipStream_t>(stream), X_dev, N, count, k1, k2, nn, usediters_dev, dir_dev, mu, src_dev);
 }
 

@@ -11,7 +11,6 @@ constexpr int FT_ROWS = 128;  // stationary rows per workgroup (32 per wave)
 constexpr int FT_C = 64;      // streamed rows (contraction tile of the second product) per step
 
 __device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
 // raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit raw format
 __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
@@ -212,7 +211,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 6) tc = live ? fmaf(-0.6931471805599453f, er[sl], tc) : tc;
                 if (u == 5 || u == 6) asm volatile("" : "+v"(tc));
             } else if (FUNC == 5) {                           // alpha-beta: B = S.^(a+b-1), A = V.^a .* S.^(b-1); cost terms S.*(A - b/(a+b)*B)
-                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_logf(es[sl]); }   // log2(S)
+                // x.^0 == 1 also for x == 0 and x == Inf (MATLAB): log2(S) is clamped to +-3e38 (one v_med3_f32), so an exponent of exactly 0
+                // (beta == 1, or alpha + beta == 1) gives 2^(+-0) = 1 where 0 * (-Inf) would be NaN; any other exponent still overflows to the same 0 / Inf
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(es[sl]), -3.0e38f, 3.0e38f); }   // log2(S)
                 if (u == 1) eq[sl] = ab_e1 * er[sl];
                 if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
                 if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)

@@ -14,7 +14,7 @@ struct PinnedSlot {   // 64 bytes per host thread, kept for the life of the proc
     unsigned long long seq = 0;
     nmfx_status get() {
         if (host) return NMFX_OK;
-        NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocMapped));
+        NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocMapped | hipHostMallocPortable));
         memset(host, 0, 64);
         NMFX_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0));
         return NMFX_OK;
@@ -747,7 +747,19 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
 
 extern "C" {
 
-nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) { return run_nmfsc(p, r); }
+// n_gpus / device_ids: a one-entry list names THE device; column shards of nmfsc / cnmfsc go through nmfx_nmfsc_dev (one rank per shard)
+static nmfx_status sc_devices(const nmfx_problem *p, nmfx_problem *q, const char *what) {
+    *q = *p;
+    if (p->n_gpus > 1) { set_error("%s: n_gpus > 1 is not implemented behind the blocking call (nmfsc shards through nmfx_nmfsc_dev, one rank per GPU)", what); return NMFX_ERR_UNSUPPORTED; }
+    if (p->n_gpus == 1 && p->device_ids) q->device = p->device_ids[0];
+    return NMFX_OK;
+}
+nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) {
+    if (!p) return run_nmfsc(p, r);
+    nmfx_problem q;
+    TRY(sc_devices(p, &q, "nmfsc"));
+    return run_nmfsc(&q, r);
+}
 nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,
                            nmfx_allreduce_fn allreduce, void *allreduce_ctx, nmfx_result *r) {
     if (!p || !r || !V_dev || !W_dev || !H_dev || !r->cost) { set_error("nmfx_nmfsc_dev: null argument"); return NMFX_ERR_INVALID; }
@@ -758,7 +770,12 @@ nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_d
     d.comm.fn = allreduce; d.comm.ctx = allreduce_ctx; d.comm.st = d.st;
     return run_nmfsc(p, r, &d);
 }
-nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) { return run_cnmfsc(p, r); }
+nmfx_status nmfx_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
+    if (!p) return run_cnmfsc(p, r);
+    nmfx_problem q;
+    TRY(sc_devices(p, &q, "cnmfsc"));
+    return run_cnmfsc(&q, r);
+}
 
 nmfx_status nmfx_nmfsc_profile(int32_t enable) {
     g_sc_prof.enable(enable != 0);

@@ -181,7 +181,8 @@ class Engine:
         # SIMD, 256 workgroups), so a concurrent RCCL kernel can only run by displacing compute workgroups -- whether the overlap
         # wins has to be measured on an xGMI node first; NMFX_W_CHUNKS / n_chunks turn it on.
         self.n_chunks = int(n_chunks) if n_chunks is not None else int(os.environ.get("NMFX_W_CHUNKS", "1"))
-        if self.path_kind != 1 or self.m % (128 * max(self.n_chunks, 1)) != 0:
+        dual = d.divergence in (_lib.DIV_IS, _lib.DIV_AB)   # fused IS / alpha-beta passes produce [N | P] in one piece: no row chunks
+        if self.path_kind != 1 or dual or self.m % (128 * max(self.n_chunks, 1)) != 0:
             self.n_chunks = 1
         self.has_halos = bool(self.hL or self.hR)
         if self.has_halos:   # V_hat / cost are refreshed only after the neighbours' new H columns have arrived

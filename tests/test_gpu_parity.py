@@ -703,6 +703,25 @@ def test_nmf_fused_is_and_alpha_beta(gpu_lib, div, ab, m, n, K, iters):
     _check(generic, ref, cost_tol=1e-5)
 
 
+@pytest.mark.parametrize("ab", [(0.5, 1.0), (0.5, 0.5), (2.0, -1.0)])      # beta == 1: S.^(beta-1) = S.^0;  alpha + beta == 1: S.^(alpha+beta-1) = S.^0
+def test_nmf_fused_alpha_beta_zero_exponent_on_zero_vhat(gpu_lib, ab):
+    """x.^0 == 1 also where x == 0 (MATLAB).  A zero row of W makes a zero row of V_hat = W*H; with an exponent of exactly 0 the fused
+    element map (exp2(e * log2(S))) must give 1 there, not 0 * (-Inf) = NaN -- one NaN would poison a whole column of the numerators."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(256, 512, 64)
+    W0 = W0.copy()
+    W0[5, :] = 0.0
+    cfg = dict(divergence="ab", alpha=ab[0], beta=ab[1], W_init=W0, H_init=H0, maxiter=4, tolerance=1e-12)
+    with np.errstate(all="ignore"):
+        ref = O.nmf(V, 64, cfg)
+    fused = gpu_lib.nmf(V, 64, dict(cfg, nmfx_path=2))
+    generic = gpu_lib.nmf(V, 64, dict(cfg, nmfx_path=1))
+    for got in (fused, generic):
+        assert np.all(np.isfinite(got[0])) == np.all(np.isfinite(ref[0])) and np.all(np.isfinite(got[1])) == np.all(np.isfinite(ref[1]))
+        if np.all(np.isfinite(ref[0])) and np.all(np.isfinite(ref[1])):
+            assert rel_fro(got[0], ref[0]) < 1e-5 and rel_fro(got[1], ref[1]) < 1e-5, (ab, rel_fro(got[0], ref[0]), rel_fro(got[1], ref[1]))
+
+
 def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(256, 512, 64)

@@ -574,3 +574,58 @@ def test_blocking_api_n_gpus_stop_rule_multi_source_and_lnmf(gpu_lib):
         gpu_lib.cnmf(V, 8, 2, dict(maxiter=1, nmfx_gpus=[0, 0]))
     with pytest.raises(Exception):
         gpu_lib.nmf(V, 64, dict(maxiter=1, nmfx_gpus=[0, 7]))                      # no such device on a 1-GPU box
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.3, 0.5)])
+def test_nmfsc_dev_resume_equals_one_run(gpu_lib, sW, sH):
+    """nmfx_problem.sc_resume / sc_stepsize_*0 (what bench.py --workload c5 times): a + b outer iterations in two calls against a + b in one -- same
+    line-search tries, same factors.  With both line searches active the objective that closes the first call comes from another kernel than
+    inside one long run (a cost-only pass instead of the speculative residual pass: another summation order), so W / H / cost are compared at
+    the contract, not bit for bit."""
+    import torch
+    from nmf_toolbox_amd.engine import nmfsc_sharded, colmajor_to_torch
+    m, n, K, a, b = 256, 1024, 64, 3, 3
+    V, W0, H0 = synth(m, n, K)
+    dev = "cuda:0"
+    mk = lambda: (colmajor_to_torch(V, dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0, dev))
+    kw = dict(W_sparsity=sW, H_sparsity=sH, tolerance=-1.0, path=2)
+    V1, W1, H1 = mk()
+    c_one, i_one = nmfsc_sharded(V1, W1, H1, maxiter=a + b, **kw)
+    V2, W2, H2 = mk()
+    c_a, i_a = nmfsc_sharded(V2, W2, H2, maxiter=a, **kw)
+    c_b, i_b = nmfsc_sharded(V2, W2, H2, maxiter=b, resume=i_a, **kw)
+    assert i_a["triesH"] + i_b["triesH"] == i_one["triesH"] and i_a["triesW"] + i_b["triesW"] == i_one["triesW"]
+    assert abs(i_b["stepsizeH"] - i_one["stepsizeH"]) <= 1e-12 * i_one["stepsizeH"]
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    assert rel(W2, W1) < 1e-5 and rel(H2, H1) < 1e-5
+    both = np.concatenate([c_a, c_b[1:]])
+    assert len(both) == len(c_one) and np.max(np.abs(both - c_one) / c_one) < 1e-6 and abs(c_b[0] - c_a[-1]) <= 1e-6 * c_a[-1]
+
+
+def test_projfunc_dev_equals_host_entry_point(gpu_lib):
+    """nmfx_projfunc_dev (device buffers, asynchronous, optional fused step src + mu*dir) against nmfx_projfunc on the same fp32 vectors"""
+    import ctypes as C
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    N, count = 3000, 5
+    S = rs.rand(N, count).astype(np.float32)
+    D = rs.randn(N, count).astype(np.float32)
+    k1 = np.sqrt(N) - (np.sqrt(N) - 1) * 0.6
+    X = torch.from_numpy(np.ascontiguousarray(S.T)).cuda()
+    it = torch.zeros(count, dtype=torch.int32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.nmfx_projfunc_dev(st, X.data_ptr(), N, count, float(k1), 1.0, 1, None, None, 0.0, it.data_ptr()))
+    torch.cuda.synchronize()
+    want, wit = zip(*[gpu_lib.projfunc(S[:, c].astype(np.float32), k1, 1.0, True) for c in range(count)])
+    got = X.cpu().numpy().T
+    for c in range(count):
+        assert rel_fro(got[:, c], np.asarray(want[c]).ravel()) < 2e-6 and int(it[c]) == int(wit[c])
+    # fused step: projection of src + mu*dir, formed in fp64 while loading
+    Xs, Dd, Out = torch.from_numpy(np.ascontiguousarray(S.T)).cuda(), torch.from_numpy(np.ascontiguousarray(D.T)).cuda(), torch.zeros(count, N, device="cuda")
+    _lib.check(lib.nmfx_projfunc_dev(st, Out.data_ptr(), N, count, float(k1), 1.0, 1, Xs.data_ptr(), Dd.data_ptr(), -0.05, None))
+    torch.cuda.synchronize()
+    for c in range(count):
+        w, _ = gpu_lib.projfunc(S[:, c].astype(np.float64) - 0.05 * D[:, c].astype(np.float64), k1, 1.0, True)
+        assert rel_fro(Out[c].cpu().numpy(), np.asarray(w).ravel()) < 2e-6
