@@ -336,7 +336,13 @@ def main():
     eng.profile(False)
     path_kind, n_chunks_used, packed_bytes = eng.path_kind, eng.n_chunks, int(eng.packed.numel() * 4)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rank_info = None
     if world > 1 or force_dist:
+        # first contact with a multi-GPU node: every rank's own time and kernel path next to the MAX the metric is computed from
+        mine = torch.tensor([dt, float(path_kind), float(eng.cost_lag)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        rank_info = [[float(x) for x in t.tolist()] for t in allr]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     c = costs[: args.warmup + args.steps].cpu().numpy()
@@ -419,6 +425,11 @@ def main():
             "roofline": roof,
         }
         out["world_size_seen"] = int(dist.get_world_size()) if (world > 1 or force_dist) else 1
+        if rank_info:
+            ms = [1e3 * r[0] / args.steps for r in rank_info]
+            out["per_rank_ms_per_step"] = {"min": round(min(ms), 4), "max": round(max(ms), 4), "all": [round(x, 4) for x in ms]}
+            out["path_kind_per_rank"] = [int(r[1]) for r in rank_info]
+            out["all_ranks_same_path"] = len({(int(r[1]), int(r[2])) for r in rank_info}) == 1
         out["overlap_chunks"] = int(n_chunks_used)
         if comm_calls:   # N > 1: how long the compute stream waited for the packed all-reduce (rank 0), per step
             ar_ms = comm_total_ms / args.steps

@@ -42,26 +42,57 @@ def shard_columns(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
-    """The N > 1 iteration loop, independent of what computes the phases.
+def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None, tolerance=None):
+    """The N > 1 iteration loop, independent of what computes the phases.  Returns the number of iterations run.
 
     `backend` provides wstep_partial(), wstep_finish(), hstep(), the tensor `packed` (this rank's W-step sums, in place
     all-reducible) and _copy_cost(dst) (this rank's cost partial into a 1-element fp64 tensor).  One all-reduce of
     `packed` per iteration is the only data-path collective; a backend with n_chunks > 1 computes `packed` in row chunks
-    (wstep_partial_chunk / packed_chunk) and the same bytes travel as n_chunks pipelined all-reduces.  nmf.m returns the cost vector (nmf.m:206-218): the ranks'
-    partials are collected per iteration and summed over ranks ONCE at the end (8*iters bytes) -- this loop runs a fixed
-    number of iterations, so no per-iteration cost collective is needed (the stop rule lives in the blocking host API).
-    On the fused path (backend.cost_lags == True) the cost of iteration i is a by-product of the W-step pass of iteration
-    i+1; the last one needs backend.cost_pass().
+    (wstep_partial_chunk / packed_chunk) and the same bytes travel as n_chunks pipelined all-reduces.  nmf.m returns the cost
+    vector (nmf.m:206-218): without a stop rule the ranks' partials are collected per iteration and summed over ranks ONCE at
+    the end (8*iters bytes).  With `tolerance` > 0 the stop rule of nmf.m:221-224 is applied: the cost of every iteration is
+    summed over the ranks as soon as it exists (one 8-byte all-reduce) and read by the host; the loop stops with W and H at
+    the state of the iteration the rule fired on, like the reference.
+    Where the cost of iteration i turns up is the backend's `cost_lag`: 0 after hstep(i); 1 after wstep_partial(i+1) (fused KL
+    passes); 2 after wstep_finish(i+1) (Gram-form cost of the euclidean fused path: W has moved by then, so the loop keeps the
+    previous W -- backend.backup_W() / restore_W() -- to hand back on a stop).  The last one needs backend.cost_pass().
     """
     lag = bool(getattr(backend, "cost_lags", False))
     lagk = int(getattr(backend, "cost_lag", 1 if lag else 0))   # 2: the lagged cost comes out of wstep_finish (Gram-form cost), not of wstep_partial
+    stop_on = tolerance is not None and tolerance > 0
+    stop_le = bool(getattr(backend, "stop_le", False))          # lnmf.m:84 compares with <=
+    if stop_on and cost_out is None:
+        raise ValueError("the stop rule needs cost_out")
+    reduced = 0                                                   # cost_out[:reduced] already hold GLOBAL costs
 
     def emit(idx):
         backend._copy_cost(cost_out[idx:idx + 1])
 
+    def fired(idx):
+        """global cost(idx) now; True when nmf.m:221 says stop"""
+        nonlocal reduced
+        if dist is not None:
+            dist.all_reduce(cost_out[idx:idx + 1], group=group)
+        reduced = idx + 1
+        if idx == 0:
+            return False
+        c, prev = float(cost_out[idx]), float(cost_out[idx - 1])
+        return (c <= prev and prev - c <= tolerance) if stop_le else (c < prev and prev - c < tolerance)
+
+    def allreduce_packed():
+        ev = getattr(backend, "comm_events", None)                # measurement hook: how long the compute stream stalls on the exchange
+        if ev is not None:
+            a, b = backend.torch.cuda.Event(enable_timing=True), backend.torch.cuda.Event(enable_timing=True)
+            a.record()
+        if dist is not None:
+            dist.all_reduce(backend.packed, group=group)          # the ONE exchange step of an iteration
+        if ev is not None:
+            b.record()
+            ev.append((a, b))
+
     nch = int(getattr(backend, "n_chunks", 1))
-    merged = nch == 1 and hasattr(backend, "between_allreduces") and not getattr(backend, "has_halos", False)
+    merged = nch == 1 and hasattr(backend, "between_allreduces") and not getattr(backend, "has_halos", False) and not stop_on
+    ran, stopped = iters, False
     for it in range(iters):
         if merged:
             # one host call per iteration next to the collective: [wstep_finish, hstep, next wstep_partial] is a single C entry point
@@ -69,14 +100,7 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
                 backend.wstep_partial()
             if lagk == 1 and it > 0 and cost_out is not None:
                 emit(it - 1)
-            ev = getattr(backend, "comm_events", None)
-            if ev is not None:
-                a, b = backend.torch.cuda.Event(enable_timing=True), backend.torch.cuda.Event(enable_timing=True)
-                a.record()
-            dist.all_reduce(backend.packed, group=group)      # the ONE exchange step of an iteration
-            if ev is not None:
-                b.record()
-                ev.append((a, b))
+            allreduce_packed()
             backend.between_allreduces(it == iters - 1)
             if lagk == 2 and it > 0 and cost_out is not None:
                 emit(it - 1)                                  # (the next wstep_partial inside between_allreduces leaves the engine's cost alone in this mode)
@@ -90,36 +114,46 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None):
             for c in range(nch):
                 backend.wstep_partial_chunk(c, nch)
                 works.append(dist.all_reduce(backend.packed_chunk(c, nch), group=group, async_op=True))
-            if lag and it > 0 and cost_out is not None:
-                emit(it - 1)                                  # (row chunks carry their cost inside the pass: always available here)
             for w in works:
                 w.wait()
+            if lag and it > 0 and cost_out is not None:
+                emit(it - 1)                                  # (row chunks carry their cost inside the pass: always available here)
+                if stop_on and fired(it - 1):                 # W and H are untouched until wstep_finish: the state of iteration it-1
+                    ran, stopped = it, True
+                    break
         else:
             backend.wstep_partial()
             if lagk == 1 and it > 0 and cost_out is not None:
                 emit(it - 1)
-            ev = getattr(backend, "comm_events", None)        # measurement hook: how long the compute stream stalls on the exchange
-            if ev is not None:
-                a, b = backend.torch.cuda.Event(enable_timing=True), backend.torch.cuda.Event(enable_timing=True)
-                a.record()
-            dist.all_reduce(backend.packed, group=group)      # the ONE exchange step of an iteration
-            if ev is not None:
-                b.record()
-                ev.append((a, b))
+                if stop_on and fired(it - 1):
+                    ran, stopped = it, True
+                    break
+            allreduce_packed()
+        keep_w = stop_on and lagk == 2 and nch == 1 and it > 0
+        if keep_w:
+            backend.backup_W()
         backend.wstep_finish()
         if lagk == 2 and nch == 1 and it > 0 and cost_out is not None:
             emit(it - 1)
+            if stop_on and fired(it - 1):
+                backend.restore_W()                           # the update that produced cost(it-1) has already moved W: hand back the one before it
+                ran, stopped = it, True
+                break
         backend.hstep()
         if getattr(backend, "has_halos", False):
             backend.exchange_halos()                          # cnmf only: T-1 columns of H to each neighbour ...
             backend.hstep_finish()                            # ... then V_hat / cost with the new H
         if not lag and cost_out is not None:
             emit(it)
-    if lag and iters > 0 and cost_out is not None:
+            if stop_on and fired(it):
+                ran, stopped = it + 1, True
+                break
+    if lag and iters > 0 and cost_out is not None and not stopped:
         backend.cost_pass()
         emit(iters - 1)
-    if iters > 0 and cost_out is not None:
-        dist.all_reduce(cost_out[:iters], group=group)        # local partials -> global costs, one small collective
+    if ran > reduced and cost_out is not None and dist is not None:
+        dist.all_reduce(cost_out[reduced:ran], group=group)   # local partials -> global costs, one small collective
+    return ran
 
 
 class Engine:
@@ -157,6 +191,7 @@ class Engine:
         d.device = self.V.device.index or 0
         d.stream = C.c_void_p(torch.cuda.current_stream(self.V.device).cuda_stream)
         d.algorithm = {"nmf": 0, "cnmf": 1, "lnmf": 2}[algorithm]
+        self.stop_le = algorithm == "lnmf"                 # lnmf.m:84
         d.path = int(path)
         d.halo_left, d.halo_right = self.hL, self.hR
         d.n_valid = int(n_valid) if n_valid is not None else self.n + self.hR
@@ -261,13 +296,22 @@ class Engine:
             if not stream_ordered:
                 torch.cuda.synchronize(self.V.device)
 
-    def iterate(self, iters, cost_out=None):
-        """`iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration."""
-        if self.dist is None:
+    def iterate(self, iters, cost_out=None, tolerance=None):
+        """At most `iters` full iterations; cost_out: optional fp64 device tensor (>= iters) receiving the GLOBAL cost per iteration.
+        tolerance > 0 applies the stop rule of nmf.m:221-224 (needs cost_out).  Returns the number of iterations run."""
+        if self.dist is None and not (tolerance is not None and tolerance > 0):
             ptr = cost_out.data_ptr() if cost_out is not None else None
             _lib.check(self.lib.nmfx_engine_iterate(self.h, int(iters), ptr))
-            return
-        run_sharded_iterations(self, iters, self.dist, self.group, cost_out)
+            return int(iters)
+        return run_sharded_iterations(self, iters, self.dist, self.group, cost_out, tolerance)
+
+    def backup_W(self):
+        if getattr(self, "_Wbak", None) is None:
+            self._Wbak = self.torch.empty_like(self.W)
+        self._Wbak.copy_(self.W)
+
+    def restore_W(self):
+        self.W.copy_(self._Wbak)
 
     def _copy_cost(self, dst):
         _lib.check(self.lib.nmfx_engine_copy_cost(self.h, dst.data_ptr()))

@@ -24,9 +24,12 @@ class NumpyShard:
         self.m, self.n = V.shape
         self.K = W.shape[1]
         self.lamW, self.lamH, self.fixW, self.fixH, self.rank0 = lamW, lamH, fixW.astype(bool), fixH.astype(bool), rank0
-        self.cost_lags = layout == "fused"
+        # where the cost of iteration i turns up (nmfx_engine_cost_lag): 0 after hstep(i), 1 after wstep_partial(i+1), 2 after wstep_finish(i+1)
+        # ("gram": the euclidean fused path's cost in Gram form, out of the column sums of the W update)
+        self.cost_lag = 2 if layout == "gram" else (1 if layout == "fused" else 0)
+        self.cost_lags = self.cost_lag != 0
         mk = self.m * self.K
-        tail = mk if layout == "generic" and div != "kl" else (self.K * self.K if (layout == "fused" and div == "euclidean") else self.K)
+        tail = mk if layout == "generic" and div != "kl" else (self.K * self.K if (layout in ("fused", "gram") and div == "euclidean") else self.K)
         self.packed = torch.zeros(mk + tail, dtype=torch.float64)
         self.cost_local = 0.0
         self.W *= 1.0 / np.sqrt((self.W ** 2).sum(0))[None, :]                       # nmf.m:130-134
@@ -44,13 +47,13 @@ class NumpyShard:
         S = self.W @ self.H
         A = self.V / S if self.div == "kl" else self.V
         N = A @ self.H.T
-        if self.cost_lags:
+        if self.cost_lag == 1:
             self._cost()
         p = self.packed.numpy()
         p[:mk] = N.ravel(order="F")
         if self.div == "kl":
             p[mk:] = self.H.sum(1)
-        elif self.layout == "fused":
+        elif self.layout in ("fused", "gram"):
             p[mk:] = (self.H @ self.H.T).ravel(order="F")
         else:
             p[mk:] = (S @ self.H.T).ravel(order="F")
@@ -85,12 +88,19 @@ class NumpyShard:
             N = p[:mk].reshape(self.m, self.K, order="F")
         if self.div == "kl":
             P = np.broadcast_to(p[mk:][None, :], N.shape)
-        elif self.layout == "fused":
+        elif self.layout in ("fused", "gram"):
             P = self.W @ p[mk:].reshape(self.K, self.K, order="F")
         else:
             P = p[mk:].reshape(self.m, self.K, order="F")
         W = self.W
         dn, dp = (W * P).sum(0), (W * N).sum(0)
+        if self.cost_lag == 2:
+            # 0.5*||V - W*H||^2 = 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')> of the state this step started from: the all-reduced sums make the
+            # cross terms global, so rank 0 alone carries them; every rank adds its own 0.5*||V_local||^2 and lambda_H*|H_local|
+            c = 0.5 * np.sum(self.V ** 2) + float(np.sum(self.lamH * np.abs(self.H).sum(1)))
+            if self.rank0:
+                c += 0.5 * dn.sum() - dp.sum() + float(np.sum(self.lamW * np.abs(W).sum(0)))
+            self.cost_local = c
         Wn = W * ((N + W * dn) / np.fmax(P + W * dp + self.lamW[None, :], EPS))
         Wn *= 1.0 / np.sqrt((Wn ** 2).sum(0))[None, :]
         self.W = np.where(self.fixW[None, :], W, Wn)
@@ -108,6 +118,12 @@ class NumpyShard:
 
     def cost_pass(self):
         self._cost()
+
+    def backup_W(self):
+        self._Wbak = self.W.copy()
+
+    def restore_W(self):
+        self.W = self._Wbak.copy()
 
     def _copy_cost(self, dst):
         dst[0] = self.cost_local
@@ -127,7 +143,7 @@ class NumpyShardMerged(NumpyShard):
                 self.cost_local = saved
 
 
-def _worker(rank, world, port, div, layout, iters, q, n_chunks=1):
+def _worker(rank, world, port, div, layout, iters, q, n_chunks=1, tolerance=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,8 +159,8 @@ def _worker(rank, world, port, div, layout, iters, q, n_chunks=1):
     n_chunks = max(n_chunks, 1)
     be = cls(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0, n_chunks)
     cost = torch.zeros(iters, dtype=torch.float64)
-    run_sharded_iterations(be, iters, dist, None, cost)
-    q.put((rank, lo, hi, be.W, be.H, cost.numpy().copy()))
+    ran = run_sharded_iterations(be, iters, dist, None, cost, tolerance)
+    q.put((rank, lo, hi, be.W, be.H, cost.numpy()[:ran].copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -157,15 +173,31 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("div", ["euclidean", "kl"])
-@pytest.mark.parametrize("layout,n_chunks", [("generic", 1), ("fused", 1), ("fused", 3), ("generic", 0), ("fused", 0)])
-def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks):
+def _cases():
+    for div in ("euclidean", "kl"):
+        for layout, n_chunks in (("generic", 1), ("fused", 1), ("fused", 3), ("generic", 0), ("fused", 0)):
+            yield div, layout, n_chunks, None
+    yield "euclidean", "gram", 1, None          # Gram-form cost: lagged, delivered by wstep_finish
+    yield "euclidean", "gram", 0, None
+    for div, layout in (("euclidean", "generic"), ("euclidean", "fused"), ("kl", "fused"), ("euclidean", "gram")):
+        yield div, layout, 1, 0.05              # the stop rule of nmf.m:221-224 inside the sharded loop
+
+
+@pytest.mark.parametrize("div,layout,n_chunks,tolerance", list(_cases()))
+def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks, tolerance):
     from oracle import nmf_oracle as O
-    world, iters = 2, 12
+    world, iters = 2, 12 if tolerance is None else 40
+    if tolerance is not None:       # a tolerance that makes nmf.m:221 fire around iteration 10 of this problem: between two consecutive decreases of the cost
+        Vt, Wt, Ht = synth(48, 90, 6)
+        ct = O.nmf(Vt, [2, 2, 2], dict(divergence=div, W_init=[Wt[:, :2], Wt[:, 2:4], Wt[:, 4:]], H_init=[Ht[:2], Ht[2:4], Ht[4:]], W_sparsity=[0.05, 0.0, 0.0],
+                                       H_sparsity=[0.0, 0.1, 0.1], W_fixed=[False, False, True], H_fixed=[True, False, False], maxiter=iters, tolerance=1e-300))[2]
+        dec = -np.diff(ct)
+        assert np.all(dec[:12] > 0) and dec[9] > dec[10]
+        tolerance = 0.5 * (dec[9] + dec[10])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q, n_chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q, n_chunks, tolerance)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
@@ -175,8 +207,11 @@ def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks):
     m, n, K = 48, 90, 6
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence=div, W_init=[W0[:, :2], W0[:, 2:4], W0[:, 4:]], H_init=[H0[:2], H0[2:4], H0[4:]], W_sparsity=[0.05, 0.0, 0.0],
-               H_sparsity=[0.0, 0.1, 0.1], W_fixed=[False, False, True], H_fixed=[True, False, False], maxiter=iters, tolerance=1e-300)
+               H_sparsity=[0.0, 0.1, 0.1], W_fixed=[False, False, True], H_fixed=[True, False, False], maxiter=iters, tolerance=1e-300 if tolerance is None else tolerance)
     W, H, cost = O.nmf(V, [2, 2, 2], cfg)
+    if tolerance is not None:
+        assert 2 < len(cost) < iters                                # the rule really fired, and not at once
+        assert all(len(r[5]) == len(cost) for r in res)             # ... at the same iteration on every rank as in the unsharded oracle
     W, H = np.hstack(W), np.vstack(H)
     assert np.array_equal(res[0][3], res[1][3])                     # W bit-identical on both ranks
     Hs = np.concatenate([r[4] for r in res], axis=1)

@@ -629,3 +629,33 @@ def test_projfunc_dev_equals_host_entry_point(gpu_lib):
     for c in range(count):
         w, _ = gpu_lib.projfunc(S[:, c].astype(np.float64) - 0.05 * D[:, c].astype(np.float64), k1, 1.0, True)
         assert rel_fro(Out[c].cpu().numpy(), np.asarray(w).ravel()) < 2e-6
+
+
+@pytest.mark.parametrize("div,path", [("euclidean", 2), ("kl", 2), ("euclidean", 1)])     # cost_lag 2 (Gram-form cost), 1 (fused KL), 0 (materialised V_hat)
+def test_engine_loop_stop_rule_equals_blocking_call(gpu_lib, div, path):
+    """nmf.m:221-224 inside the device-level loop (Engine.iterate(..., tolerance)): same number of iterations, same W / H / cost as the blocking call,
+    whose stop logic is a separate implementation (csrc/blocking.hip) -- and as the oracle"""
+    import torch
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd.engine import Engine, colmajor_to_torch, torch_to_colmajor
+    m, n, K = 256, 1024, 64
+    V, W0, H0 = synth(m, n, K, planted=True)
+    probe = O.nmf(V, K, dict(divergence=div, W_init=W0, H_init=H0, maxiter=30, tolerance=1e-300))[2]
+    dec = -np.diff(probe)
+    tol = float(0.5 * (dec[11] + dec[12]))
+    assert np.all(dec[:14] > 0) and dec[11] > dec[12]
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=30, tolerance=tol)
+    Wr, Hr, cr = O.nmf(V, K, cfg)
+    Wb, Hb, cb = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=path))
+    e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence=div, path=path, use_dist=False)
+    e.init()
+    cost = torch.zeros(30, dtype=torch.float64, device="cuda:0")
+    ran = e.iterate(30, cost, tolerance=tol)
+    assert ran == len(cb) == len(cr) and 5 < ran < 30
+    We, He = torch_to_colmajor(e.W).reshape(m, K), torch_to_colmajor(e.H)
+    assert np.array_equal(We, Wb) and np.array_equal(He, Hb)                 # the two stop implementations hand back the same state, bit for bit
+    # KL on planted (well-fitting) data: the cost is a small difference of sums of the size of sum(V), and the v_rcp / v_log element map carries a
+    # systematic -5e-9 * sum(V) (DESIGN 4.1; constant over the iterations, so it cancels in the differences the stop rule looks at): 1.6e-6 of the cost here
+    assert rel_fro(We, Wr) < 1e-5 and rel_fro(He, Hr) < 1e-5 and rel_fro(cost[:ran].cpu().numpy(), cr) < (3e-6 if div == "kl" else 1e-6)
+    assert np.max(np.abs(np.diff(cost[:ran].cpu().numpy()) - np.diff(cr))) < 1e-4 * tol
+    e.close()
