@@ -84,8 +84,10 @@ typedef struct {
     double sc_stepsize_H0, sc_stepsize_W0; /* nmfsc / nmfsc_dev: initial line-search step sizes; <= 0 = 1 (nmfsc.m:133-134).  With
                                               result.stepsize_H / stepsize_W of a previous call this resumes a run exactly */
     int32_t sc_resume;        /* nmfx_nmfsc_dev only: W / H are the state a previous call left (skip the initial projections, nmfsc.m:94-110) */
-    int32_t n_gpus;           /* nmfx_nmf / nmfx_lnmf: 0 or 1 = one GPU (p->device); N > 1 = V and H column-sharded over N GPUs of this
-                                 process, W replicated, ONE all-reduce of the packed W-step sums per iteration */
+    int32_t n_gpus;           /* nmfx_nmf / nmfx_cnmf / nmfx_lnmf / nmfx_nmfsc: 0 or 1 = one GPU (p->device); N > 1 = V and H column-sharded
+                                 over N GPUs of this process, W replicated, ONE all-reduce of the packed W-step sums per iteration
+                                 (SURVEY 8(e)); cnmf adds T-1 halo columns of H copied between neighbouring devices per iteration, nmfsc
+                                 runs one host thread per shard with the sums of its line searches / projfunc reduced over the peers */
     const int32_t *device_ids;/* [n_gpus] HIP ordinals, or NULL = 0 .. n_gpus-1 */
 } nmfx_problem;
 

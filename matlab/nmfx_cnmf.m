@@ -49,6 +49,7 @@ if ~isfield(config, 'maxiter') || config.maxiter <= 0, config.maxiter = 100; end
 if ~isfield(config, 'tolerance') || config.tolerance <= 0, config.tolerance = 1e-3; end
 opts.divergence = dv; opts.alpha = config.alpha; opts.beta = config.beta;
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
+if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end   % extension: column shards over several GPUs
 K_s = int32(cell2mat(num_basis_elems(:)'));
 W_all = cat(2, config.W_init{:});            % cell2mat(1 x S) of m x K_s x T tensors: along dimension 2
 [Wa, Ha, cost] = nmfx_mex('cnmf', double(V), double(W_all), double(cell2mat(config.H_init)), K_s, T, opts);

@@ -16,7 +16,7 @@
  *     K_s    : 1 x S int32 (basis elements per source, sum = K)       T : scalar
  *     opts   : struct; fields (all optional): divergence (0 euclidean, 1 kl, 2 is, 3 ab, 4 cnmf's 'frobenius'), alpha, beta,
  *              W_sparsity, H_sparsity (1 x S double), W_fixed, H_fixed (1 x S uint8), maxiter, tolerance, device, path,
- *              sc_W_sparsity, sc_H_sparsity (nmfsc / cnmfsc), device_ids (1 x N int32: V column-sharded over N GPUs, nmf / lnmf)
+ *              sc_W_sparsity, sc_H_sparsity (nmfsc / cnmfsc), device_ids (1 x N int32: V column-sharded over N GPUs; nmf / cnmf / lnmf / nmfsc)
  *     info   : struct iters_run, stepsize_H, stepsize_W, converged_early, tries_H, tries_W (nmfsc / cnmfsc line searches)
  *
  * build (on a machine with MATLAB):  mex -I../include nmfx_mex.c -L../nmf_toolbox_amd -lnmfx

@@ -24,6 +24,7 @@ opts.sc_H_sparsity = double(config.H_sparsity);
 opts.W_fixed = uint8(logical(config.W_fixed));
 opts.H_fixed = uint8(logical(config.H_fixed));
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
+if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end   % extension: column shards over several GPUs
 [W, H, cost, info] = nmfx_mex('nmfsc', double(V), double(config.W_init), double(config.H_init), int32(num_basis_elems), 1, opts);
 if info.converged_early, display('Algorithm converged'); end   % the step size fell below 1e-200 in a line search
 end

@@ -193,5 +193,7 @@ void host_minmax(const void *host, int dtype, size_t count, double *vmin, double
 struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0; };
 IoStats &io_stats();
 nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true);
+nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r);   // multi_sc.hip
+void sc_thread_cleanup();                                              // sc.hip
 
 }  // namespace nmfx

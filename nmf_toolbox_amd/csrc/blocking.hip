@@ -177,10 +177,11 @@ struct MultiDev {
     int ndev = 0;
     int dev[NMFX_MAX_GPUS];
     hipStream_t st[NMFX_MAX_GPUS] = {};
-    hipEvent_t evP[NMFX_MAX_GPUS] = {}, evR[NMFX_MAX_GPUS] = {}, evG[NMFX_MAX_GPUS] = {};
+    hipEvent_t evP[NMFX_MAX_GPUS] = {}, evR[NMFX_MAX_GPUS] = {}, evG[NMFX_MAX_GPUS] = {}, evH[NMFX_MAX_GPUS] = {};
     nmfx_engine *eng[NMFX_MAX_GPUS] = {};
     DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
     long lo[NMFX_MAX_GPUS + 1];
+    long hL[NMFX_MAX_GPUS] = {}, hR[NMFX_MAX_GPUS] = {};   // cnmf: T-1 halo columns of H on each inner edge (and of V on the right one)
     ~MultiDev() {
         for (int g = 0; g < ndev; ++g) {   // an error path may leave work in flight that reads the peers' buffers: drain every stream before anything is freed
             (void)hipSetDevice(dev[g]);
@@ -192,6 +193,7 @@ struct MultiDev {
             if (evP[g]) (void)hipEventDestroy(evP[g]);
             if (evR[g]) (void)hipEventDestroy(evR[g]);
             if (evG[g]) (void)hipEventDestroy(evG[g]);
+            if (evH[g]) (void)hipEventDestroy(evH[g]);
             if (st[g]) (void)hipStreamDestroy(st[g]);
         }
     }
@@ -230,13 +232,38 @@ nmfx_status multi_allreduce(MultiDev &M, size_t count) {
     return NMFX_OK;
 }
 
+// cnmf on column shards (cnmf.m:188,219 shift across the shard edges): after an H update every device fetches the T-1 columns next to
+// each of its inner edges from the neighbour that owns them, point-to-point over xGMI, on its own stream behind the neighbour's update
+nmfx_status multi_halo_exchange(MultiDev &M, int K, int hh) {
+    const int N = M.ndev;
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipEventRecord(M.evH[g], M.st[g])); }
+    const size_t bytes = (size_t)K * hh * 4;
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        const long nl = M.lo[g + 1] - M.lo[g];
+        if (g > 0) {   // my left halo = the last T-1 columns of the left neighbour
+            const long nln = M.lo[g] - M.lo[g - 1];
+            NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evH[g - 1], 0));
+            NMFX_HIP(hipMemcpyPeerAsync(M.H[g].as<float>(), M.dev[g], M.H[g - 1].as<float>() + (size_t)K * (M.hL[g - 1] + nln - hh), M.dev[g - 1], bytes, M.st[g]));
+        }
+        if (g < N - 1) {   // my right halo = the first T-1 columns of the right neighbour
+            NMFX_HIP(hipStreamWaitEvent(M.st[g], M.evH[g + 1], 0));
+            NMFX_HIP(hipMemcpyPeerAsync(M.H[g].as<float>() + (size_t)K * (M.hL[g] + nl), M.dev[g], M.H[g + 1].as<float>() + (size_t)K * M.hL[g + 1], M.dev[g + 1], bytes, M.st[g]));
+        }
+    }
+    // (the next H update of a neighbour comes after the next packed exchange, which waits for every device's stream: no copy is still reading then)
+    return NMFX_OK;
+}
+
 nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     TRY(validate_problem(p, r, false, true));
-    if (algorithm != 0 && algorithm != 2) { set_error("n_gpus > 1 is implemented for nmf and lnmf (cnmf / nmfsc shard through the device-level API)"); return NMFX_ERR_UNSUPPORTED; }
-    if (p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
+    if (algorithm != 0 && algorithm != 1 && algorithm != 2) { set_error("n_gpus > 1 is implemented for nmf, cnmf, lnmf and nmfsc"); return NMFX_ERR_UNSUPPORTED; }
+    if (algorithm != 1 && p->T != 1) { set_error("nmf / lnmf: T must be 1"); return NMFX_ERR_INVALID; }
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     const int N = p->n_gpus;
+    const int T = p->T, hh = T - 1;
     if (N > NMFX_MAX_GPUS || N > p->n) { set_error("n_gpus = %d: at most %d devices and one column per device", N, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
+    if (hh > 0 && p->n / N < hh) { set_error("cnmf on %d devices: every shard needs at least T-1 = %d columns", N, hh); return NMFX_ERR_INVALID; }
     DeviceGuard dg_;
     MultiDev M;
     for (int g = 0; g < N; ++g) {
@@ -261,7 +288,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     long nmin = n;
     for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
     const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;
-    const bool pad = Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && Kt <= 256 && ((m >= 64 && nmin >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
     std::vector<float> lw(K, 0.f), lh(K, 0.f);
     std::vector<uint8_t> fw(K, 0), fh(K, 0);
@@ -276,7 +303,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         }
         k0 += Ks;
     }
-    const size_t mK = (size_t)m * K, mKt = (size_t)m * Kt;
+    const size_t mK = (size_t)m * K * T, mKt = (size_t)m * Kt * T;   // (cnmf: the T slices of W; K is never padded there)
     size_t packed_count = 0;
     int kind = -1;
     for (int g = 0; g < N; ++g) {
@@ -286,9 +313,12 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         NMFX_HIP(hipEventCreateWithFlags(&M.evP[g], hipEventDisableTiming));
         NMFX_HIP(hipEventCreateWithFlags(&M.evR[g], hipEventDisableTiming));
         NMFX_HIP(hipEventCreateWithFlags(&M.evG[g], hipEventDisableTiming));
+        NMFX_HIP(hipEventCreateWithFlags(&M.evH[g], hipEventDisableTiming));
         const long nl = M.lo[g + 1] - M.lo[g];
+        const long hL = M.hL[g] = g > 0 ? hh : 0, hR = M.hR[g] = g < N - 1 ? hh : 0;   // H = [left halo | own columns | right halo], V = [own | right halo]
         nmfx_engine_desc d{};
-        d.m = m; d.n_local = nl; d.K_total = K; d.T = 1; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
+        d.m = m; d.n_local = nl; d.K_total = K; d.T = T; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
+        d.halo_left = (int)hL; d.halo_right = (int)hR; d.n_valid = nl + hR;
         d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
         d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = p->path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
         size_t wsb = 0, pc = 0;
@@ -297,10 +327,12 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         if (g == 0) packed_count = pc;
         else if (pc != packed_count) { set_error("n_gpus: shards disagree on the packed layout"); return NMFX_ERR_INVALID; }
         DevBuf tmp;
-        TRY(M.V[g].alloc((size_t)m * nl * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nl * 4)); TRY(M.ws[g].alloc(wsb));
-        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64));        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
-        const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
-        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * nl, 1.0));
+        const long nh = hL + nl + hR;
+        TRY(M.V[g].alloc((size_t)m * (nl + hR) * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nh * 4)); TRY(M.ws[g].alloc(wsb));
+        TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64));
+        const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
+        const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * (M.lo[g] - hL) * dsize(p->dtype);
+        TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * (nl + hR), 1.0));
         TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0));
         if (pad) {
             NMFX_HIP(hipMemsetAsync(M.W[g].as<float>() + mKt, 0, (mK - mKt) * 4, M.st[g]));
@@ -308,9 +340,10 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0));
             TRY(repack_rows(M.st[g], tmp.as<float>(), Kt, M.H[g].as<float>(), K, nl));
             NMFX_HIP(hipStreamSynchronize(M.st[g]));
-        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nl, 1.0));
+        } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nh, 1.0));
         TRY(nmfx_engine_create(&d, M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb, M.packed[g].as<float>(), &M.eng[g]));
         TRY(nmfx_engine_set_rank0(M.eng[g], g == 0));
+        if (hL || hR) TRY(nmfx_engine_defer_hstep_finish(M.eng[g], 1));   // V_hat / cost only once the neighbours' new columns are in
         const int kd = nmfx_engine_is_fused(M.eng[g]);
         if (kind < 0) kind = kd;
         else if (kd != kind) { set_error("n_gpus: shards picked different kernel paths; pass path = 1"); return NMFX_ERR_UNSUPPORTED; }
@@ -374,6 +407,10 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             }
         } else if (lagk == 2 && it > 0) TRY(read_cost(it - 1));
         for (int g = 0; g < N; ++g) TRY(nmfx_engine_hstep(M.eng[g]));
+        if (hh > 0) {
+            TRY(multi_halo_exchange(M, K, hh));
+            for (int g = 0; g < N; ++g) TRY(nmfx_engine_hstep_finish(M.eng[g]));
+        }
         if (!lag) {
             TRY(read_cost(it));
             if (stop(it)) { stopped = true; break; }
@@ -398,7 +435,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             TRY(tmp.alloc((size_t)Kt * nl * 4));
             TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, tmp.as<float>(), Kt, nl));
             TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl));
-        } else TRY(download(M.st[g], M.H[g].as<float>(), p->dtype, Hh, (size_t)K * nl));
+        } else TRY(download(M.st[g], M.H[g].as<float>() + (size_t)K * M.hL[g], p->dtype, Hh, (size_t)K * nl));
     }
     return NMFX_OK;
 }

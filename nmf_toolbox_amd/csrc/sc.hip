@@ -21,6 +21,14 @@ struct PinnedSlot {   // 64 bytes per host thread, kept for the life of the proc
     }
 };
 static thread_local PinnedSlot g_obj_slot;
+}  // namespace
+namespace nmfx {
+void sc_thread_cleanup() {   // a worker thread of the multi-GPU blocking call is about to exit: its slot goes with it
+    if (g_obj_slot.host) (void)hipHostFree(g_obj_slot.host);
+    g_obj_slot = PinnedSlot{};
+}
+}  // namespace nmfx
+namespace {
 nmfx_status read_obj(hipStream_t st, const double *partials, int count, double *cost_dev, double *out, Comm *comm = nullptr) {
     TRY(g_obj_slot.get());
     PinnedSlot &sl = g_obj_slot;
@@ -540,8 +548,9 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
     TRY(transpose_f32(st, HTd, n, K, Hk.as<float>()));
     if (dev) {
-        NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mK * 4, hipMemcpyDeviceToDevice, st));
-        NMFX_HIP(hipMemcpyAsync(dev->H, Hk.p, Kn * 4, hipMemcpyDeviceToDevice, st));
+        NMFX_HIP(hipMemcpyAsync(dev->W, Wd, mKv * 4, hipMemcpyDeviceToDevice, st));   // (the caller's arrays hold the Kv real components only)
+        if (padK) TRY(repack_rows(st, Hk.as<float>(), K, dev->H, Kv, n));
+        else NMFX_HIP(hipMemcpyAsync(dev->H, Hk.p, Kn * 4, hipMemcpyDeviceToDevice, st));
         NMFX_HIP(hipStreamSynchronize(st));
         return NMFX_OK;
     }
@@ -750,12 +759,13 @@ extern "C" {
 // n_gpus / device_ids: a one-entry list names THE device; column shards of nmfsc / cnmfsc go through nmfx_nmfsc_dev (one rank per shard)
 static nmfx_status sc_devices(const nmfx_problem *p, nmfx_problem *q, const char *what) {
     *q = *p;
-    if (p->n_gpus > 1) { set_error("%s: n_gpus > 1 is not implemented behind the blocking call (nmfsc shards through nmfx_nmfsc_dev, one rank per GPU)", what); return NMFX_ERR_UNSUPPORTED; }
+    if (p->n_gpus > 1) { set_error("%s: n_gpus > 1 is not implemented behind the blocking call (nmf, cnmf, lnmf and nmfsc are)", what); return NMFX_ERR_UNSUPPORTED; }
     if (p->n_gpus == 1 && p->device_ids) q->device = p->device_ids[0];
     return NMFX_OK;
 }
 nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (!p) return run_nmfsc(p, r);
+    if (p->n_gpus > 1) return run_nmfsc_multi(p, r);   // csrc/multi_sc.hip: one host thread per column shard over nmfx_nmfsc_dev
     nmfx_problem q;
     TRY(sc_devices(p, &q, "nmfsc"));
     return run_nmfsc(&q, r);

@@ -132,6 +132,13 @@ def _as_data(V):
     return V
 
 
+def _gpu_ids(cfg):
+    gpus = cfg.get("nmfx_gpus", None)
+    if gpus is None:
+        return None
+    return np.asarray(list(range(int(gpus))) if np.isscalar(gpus) else list(gpus), dtype=np.int32)
+
+
 def _f_order(a, dtype):
     return a if (a.dtype == dtype and a.flags.f_contiguous) else np.asfortranarray(a, dtype=dtype)
 
@@ -173,10 +180,9 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     p.tolerance = -1.0 if cfg.get("nmfx_disable_stop", False) else float(cfg["tolerance"])
     p.device = int(device)
     p.path = int(cfg.get("nmfx_path", 0))       # extension: 0 auto, 1 generic kernels only, 2 require the fused kernels
-    # extension: nmfx_gpus = N or a list of device ordinals -> V / H column-sharded over N GPUs of this process (nmf, lnmf)
-    gpus = cfg.get("nmfx_gpus", None)
-    if gpus is not None:
-        ids = np.asarray(list(range(int(gpus))) if np.isscalar(gpus) else list(gpus), dtype=np.int32)
+    # extension: nmfx_gpus = N or a list of device ordinals -> V / H column-sharded over N GPUs of this process (nmf, cnmf, lnmf, nmfsc)
+    ids = _gpu_ids(cfg)
+    if ids is not None:
         p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
     r = _lib.Result()
     r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
@@ -424,6 +430,9 @@ def nmfsc(V, num_basis_elems, config=None, device=0, info=None):
     p.maxiter, p.tolerance, p.device = maxiter, (-1.0 if cfg.get("nmfx_disable_stop", False) else tol), int(device)
     p.sc_W_sparsity, p.sc_H_sparsity = sW, sH
     p.path = int(cfg.get("nmfx_path", 0))
+    ids = _gpu_ids(cfg)                                            # extension: column shards over N GPUs of this process
+    if ids is not None:
+        p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
     r = _lib.Result()
     r.W, r.H, r.cost, r.tries_H, r.tries_W = _fptr(Wout), _fptr(Hout), _fptr(cost), _fptr(tH), _fptr(tW)
     _lib.check(_lib.load().nmfx_nmfsc(C.byref(p), C.byref(r)))
@@ -478,6 +487,9 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, device=0, info=None):
     p.W_fixed, p.H_fixed = _fptr(fw), _fptr(fh)
     p.maxiter, p.tolerance, p.device = maxiter, (-1.0 if cfg.get("nmfx_disable_stop", False) else tol), int(device)
     p.sc_W_sparsity, p.sc_H_sparsity = sW, sH
+    ids = _gpu_ids(cfg)
+    if ids is not None:
+        p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
     r = _lib.Result()
     r.W, r.H, r.cost, r.tries_H, r.tries_W = _fptr(Wout), _fptr(Hout), _fptr(cost), _fptr(tH), _fptr(tW)
     _lib.check(_lib.load().nmfx_cnmfsc(C.byref(p), C.byref(r)))

@@ -570,8 +570,10 @@ def test_blocking_api_n_gpus_stop_rule_multi_source_and_lnmf(gpu_lib):
     ref = O.lnmf(V2, 64, cfg)
     got = gpu_lib.lnmf(V2, 64, dict(cfg, nmfx_gpus=[0, 0, 0]))
     assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
-    with pytest.raises(Exception, match="n_gpus > 1 is implemented for nmf and lnmf"):
-        gpu_lib.cnmf(V, 8, 2, dict(maxiter=1, nmfx_gpus=[0, 0]))
+    with pytest.raises(Exception, match="n_gpus > 1 is not implemented"):
+        gpu_lib.cnmfsc(V, 8, 2, dict(maxiter=1, nmfx_gpus=[0, 0]))
+    with pytest.raises(Exception, match="every shard needs at least T-1"):
+        gpu_lib.cnmf(V[:, :20], 8, 6, dict(maxiter=1, nmfx_gpus=8 * [0]))
     with pytest.raises(Exception):
         gpu_lib.nmf(V, 64, dict(maxiter=1, nmfx_gpus=[0, 7]))                      # no such device on a 1-GPU box
 
@@ -659,3 +661,97 @@ def test_engine_loop_stop_rule_equals_blocking_call(gpu_lib, div, path):
     assert rel_fro(We, Wr) < 1e-5 and rel_fro(He, Hr) < 1e-5 and rel_fro(cost[:ran].cpu().numpy(), cr) < (3e-6 if div == "kl" else 1e-6)
     assert np.max(np.abs(np.diff(cost[:ran].cpu().numpy()) - np.diff(cr))) < 1e-4 * tol
     e.close()
+
+
+@pytest.mark.parametrize("div", ["euclidean", "kl"])
+@pytest.mark.parametrize("ndev,m,n,K,T", [(2, 96, 200, 6, 4), (3, 128, 333, 8, 5), (8, 192, 1030, 32, 8), (2, 256, 520, 64, 4), (4, 129, 1024, 64, 2)])
+def test_blocking_api_n_gpus_cnmf_matches_oracle(gpu_lib, div, ndev, m, n, K, T):
+    """cnmf.m behind the blocking call on N column shards of one process (nmfx_problem.n_gpus; what a MEX caller of cnmf() gets): T-1 halo columns
+    of H copied between neighbouring devices after every H update (cnmf.m:188,219 shift across the shard edges), the packed W-step sums through the
+    peer reduce-scatter / all-gather.  device_ids names the one GPU of the box N times."""
+    from oracle import nmf_oracle as O
+    from conftest import record_err
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=10, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_gpus=[0] * ndev))
+    one = gpu_lib.cnmf(V, K, T, cfg)
+    assert len(got[2]) == len(ref[2])
+    e = dict(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
+    record_err(**e)
+    assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
+    assert rel_fro(got[0], one[0]) <= 3e-6 and rel_fro(got[1], one[1]) <= 3e-6      # vs one shard: summation order only
+
+
+def test_blocking_api_n_gpus_cnmf_stop_rule_and_sources(gpu_lib):
+    from oracle import nmf_oracle as O
+    m, n, K, T = 128, 600, 16, 4
+    V, W0, H0 = synth(m, n, K, T=T)
+    probe = O.cnmf(V, K, T, dict(W_init=W0, H_init=H0, maxiter=30, tolerance=1e-300))[2]
+    dec = -np.diff(probe)
+    assert np.all(dec[:14] > 0) and dec[9] > dec[10]
+    cfg = dict(W_init=W0, H_init=H0, maxiter=30, tolerance=float(0.5 * (dec[9] + dec[10])))
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_gpus=[0, 0, 0]))
+    assert 5 < len(ref[2]) < 30 and len(got[2]) == len(ref[2])                      # cnmf.m:254-257 fires at the same iteration on 3 shards
+    assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
+    Ks = [6, 10]
+    cfg = dict(divergence="kl", W_init=[W0[:, :6], W0[:, 6:]], H_init=[H0[:6], H0[6:]], W_sparsity=[0.05, 0.0], H_sparsity=[0.0, 0.1],
+               W_fixed=[False, True], maxiter=8, tolerance=1e-12)
+    ref = O.cnmf(V, Ks, T, cfg)
+    got = gpu_lib.cnmf(V, Ks, T, dict(cfg, nmfx_gpus=[0, 0]))
+    assert rel_fro(np.concatenate(got[0], 1), np.concatenate(ref[0], 1)) <= 1e-5 and rel_fro(np.vstack(got[1]), np.vstack(ref[1])) <= 1e-5
+    assert rel_fro(got[2], ref[2]) <= 1e-6
+
+
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
+@pytest.mark.parametrize("ndev,K", [(2, 64), (3, 20), (8, 128)])
+def test_blocking_api_n_gpus_nmfsc_matches_oracle(gpu_lib, sW, sH, ndev, K):
+    """nmfsc.m behind the blocking call on N column shards of one process (csrc/multi_sc.hip): one host thread per shard over nmfx_nmfsc_dev, the
+    all-reduce callback served by the peer reduce (fp32 for [V*H' | H*H'], fp64 for objectives and the distributed projfunc, projfunc.m:22-53).
+    Identical line-search tries (nmfsc.m:152-175, 203-226) are the point: every shard must take the oracle's branches."""
+    from oracle import nmf_oracle as O
+    m, n = 256, 1024 + 8 * 9
+    V, W0, H0 = synth(m, n, K)
+    V = 2.5 * V                                                # the global max(V) rescale (nmfsc.m:62) spans the shards
+    cfg = dict(W_init=W0, H_init=H0, maxiter=10, tolerance=1e-12, nmfx_path=2)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1, i2 = {}, {}, {}
+    W, H, cost = O.nmfsc(V, K, cfg, info=i0)
+    Wg, Hg, cg = gpu_lib.nmfsc(V, K, dict(cfg, nmfx_gpus=[0] * ndev), info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    assert rel_fro(Wg, W) <= 1e-5 and rel_fro(Hg, H) <= 1e-5, (rel_fro(Wg, W), rel_fro(Hg, H))
+    assert len(cg) == len(cost) and rel_fro(cg, cost) <= 1e-6
+    W1, H1, c1 = gpu_lib.nmfsc(V, K, cfg, info=i2)             # one shard, same kernels: summation order only
+    assert i2["triesH"] == i1["triesH"] and rel_fro(Wg, W1) <= 3e-6 and rel_fro(Hg, H1) <= 3e-6
+    if sH:                                                     # Hoyer postconditions hold on WHOLE rows of H (projfunc.m:3-7)
+        L1s = np.sqrt(n) - (np.sqrt(n) - 1) * sH
+        assert np.allclose(Hg.sum(1), L1s, rtol=1e-5) and np.allclose((Hg ** 2).sum(1), 1.0, rtol=1e-5) and Hg.min() >= 0
+
+
+def test_blocking_api_n_gpus_nmfsc_stop_rule_errors_and_determinism(gpu_lib):
+    from oracle import nmf_oracle as O
+    m, n, K = 256, 1024, 32
+    V, W0, H0 = synth(m, n, K)
+    probe = O.nmfsc(V, K, dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=25, tolerance=1e-300))[2]
+    dec = -np.diff(probe)
+    j = 8
+    assert np.all(dec[:j + 2] > 0) and dec[j] > dec[j + 1]
+    cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=25, tolerance=float(0.5 * (dec[j] + dec[j + 1])), nmfx_path=2)
+    ref = O.nmfsc(V, K, cfg)
+    a = gpu_lib.nmfsc(V, K, dict(cfg, nmfx_gpus=4 * [0]))
+    b = gpu_lib.nmfsc(V, K, dict(cfg, nmfx_gpus=4 * [0]))
+    assert 3 < len(ref[2]) < 26 and len(a[2]) == len(ref[2])                        # nmfsc.m:241-244 fires at the same iteration on 4 shards
+    assert rel_fro(a[0], ref[0]) <= 1e-5 and rel_fro(a[1], ref[1]) <= 1e-5 and rel_fro(a[2], ref[2]) <= 1e-6
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])   # run-to-run: bit-identical (fixed summation order)
+    Vn = V.copy()
+    Vn[3, 900] = -1.0
+    with pytest.raises(Exception, match="Negative values in data!"):
+        gpu_lib.nmfsc(Vn, K, dict(cfg, nmfx_gpus=[0, 0]))
+    with pytest.raises(Exception, match="fused kernels only"):                       # a worker thread's error text reaches the caller
+        gpu_lib.nmfsc(*([synth(256, 600, 300)[0]] + [300]), dict(H_sparsity=0.5, maxiter=2, nmfx_gpus=[0, 0]))
+    with pytest.raises(Exception):
+        gpu_lib.nmfsc(V, K, dict(cfg, nmfx_gpus=[0, 7]))                             # no such device on a 1-GPU box

@@ -138,6 +138,10 @@ def test_gateway_runs_every_branch_like_the_ctypes_path(mex, gpu_lib):
     W, H, cost = M.call(3, "cnmf", M.arr(V), M.arr(W0), M.arr(H0), M.arr([6], "int32"), M.arr([3.0]), o(divergence=0, maxiter=40, tolerance=5.0))
     Wr, Hr, cr = gpu_lib.cnmf(V, 6, 3, dict(W_init=W0, H_init=H0, maxiter=40, tolerance=5.0))
     assert W.shape == (96, 6, 3) and np.array_equal(W, Wr) and np.array_equal(H, Hr) and cost.shape == (len(cr), 1) and len(cr) < 40
+    # cnmf on two shards of one GPU (device_ids): halo columns between the shards
+    Wm, Hm, cm = M.call(3, "cnmf", M.arr(V), M.arr(W0), M.arr(H0), M.arr([6], "int32"), M.arr([3.0]), o(divergence=1, maxiter=5, tolerance=1e-12, device_ids=([0, 0], "int32")))
+    Wr, Hr, cr = gpu_lib.cnmf(V, 6, 3, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=5, tolerance=1e-12, nmfx_gpus=[0, 0]))
+    assert np.array_equal(Wm, Wr) and np.array_equal(Hm, Hr) and np.array_equal(cm.ravel(), cr)
     # lnmf
     W, H, cost = M.call(3, "lnmf", M.arr(V), M.arr(W2), M.arr(H0), M.arr([6], "int32"), M.arr([1.0]), o(divergence=1, maxiter=6, tolerance=1e-12))
     Wr, Hr, cr = gpu_lib.lnmf(V, 6, dict(W_init=W2, H_init=H0, maxiter=6, tolerance=1e-12))
@@ -149,6 +153,13 @@ def test_gateway_runs_every_branch_like_the_ctypes_path(mex, gpu_lib):
     assert np.array_equal(W, Wr) and np.array_equal(H, Hr) and np.array_equal(cost.ravel(), cr) and cost.shape[0] == 7
     assert [t for t in info["tries_H"].ravel() if t > 0] == i1["triesH"] and [t for t in info["tries_W"].ravel() if t > 0] == i1["triesW"]
     assert info["stepsize_H"][0, 0] == i1["stepsizeH"]
+    # nmfsc on two shards of one GPU (one host thread per shard inside the library)
+    i2 = {}
+    W, H, cost, info = M.call(4, "nmfsc", M.arr(V), M.arr(W2), M.arr(H0), M.arr([6], "int32"), M.arr([1.0]),
+                              o(maxiter=6, tolerance=1e-12, sc_H_sparsity=0.5, sc_W_sparsity=0.3, device_ids=([0, 0], "int32")))
+    Wr, Hr, cr = gpu_lib.nmfsc(V, 6, dict(W_init=W2, H_init=H0, maxiter=6, tolerance=1e-12, H_sparsity=0.5, W_sparsity=0.3, nmfx_gpus=[0, 0]), info=i2)
+    assert np.array_equal(W, Wr) and np.array_equal(H, Hr) and np.array_equal(cost.ravel(), cr)
+    assert [t for t in info["tries_H"].ravel() if t > 0] == i2["triesH"] == i1["triesH"]
     W, H, cost, info = M.call(4, "cnmfsc", M.arr(V), M.arr(W0), M.arr(H0), M.arr([6], "int32"), M.arr([3.0]), o(maxiter=4, tolerance=1e-12, sc_H_sparsity=0.5))
     Wr, Hr, cr = gpu_lib.cnmfsc(V, 6, 3, dict(W_init=W0, H_init=H0, maxiter=4, tolerance=1e-12, H_sparsity=0.5), info=i1)
     assert np.array_equal(W, Wr) and np.array_equal(H, Hr) and np.array_equal(cost.ravel(), cr) and info["tries_W"].shape == (12, 1)
