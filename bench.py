@@ -419,6 +419,7 @@ def main():
                        "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
                                 3: "fused cnmf passes, shift-sum in LDS + Gram denominators (V_hat never materialised)",
                                 4: "fused cnmf passes, shift-sum in LDS; R = V./V_hat in HBM, V_hat never",
+                                5: "KL with K > 256: S = W*H over column blocks on the stationary kernel, R = V./S in HBM, V_hat never",
                                 0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),

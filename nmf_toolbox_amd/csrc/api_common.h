@@ -131,6 +131,16 @@ struct nmfx_engine {
     bool fusedT_kl;           // KL cnmf on the fused passes: an S pass stores R = V./V_hat (in the V_hat buffer) and yields the cost of the state it
                               // started from (lagged, like the nmf fused path); the numerator passes then read R instead of V
     double *sumV_g, *colV_g;  // its closed-form cost term sum(V)
+    bool klw;                 // KL nmf / lnmf / constrainednmf with K > 256 (nmf.m:152-153,183-184 have no K limit): V_hat is never formed either.  S = W*H is
+                              // accumulated over column blocks of <= 256 components by the stationary kernel (functors 7 / 8, partial sums and then R = V./S in
+                              // the V_hat buffer), the numerators R*H' run block by block on the same kernel, W'*R on the two-operand GEMM; the cost lags like
+                              // the fused path's
+    int klw_nb, klw_k0[8], klw_kb[8];   // its column blocks
+    bool klw_vt;              // ... with the H step on the transposed copy of V: R' = V'./(H'*W') straight from the same kernels, then (R'*W)' -- every V / R tile
+                              // read along its contiguous dimension, no two-operand GEMM (needs V' and the W' copy)
+    int klw_hsplit;
+    long klw_hcps;
+    float *slabsH;
     bool qgemm;               // cnmf, T > 1: H-step numerator sum_t W_t' * lshift_t(A) as ONE (KT x n x m) GEMM Q = W_flat' * A + a shift-sum over t
     float *Hpad, *Qbuf, *slabsT;
     int nsplit_T;

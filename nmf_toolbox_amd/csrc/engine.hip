@@ -155,6 +155,20 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumV_g = c.take<double>(1);
         e->colV_g = c.take<double>(e->n);
     }
+    if (e->klw) {
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * e->m * 256) : nullptr;
+        const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        e->sumV = c.take<double>(1);
+        e->colV = c.take<double>(e->n);
+        if (e->klw_vt) {
+            e->VT = c.take<float>((size_t)e->m * e->n);
+            e->WT = c.take<float>(mKT);
+            e->slabsH = e->klw_hsplit > 1 ? c.take<float>((size_t)e->klw_hsplit * Kn) : nullptr;
+            const int needh = (int)((e->n + 127) / 128) * e->klw_hsplit;
+            if (needh > e->n_cost_partials) { e->n_cost_partials = needh; e->cost_partials = c.take<double>(needh); }
+        }
+    }
     L.total = c.off;
     L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
     return L;
@@ -248,6 +262,21 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    static const bool no_klw = getenv("NMFX_KL_WIDE_OFF") != nullptr;   // dev switch (A/B runs): K > 256 on the materialised path
+    e->klw = !e->fused && e->algo != 1 && e->T == 1 && e->div == NMFX_DIV_KL && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
+             e->m >= 64 && e->n >= 64 && d->path != 1 && !no_klw;
+    if (e->klw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
+        const int units = e->K / 32;
+        e->klw_nb = (e->K + 255) / 256;
+        for (int b = 0, k0 = 0; b < e->klw_nb; ++b) {
+            const int u = units / e->klw_nb + (b < units % e->klw_nb ? 1 : 0);
+            e->klw_k0[b] = k0; e->klw_kb[b] = 32 * u;
+            k0 += 32 * u;
+        }
+        e->nsplit_T = fused_split((e->m + 127) / 128, e->n, 256, &e->cps_T);
+        e->klw_vt = !no_vt && room_vt;
+        e->klw_hsplit = fused_split((e->n + 127) / 128, e->m, 256, &e->klw_hcps);
+    }
     static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
     e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
     // cnmf on the fused passes, unsharded: the same Gram-form cost (its explicit residual pass is a third of the iteration)
@@ -563,6 +592,97 @@ nmfx_status fusedT_kl_cost(nmfx_engine *e) {
     return NMFX_OK;
 }
 
+// KL with K > 256 (e->klw).  S pass: S = W*H accumulated block by block in the V_hat buffer; the last block maps it to R = V./S (kept there for the
+// numerator passes when store_R) and reduces sum(V.*log(V./S)) when with_cost
+nmfx_status klw_s_pass(nmfx_engine *e, bool store_R, bool with_cost) {
+    Scope s(e, TAG_FUSED_COST);
+    for (int b = 0; b < e->klw_nb; ++b) {
+        const bool last = b + 1 == e->klw_nb;
+        const int kb = e->klw_kb[b];
+        long cps = 0;
+        const int split = fused_split((e->m + 127) / 128, e->n, kb, &cps);
+        if ((long)((e->m + 127) / 128) * split > e->n_cost_partials) { set_error("klw_s_pass: cost partials too small"); return NMFX_ERR_INVALID; }
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = e->W + (size_t)e->m * e->klw_k0[b]; f.xs_r = 1; f.xs_k = e->m;
+        f.Y = e->H + e->klw_k0[b]; f.y_stride = e->K;
+        f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = kb; f.c_per_split = cps;
+        f.Sin = b > 0 ? e->Vhat : nullptr;
+        f.Rout = (!last || store_R) ? e->Vhat : nullptr;
+        f.cost_partials = (last && with_cost) ? e->cost_partials : nullptr;
+        TRY(launch_fused(e->st, f, split, true, last ? 8 : 7, false, 0));
+        if (last) e->n_cost_used = (int)((e->m + 127) / 128) * split;
+    }
+    return NMFX_OK;
+}
+// N(:, block) = R * H(block, :)' for every column block, R = V./S in the V_hat buffer: the W-step form without a first product
+nmfx_status klw_num_pass(nmfx_engine *e, float *out) {
+    for (int b = 0; b < e->klw_nb; ++b) {
+        const int kb = e->klw_kb[b];
+        long cps = 0;
+        int split = fused_split((e->m + 127) / 128, e->n, kb, &cps);
+        if (split > e->nsplit_T) { split = e->nsplit_T; cps = e->cps_T; }
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.Y = e->H + e->klw_k0[b]; f.y_stride = e->K;
+        f.D = e->Vhat; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = kb; f.c_per_split = cps;
+        float *dst = out + (size_t)e->m * e->klw_k0[b];
+        f.out = split == 1 ? dst : e->slabsT; f.slab_stride = e->m * (long)kb; f.os_r = 1; f.os_k = e->m;
+        {
+            Scope s(e, TAG_FUSED_W);
+            TRY(launch_fused(e->st, f, split, true, 0, true, 0));
+        }
+        if (split > 1) { Scope s(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->slabsT, split, f.slab_stride, f.slab_stride, dst, 0)); }
+    }
+    return NMFX_OK;
+}
+// H step on the transposed copy of V: rows of V' (columns j of V) stationary, rows of W (the W' copy) streamed.  R' = V'./(H'*W') block by block into the V_hat
+// buffer (as n x m), then Gn(block, :) = (R'*W(:, block))' on the same kernel without a first product
+nmfx_status klw_hstep_vt(nmfx_engine *e) {
+    {
+        Scope s(e, TAG_SMALL);
+        TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
+    }
+    {
+        Scope s(e, TAG_FUSED_COST);
+        for (int b = 0; b < e->klw_nb; ++b) {
+            const bool last = b + 1 == e->klw_nb;
+            long cps = 0;
+            const int split = fused_split((e->n + 127) / 128, e->m, e->klw_kb[b], &cps);
+            FusedParams f;
+            memset(&f, 0, sizeof(f));
+            f.X = e->H + e->klw_k0[b]; f.xs_r = e->K; f.xs_k = 1;
+            f.Y = e->WT + e->klw_k0[b]; f.y_stride = e->K;
+            f.D = e->VT; f.ldd = e->n; f.R = e->n; f.Cn = e->m; f.K = e->klw_kb[b]; f.c_per_split = cps;
+            f.Sin = b > 0 ? e->Vhat : nullptr;
+            f.Rout = e->Vhat;
+            TRY(launch_fused(e->st, f, split, true, last ? 8 : 7, false, 0));
+        }
+    }
+    const long Kn = (long)e->K * e->n;
+    int split = e->klw_hsplit;
+    for (int b = 0; b < e->klw_nb; ++b) {
+        FusedParams g;
+        memset(&g, 0, sizeof(g));
+        g.Y = e->WT + e->klw_k0[b]; g.y_stride = e->K;
+        g.D = e->Vhat; g.ldd = e->n; g.R = e->n; g.Cn = e->m; g.K = e->klw_kb[b]; g.c_per_split = e->klw_hcps;
+        g.out = (split == 1 ? e->Gn : e->slabsH) + e->klw_k0[b]; g.slab_stride = Kn; g.os_r = e->K; g.os_k = 1;
+        Scope s(e, TAG_HNUM);
+        TRY(launch_fused(e->st, g, split, true, 0, true, 0));
+    }
+    if (split > 1) { Scope s(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->slabsH, split, Kn, Kn, e->Gn, 0)); }
+    return NMFX_OK;
+}
+// ... and the cost of the CURRENT (W, H) from the S pass's partials (closed-form sum(V_hat) - sum(V), like the fused path)
+nmfx_status klw_cost(nmfx_engine *e) {
+    Scope s(e, TAG_SMALL);
+    TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+    TRY(col_reduce(e->st, e->W, e->m, e->m, e->K, 0, e->Gpvec));
+    TRY(cost_from_partials(e, e->n_cost_used, true));
+    e->cost_valid = true;
+    return NMFX_OK;
+}
+
 nmfx_status refresh_w_derived(nmfx_engine *e, bool have_colsum = false) {   // W^T copy (streamed operand of the H step) + KL / Gram denominators
     TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
     if (e->div == NMFX_DIV_KL && !have_colsum) {   // (after a W update the update kernel has already left colsum(W) in Gpvec)
@@ -607,12 +727,13 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     e->V = V; e->W = W; e->Hext = H; e->H = H + (size_t)e->K * e->hL; e->packed = packed;
     // the transposed copy of V is optional: it is used when the workspace the caller brought has the room for it (nmfx_engine_workspace_bytes
     // asks for it when the device looked roomy at that moment; a caller that allocated less simply gets the path without it)
-    if ((e->use_vt || e->use_vtq) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = false;
-    else if (!e->use_vt && !e->use_vtq) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
+    if ((e->use_vt || e->use_vtq || e->klw_vt) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = e->klw_vt = false;
+    else if (!e->use_vt && !e->use_vtq && !e->klw_vt) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
         nmfx_engine probe = *e;
         probe.use_vt = probe.fused && probe.div == NMFX_DIV_EUCLIDEAN && getenv("NMFX_NO_VT") == nullptr;
         probe.use_vtq = probe.fusedT && probe.qgemm && probe.hL == 0 && probe.hR == 0 && getenv("NMFX_NO_VT") == nullptr && probe.KT % probe.vtq_block == 0 && fused_supported(probe.vtq_block);
-        if ((probe.use_vt || probe.use_vtq) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; }
+        probe.klw_vt = probe.klw && getenv("NMFX_NO_VT") == nullptr;
+        if ((probe.use_vt || probe.use_vtq || probe.klw_vt) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; e->klw_vt = probe.klw_vt; }
     }
     Layout L = layout(e, workspace);
     if (L.total > workspace_bytes) {
@@ -692,7 +813,7 @@ nmfx_status nmfx_engine_sumvv_set_global(nmfx_engine *e, const double *src_dev) 
 }
 // 0: the cost of iteration i is ready after hstep(i); 1: after wstep_partial(i+1); 2: after wstep_finish(i+1) (read it there; engines of kind 2
 // may also deliver it at point 1 -- reading at point 2 is always right for them)
-int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl) ? 1 : 0); }
+int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->klw) ? 1 : 0); }
 
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
 nmfx_status nmfx_engine_init(nmfx_engine *e) {
@@ -744,6 +865,13 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             e->cost_valid = false;
         }
         return NMFX_OK;
+    }
+    if (e->klw) {                  // nor here
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = false;
+        TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 0, e->colV));
+        if (e->klw_vt) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+        return sum_vec(e->st, e->colV, e->n, e->sumV);
     }
     if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
         Scope s(e, TAG_SMALL);
@@ -826,12 +954,17 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
         TRY(fusedT_kl_cost(e));
     }
+    if (e->klw) {         // the same for nmf with K > 256
+        TRY(klw_s_pass(e, !e->all_fixW, true));
+        TRY(klw_cost(e));
+    }
     e->wstep_gram = e->fusedT && e->gram_cost;   // the cost of the state this step starts from follows in wstep_finish (no host latch here: once the device flag
                                                  // is set the conditional residual pass simply runs every time -- the same work the un-lagged cost pass was)
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
     if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
+    else if (e->klw) TRY(klw_num_pass(e, e->packed));
     else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
     if (e->lagram) {   // Hs*Hs' from the T lag Grams L_d = sum_u H(:,u) H(:,u+d)' (K x T*K, contraction n, on the zero-padded copy) + boundary terms
         TRY(ensure_hpad(e));
@@ -947,7 +1080,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
         e->cost_valid = false;
     }
-    if (e->gram || e->fusedT_kl) return NMFX_OK;
+    if (e->gram || e->fusedT_kl || e->klw) return NMFX_OK;
     return recon(e, false);
 }
 
@@ -1073,8 +1206,13 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(fusedT_pass(e, FT_S_KL, nullptr));
             a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         }
+        if (e->klw && !e->klw_vt) {         // likewise
+            TRY(klw_s_pass(e, true, false));
+            a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        }
         e->hpad_valid = false;
-        if (e->qgemm) {
+        if (e->klw_vt) TRY(klw_hstep_vt(e));
+        else if (e->qgemm) {
             // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
             // (K x n) GEMM with contraction T*m whose 64-row output starves the tiles
             if (e->use_vtq && a.p == e->V && !a.p2 && a.func == NMFX_PRO_NONE && e->nvalid == e->n) {
@@ -1174,7 +1312,7 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    if (e->fusedT_kl) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT_kl || e->klw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
     if (e->fusedT && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
     if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
@@ -1193,6 +1331,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     if (e->cost_valid) return NMFX_OK;
     if (e->fused) return fused_wpass(e, false);
     if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
+    if (e->klw) { TRY(klw_s_pass(e, false, true)); return klw_cost(e); }
     if (e->fusedT && e->gram_cost) {
         TRY(fusedT_pass(e, FT_COST_EUC, nullptr));
         Scope s(e, TAG_SMALL);
@@ -1202,7 +1341,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->fusedT ? 3 : (e->gram ? 2 : 0))); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 2 Gram form on the GEMM, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->gram ? 2 : 0)))); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
@@ -1275,7 +1414,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
-        if (e->fusedT || e->fusedT_kl) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction
+        if (e->fusedT || e->fusedT_kl || e->klw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;

@@ -27,6 +27,10 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //       5 alpha-beta, alpha ~= 0 (nmf.m:162-163,193-194,214): A = V.^alpha .* S.^(beta-1), B = S.^(alpha+beta-1); D holds V.^alpha
 //       6 R = S - V (the residual) + euclidean cost: the gradients of nmfsc.m:144-148,194-200 in ONE contraction, dH = W'*(W*H - V) /
 //         dW = (W*H - V)*H', instead of the difference of two separately rounded products (which cancels as the fit improves)
+//       7 / 8 (cost-only form, W-step form): the first product in SEVERAL launches over column blocks of a factor wider than 256 (KL with K > 256,
+//         nmf.m:152-153,183-184 have no K limit).  Every launch starts its S tile from the partial sums of the launches before it (p.Sin, read like the
+//         V tile; nullptr = zeros) and contracts its own <= 256 components: 7 stores the raw partial S (p.Rout), 8 is the last block and goes on
+//         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -47,6 +51,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
+    constexpr bool S_IN = FUNC == 7 || FUNC == 8;   // S accumulated over several launches (column blocks of a wide factor)
+    constexpr int MF = FUNC == 8 ? 3 : FUNC;        // the element map
+    static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
     constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
     static_assert(!DUAL || (K <= 128 && TT == 1), "dual-map kernels: K <= 128 (two accumulator sets + the stationary operand must fit 512 VGPRs)");
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     };
     // piece i of 16: D_RC two dwords (columns c0 + 32*jb + {(reg&3) + 8*(reg>>2)}), else half of the 8 float4 (one per even i)
     auto load_d_piece = [&](const __amdgpu_buffer_rsrc_t srd, int t, int i) {
-        if (PROBE & 4) return;
+        if ((PROBE & 4) || FUNC == 7) return;
         if (D_RC) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -148,6 +155,20 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         }
     };
 
+    // partial S of the same tile (S_IN), same register layout as d[]: a descriptor of zero bytes (no p.Sin) reads zeros, so the first launch
+    // of a chain runs the same instruction stream
+    float sin_[S_IN ? 32 : 1];
+    auto s_srd = [&](int t) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p.Sin ? p.Sin + p.ldd * (cbeg + (long)t * FT_C) : p.D), 0, p.Sin ? (int)(unsigned)(tile_rows(t) * p.ldd * 4) : 0, 0x00020000);
+    };
+    auto load_s_piece = [&](const __amdgpu_buffer_rsrc_t srd, int i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = 2 * i + u, jb = e >> 4, reg = e & 15;
+            sin_[S_IN ? e : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0));
+        }
+    };
+
     double cost = 0.0;
     if (ntiles > 0) {
         const i32x4 ys = y_srd(0);
@@ -156,6 +177,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         const __amdgpu_buffer_rsrc_t ds0 = d_srd(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) load_d_piece(ds0, 0, i);
+        if (S_IN) {
+            const __amdgpu_buffer_rsrc_t ss0 = s_srd(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) load_s_piece(ss0, i);
+        }
     }
     for (int t = 0; t < ntiles; ++t) {
         const int b = (PROBE & 1) ? 0 : (t & 1);
@@ -165,13 +191,16 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // rows (loads return in order), and V is first needed in P2, a whole P1 (>= 3 us of MFMAs) later: leave them in
             // flight instead of draining to vmcnt(0), which exposed one HBM round trip (~2 us of a 13.6 us tile at K = 256) per tile.
             // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
-            if (NEED_S && !(PROBE & 4)) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            // S_IN: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
+            if (S_IN) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else if (NEED_S && !(PROBE & 4)) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
         }
         const float *Yt = lds + b * BUF;
         const i32x4 ysn = y_srd(tn);
         const __amdgpu_buffer_rsrc_t dsn = d_srd(tn);
+        const __amdgpu_buffer_rsrc_t ssn = S_IN ? s_srd(tn) : dsn;
         int dma_c = 0;                                        // rows of tile tn issued so far (compile-time after unrolling)
         auto dma_some = [&](int upto) {                       // issue rows until `upto` have been issued
             if (PROBE & 1) return;
@@ -199,6 +228,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
             const int sl = reg & 1;
             if (PROBE & 2) { if (u == 0) asm volatile("" : "+v"(sacc[jb][reg])); return; }
+            if (FUNC == 7) return;                            // the raw partial S is what gets stored
             const float v = d[jb * 16 + reg];
             const bool live = !RAG || (32 * jb + (reg & 3) + 8 * (reg >> 2)) < cvh;   // streamed index inside the matrix
             if (FUNC == 4) {                                  // IS: B = 1./S, A = V./S.^2, cost terms q - ln(q) with q = V./S (the -1 per element: caller)
@@ -223,10 +253,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
                 if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
-            } else if (FUNC >= 2) {
+            } else if (MF >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
-                if (FUNC == 3) {
+                if (MF == 3) {
                     if (u == 2) er[sl] = (PROBE & 8) ? er[sl] * 1.25f : __builtin_amdgcn_logf(er[sl]);   // log2(q)
                     if (u == 3) tc = live ? fmaf(v, er[sl], tc) : tc;   // sum(V_hat - V) is added in closed form by the caller (see FusedParams)
                 }
@@ -236,7 +266,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     sacc[jb][reg] = live ? v : 0.0f;
                 }
             }
-            if (((FUNC == 1 || FUNC == 6) && u == 0) || (FUNC == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
+            if (((FUNC == 1 || FUNC == 6) && u == 0) || (MF == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
         // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
         // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[jb][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) sacc[jb][e] = S_IN ? sin_[S_IN ? jb * 16 + e : 0] : 0.0f;
             float4 a_cur = g1_read(0, 0);
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {                          // P1 (ph 0), P2 (ph 1)
@@ -263,6 +293,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                         sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
                         if (ph == 1) emap_fill(0, 4 * g + e, 4 * NG);
                         if (ph == 0 && e == 0) dma_some(((g + 1) * ROWS_PER_WAVE + NG - 1) / NG);
+                        if (S_IN && ph == 1 && 4 * g + e < 16) load_s_piece(ssn, 4 * g + e);   // partial S of the next tile (sin_ went into sacc at the tile top)
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     one(0, a_cur.x); one(1, a_cur.y); one(2, a_cur.z); one(3, a_cur.w);
@@ -304,11 +335,14 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 for (int kb = 0; kb < NKB; ++kb) y_cur[kb] = y_nxt[kb];
             }
         } else {
+            // S_IN: the next tile's DMA rows went out during P1, only the 32 partial-S loads of P2 are younger: the rows have landed once at most those
+            // are in flight (the R stores and V loads below would push the count past what s_waitcnt can express at the tile top)
+            if (S_IN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
-            if (D_RC && FUNC >= 2 && FUNC <= 3 && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
 #pragma unroll
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         if (lane == 0) red[w] = cost;
         __syncthreads();
         // KL: the kernel sums V.*log2(V./V_hat); ln 2 is applied here, sum(V_hat) - sum(V) by the caller in closed form
-        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (FUNC == 3 ? 0.6931471805599453 : 1.0);
+        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (MF == 3 ? 0.6931471805599453 : 1.0);
     }
 }
 

@@ -279,7 +279,7 @@ static nmfx_status dispatch_views(hipStream_t st, const GemmParams &p) {
 
 void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     bm = 128; bn = 128;
-    if (M % 128 != 0 && M % 64 == 0 && M <= 192) bm = 64;
+    if (M % 128 != 0 && M % 64 == 0) bm = 64;   // (320, 448, ...: whole 64-row tiles instead of the guarded-edge kernel)
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
     // few output tiles (W*(H*H'): 64 of them at C2): half-height tiles double the workgroups of a launch that cannot fill the chip anyway
     static const bool no_half = getenv("NMFX_GEMM_NO_HALF_TILES") != nullptr;   // dev switch (A/B runs)

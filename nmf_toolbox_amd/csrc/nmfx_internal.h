@@ -115,7 +115,8 @@ struct FusedParams {
     long c_per_split;     // streamed rows per grid.y slice (multiple of 64)
     int K;
     float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
-    float *Rout;          // func 2 / 3, cost-only pass, W-step form: also store R = V./S (m x n, ld = ldd); nullptr = don't
+    float *Rout;          // func 2 / 3, cost-only pass, W-step form: also store R = V./S (m x n, ld = ldd); nullptr = don't.  func 7: the partial S; func 8: R
+    const float *Sin;     // func 7 / 8: partial S (m x n, ld = ldd) of the column blocks contracted by earlier launches, or nullptr (first block)
     float *out2;          // func 4 / 5 (dual-map divergences), EPI 0: the second contraction (denominators), same indexing
     float ab_alpha, ab_beta;   // func 5
     float inv_exp;        // func 4 / 5, EPI 1: outer exponent 1/alpha of nmf.m:193-194 (1 = none); set it to 1 for func 4
@@ -133,7 +134,8 @@ struct FusedParams {
 };
 bool fused_supported(int K);
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
-// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128) | 6 R=S-V + euclidean cost (do_g2, slabs out);  do_g2=false: cost-only pass
+// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128) | 6 R=S-V + euclidean cost (do_g2, slabs out)
+//       | 7 / 8 (do_g2=false): S over column blocks of a wide factor, see fused_kernel.h;  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
 // ---- small products of the Gram form (small_mm.hip) ----------------------------------------------------------------------

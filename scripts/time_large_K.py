@@ -11,6 +11,8 @@ def run(m, n, K, div, path, iters=6):
     fl = 8.0 * m * n * K if div == "kl" else 6.0 * m * n * K
     print("%s %dx%d K=%d path %d: %.3f ms / iteration, %.1f TFLOP/s by the fused paths' flop count (%.2f of peak), path_kind %s" % (div, m, n, K, path, dt * 1e3, fl / dt / 1e12, fl / dt / 157.3e12, e.path_kind))
     e.close()
-for K in (256, 320, 512):
-    for div in ("kl", "euclidean"):
+Ks = [int(k) for k in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 320, 512]
+divs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["kl", "euclidean"]
+for K in Ks:
+    for div in divs:
         run(8192, 32768, K, div, 0)

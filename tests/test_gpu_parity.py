@@ -685,6 +685,49 @@ def test_nmf_K_above_256(gpu_lib, div, m, n, K):
     _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1)), ref)
 
 
+@pytest.mark.parametrize("m,n,K,algo", [(512, 768, 320, "nmf"), (300, 1000, 257, "nmf"), (640, 512, 512, "nmf"), (257, 4160, 288, "nmf"), (384, 1024, 800, "nmf"),
+                                        (512, 768, 320, "lnmf"), (200, 900, 300, "src2")])
+def test_nmf_kl_K_above_256_in_column_blocks(gpu_lib, m, n, K, algo):
+    """nmf.m:152-153,183-184 with K > 256 (the reference has no K limit): S = W*H accumulated over column blocks of <= 256 components by the stationary kernel
+    (functors 7 / 8), R = V./S in HBM, V_hat never -- engine path 5.  Any K through the blocking call (padded to a multiple of 32), ragged m / n, three blocks
+    (K = 800), lnmf, two sources with sparsity and fixed flags, the stop rule handing back the state of the iteration it fired on, column shards."""
+    import torch
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
+    V, W0, H0 = synth(m, n, K)
+    if K % 32 == 0:
+        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence="kl", use_dist=False,
+                   algorithm="lnmf" if algo == "lnmf" else "nmf")
+        assert e.path_kind == 5 and e.cost_lag == 1
+        e.close()
+    if algo == "lnmf":
+        cfg = dict(W_init=W0 / W0.sum(0), H_init=H0, maxiter=6, tolerance=1e-12)
+        ref = O.lnmf(V, K, cfg)
+        got = gpu_lib.lnmf(V, K, cfg)
+        assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
+        return
+    if algo == "src2":
+        Ks = [120, 180]
+        cfg = dict(divergence="kl", W_init=[W0[:, :120], W0[:, 120:]], H_init=[H0[:120], H0[120:]], W_sparsity=[0.05, 0.0], H_sparsity=[0.0, 0.1],
+                   W_fixed=[False, True], maxiter=6, tolerance=1e-12)
+        ref = O.nmf(V, Ks, cfg)
+        got = gpu_lib.nmf(V, Ks, cfg)
+        assert rel_fro(np.hstack(got[0]), np.hstack(ref[0])) <= 1e-5 and rel_fro(np.vstack(got[1]), np.vstack(ref[1])) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
+        return
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.nmf(V, K, cfg)
+    _check(gpu_lib.nmf(V, K, cfg), ref)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0, 0, 0])), ref)          # three column shards of one GPU
+    probe = O.nmf(V, K, dict(cfg, maxiter=14, tolerance=1e-300))[2]
+    dec = -np.diff(probe)
+    if np.all(dec[:8] > 0) and dec[5] > dec[6]:
+        cfg2 = dict(cfg, maxiter=14, tolerance=float(0.5 * (dec[5] + dec[6])))
+        ref2 = O.nmf(V, K, cfg2)
+        got2 = gpu_lib.nmf(V, K, cfg2)
+        assert len(got2[2]) == len(ref2[2]) < 14
+        _check(got2, ref2)
+
+
 # ---- IS and alpha-beta on the fused kernels (two element maps / two accumulator sets per pass, K <= 128): split and un-split epilogues,
 # ragged shapes, padded K, sources with sparsity / fixed flags; against the oracle and against the generic (materialised V_hat) path ----
 @pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5)), ("ab", (2.0, -0.5)), ("ab", (1.0, 0.5)), ("ab", (1.5, -1.5))])
