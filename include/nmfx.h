@@ -147,6 +147,9 @@ nmfx_status nmfx_nmfsc_profile(int32_t enable);
 int32_t nmfx_nmfsc_profile_ntags(void);
 const char *nmfx_nmfsc_profile_tag_name(int32_t tag);
 nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag);
+/* measurement hook (bench.py --workload c4sc): completion time, in seconds from the start of the iterations, of every outer iteration of the last
+ * nmfx_cnmfsc call on this thread; returns their number */
+int32_t nmfx_sc_iteration_seconds(double *out, int32_t capacity);
 /* V_hat = ReconstructFromDecomposition(W, H)              -- replaces ReconstructFromDecomposition.m:1 */
 nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t dtype, const void *W,
                              const void *H, void *V_hat, int32_t device);

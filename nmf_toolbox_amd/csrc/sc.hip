@@ -1,4 +1,6 @@
 // nmfsc (nmfsc.m:57-245) and cnmfsc (cnmfsc.m:67-277): host-driven line searches over the fused / GEMM kernels and projfunc.
+#include <chrono>
+
 #include "api_common.h"
 
 using namespace nmfx;
@@ -56,6 +58,7 @@ enum ScTag { SC_OBJ = 0, SC_PROJ = 1, SC_HTERMS = 2, SC_WTERMS = 3, SC_SMALL = 4
 static const char *const kScTagNames[SC_COUNT] = {"fused:objective pass (S=W*H -> 0.5||V-S||^2)", "projfunc (Hoyer projection of the rows of H)",
                                                   "H-step terms (sparse H: fused residual pass dH = W'*(W*H-V) + objective; MU: W'*V, (W'*W)*H)", "W-step terms (MU: V*H', W*(H*H'); sparse W: fused residual pass)", "small kernels (transposes, updates)"};
 static thread_local Profiler g_sc_prof;
+static thread_local std::vector<double> g_iter_t;   // seconds from the start of the iterations to the end of every outer iteration of the last sc call (bench.py)
 
 // device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
 struct ScDev {
@@ -573,6 +576,12 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     DeviceGuard dg_;
     TRY(check_device(p->device));
     hipStream_t st = nullptr;
+    g_sc_prof.st = st;
+    if (g_sc_prof.on) { g_sc_prof.events.clear(); g_sc_prof.pool_used = 0; }
+    Profiler *pf = &g_sc_prof;
+    IoStats &io = io_stats();
+    io = IoStats{};
+    const auto t_in = std::chrono::steady_clock::now();
     double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity, L1a = 0, L1s = 0;
     if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // cnmfsc.m:100-104
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // cnmfsc.m:116-120
@@ -616,6 +625,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     };
     // V_hat = RFD(Wx (m x K x T), Hx) and 0.5*||V - V_hat||^2
     auto rfd = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+        PScope ps(pf, SC_OBJ);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = n; g.Kc = KT;
         g.A = OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -626,6 +636,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     // out (K x n) = sum_t Wx_t' * lshift_t(X)
     // (X2 given: X is replaced by X2 - X element-wise while it is loaded -- the gradient in residual form, see run_nmfsc)
     auto hgrad = [&](const float *Wx, const float *X, float *out, const float *X2 = nullptr) -> nmfx_status {
+        PScope ps(pf, SC_HTERMS);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = K; g.N = n; g.Kc = (long)T * m;
         g.A = OpView{Wx, nullptr, m, VIEW_WSTACK_KC, (int)m, m * (long)K, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -635,6 +646,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     };
     // out (m x K) = X * rshift_t(H)'
     auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
+        PScope ps(pf, SC_WTERMS);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = K; g.Kc = n;
         g.A = OpView{X, X2, m, VIEW_RC, 0, 0, 0, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
@@ -645,7 +657,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
 
     double stepH = 1.0;
     std::vector<double> stepW(T, 1.0);                                                           // cnmfsc.m:147-148
-    TRY(rfd(W, H, &r->cost[0]));                                                                 // cnmfsc.m:152-153
+    TRY(rfd(W, H, &r->cost[0]));                                                                 // cnmfsc.m:152-153  (reads the objective: the uploads have drained)
+    const auto t_it = std::chrono::steady_clock::now();
+    g_iter_t.clear();
     int ncost = p->maxiter + 1, nH = 0, nW = 0;
     bool early = false;
     double *nrm2 = costd.as<double>() + 8;
@@ -662,7 +676,10 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 }
                 for (;;) {
                     ++tries;
-                    TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, small64h ? nullptr : G1.as<float>(), -stepH, HT, small64h ? g64h.as<double>() : nullptr));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
+                    {
+                        PScope ps(pf, SC_PROJ);
+                        TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, small64h ? nullptr : G1.as<float>(), -stepH, HT, small64h ? g64h.as<double>() : nullptr));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
+                    }
                     TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
                     double newobj;
                     TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181
@@ -729,6 +746,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     // happens to start a mapping (found by scripts/fuzz_campaign_sc.py)
                     g.B = OpView{H - (long)K * t, nullptr, (long)K, VIEW_HSTACK_KC, K, 0, -t, NMFX_PRO_NONE, 0.f, 0.f, 0, (long)K * t};
                     g.C = Vh.as<float>(); g.ldc = m; g.accumulate = 1; g.clamp0 = 1; g.epi = EPI_STORE; g.splitk = 1;
+                    PScope ps(pf, SC_WTERMS);
                     TRY(launch_gemm(st, g));
                 }
             }
@@ -736,6 +754,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         }
         NMFX_HIP(hipMemcpyAsync(W0, W, mKT * 4, hipMemcpyDeviceToDevice, st));                   // W0 = W   cnmfsc.m:266
         TRY(rfd(W0, H, &r->cost[it]));                                                           // cnmfsc.m:269-270
+        g_iter_t.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_it).count());   // (the objective was read on the host: the iteration is complete)
         if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // cnmfsc.m:273-276
             ncost = it + 1;
             break;
@@ -747,8 +766,11 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     r->converged_early = early ? 1 : 0;
     if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
     if (r->tries_W) for (int i = nW; i < p->maxiter * T; ++i) r->tries_W[i] = 0;
+    const auto t_out = std::chrono::steady_clock::now();
     TRY(download(st, W, p->dtype, r->W, mKT));
     TRY(download(st, H, p->dtype, r->H, Kn));
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    io.ingest_s = sec(t_in, t_it); io.iterate_s = sec(t_it, t_out); io.egress_s = sec(t_out, std::chrono::steady_clock::now());
     return NMFX_OK;
 }
 
@@ -795,5 +817,12 @@ nmfx_status nmfx_nmfsc_profile(int32_t enable) {
 int32_t nmfx_nmfsc_profile_ntags(void) { return SC_COUNT; }
 const char *nmfx_nmfsc_profile_tag_name(int32_t tag) { return (tag >= 0 && tag < SC_COUNT) ? kScTagNames[tag] : ""; }
 nmfx_status nmfx_nmfsc_profile_read(double *ms_per_tag, int32_t *count_per_tag) { return g_sc_prof.read(SC_COUNT, ms_per_tag, count_per_tag); }
+// seconds from the start of the iterations to the end of each outer iteration of the last nmfx_cnmfsc call on this thread (every iteration ends with an
+// objective the host reads, so these are completion times); returns how many there are
+int32_t nmfx_sc_iteration_seconds(double *out, int32_t capacity) {
+    const int32_t nn = (int32_t)g_iter_t.size();
+    for (int32_t i = 0; i < nn && i < capacity; ++i) out[i] = g_iter_t[i];
+    return nn;
+}
 
 }  // extern "C"
