@@ -226,8 +226,9 @@ def bench_cnmfsc(args):
     its = args.steps / dt
     tries = info["triesH"]
     f = 2.0 * m * n * K * T
-    label = {names[0]: "V_hat = W_flat*H_stack + 0.5||V - V_hat||^2 (two-operand GEMM with shift views, V_hat stored: cnmfsc.m:262 updates it in place)",
-             names[2]: "dH = sum_t W_t'*lshift_t(V_hat - V) (two-operand GEMM, contraction T*m)", names[3]: "W-step terms per slice t: V*Hs', V_hat*Hs', V_hat += dW*Hs (two-operand GEMMs)"}
+    label = {names[0]: "objective passes: S = sum_t W_t*rshift_t(H) in registers -> 0.5||V - S||^2 (fused_kernel<K*T, ..., TT=T>, cost-only form; S stored as V_hat only where cnmfsc.m:215,269 keep it)",
+             names[2]: "dH = sum_t W_t'*lshift_t(V_hat - V) as Q = W_flat'*(V_hat - V) (two-operand GEMM) + shift-sum",
+             names[3]: "W-step terms: V*H_stack' for all t in one fused pass; per slice V_hat*rshift_t(H)' and V_hat = max(V_hat + dW*rshift_t(H), 0) (functor 9, in place)"}
     work = {names[0]: (f, 4.0 * (2 * m * n + m * K * T + K * n)), names[2]: (f, 4.0 * (2 * m * n + m * K * T + K * n)), names[3]: (f / T, 4.0 * (m * n + m * K + K * n))}
     tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in work}
     roof = None

@@ -31,6 +31,8 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         nmf.m:152-153,183-184 have no K limit).  Every launch starts its S tile from the partial sums of the launches before it (p.Sin, read like the
 //         V tile; nullptr = zeros) and contracts its own <= 256 components: 7 stores the raw partial S (p.Rout), 8 is the last block and goes on
 //         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes
+//       9 (cost-only form, W-step form): R = max(D + S, 0) stored to p.Rout -- cnmfsc.m:262, V_hat = max(V_hat + dW_t * rshift_t(H), 0), in place (D = Rout = V_hat)
+//       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc keeps V_hat: its W branch updates it slice by slice)
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -251,6 +253,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 5) sacc2[jb][reg] = live ? er[sl] : 0.0f;
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC == 9) {                           // V_hat <- max(V_hat + dW*Hs, 0)   (cnmfsc.m:262)
+                if (u == 0) sacc[jb][reg] = fmaxf(v + sacc[jb][reg], 0.0f);
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
                 if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
             } else if (MF >= 2) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             } else {
                 if (u == 0) {
                     if (FUNC == 1) { const float e = v - sacc[jb][reg]; tc = live ? fmaf(e, e, tc) : tc; }   // nmf.m:208
-                    sacc[jb][reg] = live ? v : 0.0f;
+                    if (DO_G2 || FUNC != 1) sacc[jb][reg] = live ? v : 0.0f;   // (cost-only form: S stays, for the optional store below)
                 }
             }
             if (((FUNC == 1 || FUNC == 6) && u == 0) || (MF == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
-            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 9 || FUNC == 1) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
 #pragma unroll

@@ -595,13 +595,31 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     DevBuf g64h;   // the same for the sparse-H gradient (aux.hip::resid_hgrad64): m*n*K*T fp64 FMAs
     const bool small64h = p->sc_H_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total * (double)p->T <= (double)(1 << 27);
     if (small64h) TRY(g64h.alloc(sizeof(double) * (size_t)p->n * p->K_total));
+    // Fused passes (the register-stationary kernels of cnmf) for every evaluation that is a whole-matrix contraction: objectives without a
+    // stored V_hat inside the H line search, V_hat + objective in one pass where the algorithm keeps V_hat, all T products V*rshift_t(H)' in one pass,
+    // V_hat*rshift_t(H)' and the in-place update of cnmfsc.m:262 per slice, dH through Q = W_flat'*(V_hat - V) + shift-sum.  Default for problems
+    // past the float64-gradient sizes; path 2 asks for them by name, path 1 keeps the two-operand GEMMs.
+    const bool fusedsc = p->path != 1 && fused_supported_T(K, T) && fused_supported(K) && K <= 128 && m >= 64 && n >= 64 && m % 4 == 0 &&
+                         (p->path == 2 || (!small64 && !small64h));
+    if (p->path == 2 && !fusedsc) { set_error("cnmfsc: fused passes requested but the problem is not eligible (an instantiated (K, T) pair, m and n >= 64, m a multiple of 4)"); return NMFX_ERR_UNSUPPORTED; }
+    DevBuf Hpadb, slabsb, Qb;
+    long cpsT = 0, cpsK = 0;
+    int nsplitT = 1, nsplitK = 1;
+    if (fusedsc) {
+        nsplitT = fused_split((m + 127) / 128, n, KT, &cpsT);
+        nsplitK = fused_split((m + 127) / 128, n, K, &cpsK);
+        TRY(Hpadb.alloc((size_t)K * (n + T - 1) * 4));
+        TRY(slabsb.alloc(std::max((size_t)nsplitT * mKT, (size_t)nsplitK * mK) * 4));
+        TRY(Qb.alloc((size_t)KT * n * 4));
+    }
     TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
     TRY(HnT.alloc((size_t)p->K_total * p->n * 4));
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
     TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
     const size_t gmax = std::max(Kn, mKT);
-    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * gemm_grid_blocks(m, n))); TRY(costd.alloc(64 + sizeof(double) * K));
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * std::max<size_t>(gemm_grid_blocks(m, n), (size_t)((m + 127) / 128) * std::max(nsplitT, nsplitK)))); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
+    if (fusedsc) sb = std::max(sb, gemm_scratch_bytes(KT, n, m));
     TRY(scratch.alloc(sb));
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax));
     TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0));
@@ -624,7 +642,30 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         return read_obj(st, part.as<double>(), (int)blocks, costd.as<double>(), obj);
     };
     // V_hat = RFD(Wx (m x K x T), Hx) and 0.5*||V - V_hat||^2
-    auto rfd = [&](const float *Wx, const float *Hx, double *obj) -> nmfx_status {
+    // (fused) Hpad = [T-1 zero columns | Hx]: what the shifted views of the stationary kernel stream from
+    const float *hpad_of = nullptr;
+    auto ensure_hpad = [&](const float *Hx) -> nmfx_status {
+        if (hpad_of == Hx) return NMFX_OK;
+        TRY(pad_left(st, Hx, K, n, T - 1, Hpadb.as<float>()));
+        hpad_of = Hx;
+        return NMFX_OK;
+    };
+    // (fused) S = sum_t Wx_t * rshift_t(Hx) in registers -> 0.5*||V - S||^2; store: S is kept as V_hat
+    auto rfd_fused = [&](const float *Wx, const float *Hx, double *obj, bool store) -> nmfx_status {
+        TRY(ensure_hpad(Hx));
+        FusedParams f; memset(&f, 0, sizeof(f));
+        f.X = Wx; f.xs_r = 1; f.xs_k = m; f.xs_t = m * (long)K; f.T = T;
+        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1); f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = KT; f.c_per_split = cpsT;
+        f.Rout = store ? Vh.as<float>() : nullptr;
+        f.cost_partials = part.as<double>();
+        {
+            PScope ps(pf, SC_OBJ);
+            TRY(launch_fused(st, f, nsplitT, true, 1, false, 0));
+        }
+        return read_obj(st, part.as<double>(), (int)((m + 127) / 128) * nsplitT, costd.as<double>(), obj);
+    };
+    auto rfd = [&](const float *Wx, const float *Hx, double *obj, bool store = true) -> nmfx_status {
+        if (fusedsc) return rfd_fused(Wx, Hx, obj, store);
         PScope ps(pf, SC_OBJ);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = n; g.Kc = KT;
@@ -637,6 +678,15 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     // (X2 given: X is replaced by X2 - X element-wise while it is loaded -- the gradient in residual form, see run_nmfsc)
     auto hgrad = [&](const float *Wx, const float *X, float *out, const float *X2 = nullptr) -> nmfx_status {
         PScope ps(pf, SC_HTERMS);
+        if (fusedsc) {   // Q = W_flat' * X (KT x n, contraction m: a well-shaped product) and out(k, j) = sum_t Q((t,k), j+t), as cnmf's H step does
+            GemmParams q; memset(&q, 0, sizeof(q));
+            q.M = KT; q.N = n; q.Kc = m;
+            q.A = OpView{Wx, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+            q.B = OpView{X, X2, m, VIEW_KC, 0, 0, 0, X2 ? NMFX_PRO_DIFF : NMFX_PRO_NONE, 0.f, 0.f};
+            q.C = Qb.as<float>(); q.ldc = KT; q.epi = EPI_STORE; q.splitk = 1;
+            TRY(gemm_auto(st, q, scratch.p, sb));
+            return shift_sum(st, Qb.as<float>(), K, T, n, n, out);
+        }
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = K; g.N = n; g.Kc = (long)T * m;
         g.A = OpView{Wx, nullptr, m, VIEW_WSTACK_KC, (int)m, m * (long)K, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -645,7 +695,40 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         return gemm(g, nullptr);
     };
     // out (m x K) = X * rshift_t(H)'
+    // (fused) out (m x K) = X * rshift_t(Hx)' on the stationary kernel: streamed row j = column j - t of the padded copy
+    auto xht_fused = [&](const float *X, const float *Hx, int t, float *out) -> nmfx_status {
+        TRY(ensure_hpad(Hx));
+        FusedParams f; memset(&f, 0, sizeof(f));
+        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = X; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
+        f.out = nsplitK == 1 ? out : slabsb.as<float>(); f.slab_stride = (long)mK; f.os_r = 1; f.os_k = m;
+        PScope ps(pf, SC_WTERMS);
+        TRY(launch_fused(st, f, nsplitK, true, 0, true, 0));
+        if (nsplitK > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitK, (long)mK, (long)mK, out, 0));
+        return NMFX_OK;
+    };
+    // (fused) out (m x K x T) = V * H_stack': the T products V * rshift_t(Hx)' in ONE pass over V
+    auto vht_all_fused = [&](const float *Hx, float *out) -> nmfx_status {
+        TRY(ensure_hpad(Hx));
+        FusedParams f; memset(&f, 0, sizeof(f));
+        f.T = T; f.Y = Hpadb.as<float>() + (size_t)K * (T - 1); f.D = V.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = KT; f.c_per_split = cpsT;
+        f.out = nsplitT == 1 ? out : slabsb.as<float>(); f.slab_stride = (long)mKT; f.os_r = 1; f.os_k = m; f.os_t = m * (long)K;
+        PScope ps(pf, SC_WTERMS);
+        TRY(launch_fused(st, f, nsplitT, true, 0, true, 0));
+        if (nsplitT > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitT, (long)mKT, (long)mKT, out, 0));
+        return NMFX_OK;
+    };
+    // (fused) V_hat = max(V_hat + dW * rshift_t(Hx), 0) in place   (cnmfsc.m:262)
+    auto vhat_update_fused = [&](const float *dW, const float *Hx, int t) -> nmfx_status {
+        TRY(ensure_hpad(Hx));
+        FusedParams f; memset(&f, 0, sizeof(f));
+        f.X = dW; f.xs_r = 1; f.xs_k = m;
+        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = Vh.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
+        f.Rout = Vh.as<float>();
+        PScope ps(pf, SC_WTERMS);
+        return launch_fused(st, f, nsplitK, true, 9, false, 0);
+    };
     auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
+        if (fusedsc && !X2) return xht_fused(X, Hx, t, out);
         PScope ps(pf, SC_WTERMS);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = K; g.Kc = n;
@@ -681,8 +764,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                         TRY(projfunc_cols(st, HnT.as<float>(), n, K, L1s, 1.0, 1, nullptr, small64h ? nullptr : G1.as<float>(), -stepH, HT, small64h ? g64h.as<double>() : nullptr));   // cnmfsc.m:174-177 (step formed in fp64 while loading)
                     }
                     TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
+                    hpad_of = nullptr;                                                               // (Hnew was just rewritten)
                     double newobj;
-                    TRY(rfd(W0, Hnew, &newobj));                                                     // cnmfsc.m:180-181
+                    TRY(rfd(W0, Hnew, &newobj, false));                                              // cnmfsc.m:180-181 (V_hat of the accepted point is re-formed at cnmfsc.m:215, or at 269)
                     if (newobj <= begobj) break;
                     stepH /= 2;
                     if (stepH < 1e-200) { early = true; break; }                                     // cnmfsc.m:190-194
@@ -700,12 +784,14 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 TRY(transpose_f32(st, H, K, n, HT));
                 TRY(scale_cols(st, HT, n, K, nrm2, 1, 1));                                           // cnmfsc.m:206
                 TRY(transpose_f32(st, HT, n, K, H));
+                hpad_of = nullptr;
                 for (int t = 0; t < T; ++t) TRY(scale_cols(st, W0 + (size_t)t * mK, m, K, nrm2, 1, 0));   // cnmfsc.m:207-209
             }
         }
         if (!fixW) {
             double begobj;
             TRY(rfd(W0, H, &begobj));                                                            // cnmfsc.m:215
+            if (fusedsc && !(sW > 0)) TRY(vht_all_fused(H, G1.as<float>()));                     // neg_t = V * rshift_t(H)' for every t: V and H do not change inside the loop
             for (int t = 0; t < T && !early; ++t) {
                 float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
                 if (sW > 0) {
@@ -733,11 +819,13 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     NMFX_HIP(hipMemcpyAsync(Wt, Wnew, mK * 4, hipMemcpyDeviceToDevice, st));         // W(:,:,t) = Wnew
                     begobj = newobj;                                                                 // next t: 0.5*||V - V_hat||^2 of the V_hat left here
                 } else {
-                    TRY(xht(V.as<float>(), H, t, G1.as<float>()));                               // neg = V * Hs'
+                    const float *negt = fusedsc ? G1.as<float>() + (size_t)t * mK : G1.as<float>();
+                    if (!fusedsc) TRY(xht(V.as<float>(), H, t, G1.as<float>()));                 // neg = V * Hs'
                     TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
                     NMFX_HIP(hipMemcpyAsync(Wt, W0t, mK * 4, hipMemcpyDeviceToDevice, st));
-                    TRY(mu_plain(st, Wt, G1.as<float>(), G2.as<float>(), (long)mK));                 // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
+                    TRY(mu_plain(st, Wt, negt, G2.as<float>(), (long)mK));                           // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
                     TRY(axpy_f32(st, (long)mK, -1.0f, W0t, Wt, Wnew));                               // dW = W_t - W0_t
+                    if (fusedsc) { TRY(vhat_update_fused(Wnew, H, t)); continue; }                   // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     g.M = m; g.N = n; g.Kc = K;
                     g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};

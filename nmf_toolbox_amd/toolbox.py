@@ -487,6 +487,7 @@ def cnmfsc(V, num_basis_elems, context_len, config=None, device=0, info=None):
     p.W_fixed, p.H_fixed = _fptr(fw), _fptr(fh)
     p.maxiter, p.tolerance, p.device = maxiter, (-1.0 if cfg.get("nmfx_disable_stop", False) else tol), int(device)
     p.sc_W_sparsity, p.sc_H_sparsity = sW, sH
+    p.path = int(cfg.get("nmfx_path", 0))
     ids = _gpu_ids(cfg)
     if ids is not None:
         p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)

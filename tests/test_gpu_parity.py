@@ -324,6 +324,29 @@ def test_cnmfsc_matches_oracle(gpu_lib, sW, sH, m, n, K, T):
     _check(got, ref)
 
 
+@pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.0, 0.0), (0.6, 0.0), (0.4, 0.6)])
+@pytest.mark.parametrize("m,n,K,T", [(256, 1024, 32, 4), (192, 777, 64, 2), (320, 2048, 64, 8), (129 * 4, 1031, 32, 8)])
+def test_cnmfsc_fused_passes_match_oracle(gpu_lib, sW, sH, m, n, K, T):
+    """cnmfsc.m:155-277 with every whole-matrix contraction on the register-stationary kernels (nmfx_path = 2; the default above the float64-gradient
+    sizes): objectives of the H line search without a stored V_hat, V_hat + objective in one pass (cnmfsc.m:215,269), the T products V*rshift_t(H)' in
+    one pass, V_hat*rshift_t(H)' and V_hat = max(V_hat + dW*rshift_t(H), 0) (cnmfsc.m:262, functor 9, in place) per slice, dH through Q + shift-sum.
+    Identical line-search tries; also against the two-operand GEMM path (nmfx_path = 1)."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12)
+    if sW:
+        cfg["W_sparsity"] = sW
+    if sH:
+        cfg["H_sparsity"] = sH
+    i0, i1, i2 = {}, {}, {}
+    ref = O.cnmfsc(2.0 * V, K, T, cfg, info=i0)
+    got = gpu_lib.cnmfsc(2.0 * V, K, T, dict(cfg, nmfx_path=2), info=i1)
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    _check(got, ref)
+    gen = gpu_lib.cnmfsc(2.0 * V, K, T, dict(cfg, nmfx_path=1), info=i2)
+    assert i2["triesH"] == i1["triesH"] and rel_fro(got[0], gen[0]) <= 5e-6 and rel_fro(got[1], gen[1]) <= 5e-6
+
+
 # ---- lnmf (SURVEY 8(f) row f3) on the generic and the fused KL kernels ------------------------------------------------
 @pytest.mark.parametrize("m,n,K,path", [(96, 160, 8, 0), (256, 1024, 64, 2), (256, 1024, 64, 1), (128, 32768, 64, 2)])
 def test_lnmf_matches_oracle(gpu_lib, m, n, K, path):
