@@ -148,7 +148,7 @@ Layout layout(nmfx_engine *e, void *ws) {
     if (e->qgemm) e->Qbuf = c.take<float>((size_t)e->KT * (e->n + e->hR));
     if (e->use_vtq) { e->VT = c.take<float>((size_t)e->m * e->n); e->WTf = c.take<float>(mKT); }
     if (e->fusedT_kl) {
-        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->hR + e->T - 1));
         e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
         const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
         if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
@@ -255,10 +255,12 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
     static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
     e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
+    // (column shards: the T-1 columns left of the shard are its halo -- or zeros on the first one --, and R = V./V_hat is also formed on the T-1 right-halo
+    // columns, whose terms the shift-sum of the H step needs: cnmf.m:219)
     e->fusedT_kl = !e->fused && e->algo == 1 && e->div == NMFX_DIV_KL && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 &&
-                   e->hL == 0 && e->hR == 0 && d->path != 1 && !no_fusedT;
+                   (e->hL == 0 || e->hL >= e->T - 1) && d->path != 1 && !no_fusedT;
     if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl) {
-        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or unsharded kl, T > 1, an instantiated (K, T) pair)");
+        set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or kl, T > 1, an instantiated (K, T) pair)");
         return NMFX_ERR_UNSUPPORTED;
     }
     if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
@@ -541,7 +543,7 @@ enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3 };
 nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-1 zero columns (lag-form Gram products only)]
     if (e->hpad_valid) return NMFX_OK;      // H changed since the last pass (init, H step)
     Scope s(e, TAG_SMALL);
-    TRY(pad_left(e->st, e->H, e->K, e->n, e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));
+    TRY(pad_left(e->st, e->H, e->K, e->n + (e->fusedT_kl ? e->hR : 0), e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));   // (KL shards: the S pass also runs over the right-halo columns)
     e->hpad_valid = true;
     return NMFX_OK;
 }
@@ -574,6 +576,15 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if 
         TRY(reduce_slabs(e->st, e->slabsT, e->nsplit_T, mKT, mKT, out, 0));
     }
     if (!do_g2) e->n_cost_used = (int)((e->m + 127) / 128) * e->nsplit_T;
+    if (mode == FT_S_KL && e->hR > 0) {
+        // column shard: R = V./V_hat on the T-1 right-halo columns too (Q((t,k), j+t) of the last local columns reads them, cnmf.m:219); they belong to
+        // the neighbour's cost, so this second, tiny launch carries none
+        FusedParams h = f;
+        h.Y = Hy + (size_t)e->K * e->n; h.D = e->V + (size_t)e->m * e->n; h.Rout = e->Vhat + (size_t)e->m * e->n;
+        h.Cn = e->hR; h.c_per_split = 64; h.cost_partials = nullptr; h.out = nullptr;
+        Scope s(e, TAG_SMALL);
+        TRY(launch_fused(e->st, h, 1, true, 3, false, 0));
+    }
     return NMFX_OK;
 }
 // KL cnmf on the fused passes: the cost of the CURRENT (W, H) from the S pass's partials, sum(V.*log(V./V_hat)), plus the closed form
@@ -581,7 +592,7 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if 
 nmfx_status fusedT_kl_cost(nmfx_engine *e) {
     Scope s(e, TAG_SMALL);
     TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
-    TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, 0));
+    TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, e->hL));   // sum over the shard's own columns j of H(k, j - t): reaches into the left halo
     TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));

@@ -287,11 +287,25 @@ def test_cnmf_shards_with_halos_equal_oracle(gpu_lib, div, nshards, m, n, K, T):
     # the oracle's init rescales H by the slab norms of W (cnmf.m:157-166): shards are cut from the raw H_init, every rank applies the same factors
     parts = [shard_columns(n, nshards, r) for r in range(nshards)]
     engs = _cnmf_shard_engines(torch, V, W0, H0, div, T, parts)
+    if K >= 32:       # instantiated (K, T) pairs: the fused shift-sum passes on every shard, for KL too (R = V./V_hat also on the right-halo columns)
+        assert all(e.path_kind == (4 if div == "kl" else 3) for e in engs)
     iters = 10
     costs = []
+    lag = engs[0].cost_lag          # where the cost of an iteration turns up: 0 after its H step, 1 after the next W-step partial (KL on the fused passes: out of the S pass)
+    assert lag in (0, 1) and all(e.cost_lag == lag for e in engs)
+
+    def read_cost():
+        c = 0.0
+        for e in engs:
+            e._copy_cost(e._cost_t)
+            c += float(e._cost_t.item())
+        costs.append(c)
+
     for it in range(iters):
         for e in engs:
             e.wstep_partial()
+        if lag == 1 and it > 0:
+            read_cost()
         s = engs[0].packed.clone()
         for e in engs[1:]:
             s += e.packed
@@ -302,11 +316,12 @@ def test_cnmf_shards_with_halos_equal_oracle(gpu_lib, div, nshards, m, n, K, T):
         _emulated_halo_exchange(engs, T)
         for e in engs:
             e.hstep_finish()
-        c = 0.0
+        if lag == 0:
+            read_cost()
+    if lag == 1:
         for e in engs:
-            e._copy_cost(e._cost_t)
-            c += float(e._cost_t.item())
-        costs.append(c)
+            e.cost_pass()
+        read_cost()
     W, H, c0 = O.cnmf(V, K, T, dict(divergence=div, W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300))
     Wg = torch_to_colmajor(engs[0].W)
     Hg = np.concatenate([torch_to_colmajor(e.H_local) for e in engs], axis=1)
