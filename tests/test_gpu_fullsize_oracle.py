@@ -119,3 +119,56 @@ def test_default_100_iterations(gpu_lib, div):
     _report("100 iterations 2048x8192 K=128 " + div, got, ref, tg, tc)
     d = -np.diff(ref[2])
     print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], ref[2][-1]))
+
+
+def _kl_cost_f64(V, W, H, chunk=4096):
+    """nmf.m:210 in float64 on the host (torch CPU, all cores), column chunk by column chunk: sum(V .* log(V ./ V_hat) - V + V_hat).
+    Works on the transposes: the column-major arrays the library hands back are C-contiguous that way, so nothing is copied or re-laid-out."""
+    import torch
+    t = lambda a: torch.from_numpy(a.T if a.flags.f_contiguous else np.ascontiguousarray(a.T))
+    Vt, Wt, Ht = t(V), t(W).double(), t(H)
+    tot = 0.0
+    for j0 in range(0, V.shape[1], chunk):
+        Vc = Vt[j0:j0 + chunk].double()
+        S = Ht[j0:j0 + chunk].double() @ Wt
+        tot += float((Vc * torch.log(Vc / S) - Vc + S).sum())
+    return tot
+
+
+def test_c3_stop_rule_near_convergence(gpu_lib):
+    """The ABSOLUTE stop rule of nmf.m:221-224 at BASELINE config 3's size (16384 x 65536, K = 256, KL) with the rule active where the decreases
+    have become small: the fp32 path's cost DECREASE is compared with the float64 cost (nmf.m:210 on the host) of the very iterates it produced,
+    the band |d_fp32 - d_f64| is recorded, and the rule must (a) fire exactly at the iteration whose float64 decrease crosses a tolerance that lies
+    outside that band, handing back exactly that iteration's state, and (b) move by at most one iteration when the tolerance IS the float64
+    decrease."""
+    m, n, K = 16384, 65536, 256
+    t0 = time.time()
+    V, W0, H0 = synth(m, n, K, planted=True)
+    V = np.asfortranarray(V, dtype=np.float32)              # (the library computes in fp32 anyway; half the host traffic of the four calls)
+    base = dict(divergence="kl", W_init=W0.astype(np.float32), H_init=H0.astype(np.float32))
+    N = 200
+    t1 = time.time()
+    sN = gpu_lib.nmf(V, K, dict(base, maxiter=N, nmfx_disable_stop=True))
+    sM = gpu_lib.nmf(V, K, dict(base, maxiter=N - 1, nmfx_disable_stop=True))
+    c = sN[2]
+    assert np.array_equal(sM[2], c[:N - 1])                  # deterministic prefix
+    d = -np.diff(c)                                          # d[q-1] = c[q-1] - c[q]: what the rule looks at after iteration q+1 (0-based q)
+    assert np.all(d > 0)
+    t2 = time.time()
+    c64N, c64M = _kl_cost_f64(V, sN[0], sN[1]), _kl_cost_f64(V, sM[0], sM[1])
+    t3 = time.time()
+    D64, d32 = c64M - c64N, d[N - 2]
+    band = abs(D64 - d32)
+    bias = max(abs(c64N - c[N - 1]), abs(c64M - c[N - 2]))
+    record_err(c3_stop_band_abs=float(band), c3_stop_decrease=float(D64), c3_cost_bias_abs=float(bias))
+    print("\n[C3 stop rule] iteration %d: cost %.6g, decrease fp32 %.6g / float64 %.6g, band |d32 - d64| = %.3g, bias of the cost itself %.3g (%.2e relative)"
+          % (N, c64N, d32, D64, band, bias, bias / c64N))
+    assert band <= 0.01 * D64 + 0.05, (band, D64)            # the decrease is resolved far better than the cost itself (the bias is common to both)
+    tol = 0.5 * (d[N - 3] + d32)                             # between the decreases of iterations N-1 and N
+    assert d[N - 3] > d32 and np.all(d[:N - 2] > tol) and abs(D64 - tol) > 10 * band
+    got = gpu_lib.nmf(V, K, dict(base, maxiter=N + 20, tolerance=float(tol)))
+    assert len(got[2]) == N                                  # (a) fires where the float64 decrease crosses the tolerance ...
+    assert np.array_equal(got[0], sN[0]) and np.array_equal(got[1], sN[1])   # ... and returns that iteration's state, bit for bit
+    got = gpu_lib.nmf(V, K, dict(base, maxiter=N + 20, tolerance=float(D64)))
+    assert abs(len(got[2]) - N) <= 1                         # (b)
+    print("[C3 stop rule] seconds: data %.0f, two runs %.0f, float64 costs %.0f, stop runs %.0f" % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3))
