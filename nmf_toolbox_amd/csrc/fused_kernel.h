@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int MF = FUNC == 8 ? 3 : FUNC;        // the element map
     static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
+    // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
+    // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
+    // trip per tile: c4kl's S pass)
+    constexpr bool EARLY = !DO_G2 && NEED_S && PROBE == 0;
     constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
     static_assert(!DUAL || (K <= 128 && TT == 1), "dual-map kernels: K <= 128 (two accumulator sets + the stationary operand must fit 512 VGPRs)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // rows (loads return in order), and V is first needed in P2, a whole P1 (>= 3 us of MFMAs) later: leave them in
             // flight instead of draining to vmcnt(0), which exposed one HBM round trip (~2 us of a 13.6 us tile at K = 256) per tile.
             // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
-            // S_IN: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
-            if (S_IN) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            // EARLY: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
+            if (EARLY) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             else if (NEED_S && !(PROBE & 4)) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // S_IN: the next tile's DMA rows went out during P1, only the 32 partial-S loads of P2 are younger: the rows have landed once at most those
             // are in flight (the R stores and V loads below would push the count past what s_waitcnt can express at the tile top)
             if (S_IN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
