@@ -309,8 +309,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 }
             }
         } else {
+            // no first product: R = V, needed at once.  Both halves move into the R tile here, so d[] is free for the whole tile and the V loads of the
+            // next tile go out during P3 -- a tile ahead of their use instead of half a tile (at K = 128 that half is 1.7 us, less than an HBM round trip
+            // under load, and the wait at the next tile top exposed the rest)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) emap_u(0, reg, 0);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) emap_u(1, reg, 0);
         }
         if (DO_G2) {
             auto g2_read = [&](int jb, int reg, float (&y)[NKB]) {
@@ -329,9 +334,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
-                    if (jb == 0) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
-                    if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 32);   // no first product: the DMA rides here
-                    if (kb == NKB / 2 && jb == 1) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4
+                    if (jb == 0 && NEED_S) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
+                    if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 24 < ROWS_PER_WAVE ? (st + 1) * ROWS_PER_WAVE / 24 : ROWS_PER_WAVE);   // no first product: the DMA rides here, done by step 24
+                    if (kb == NKB / 2 && jb == (NEED_S ? 1 : 0)) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4 (no first product: under P3 already)
                     __builtin_amdgcn_sched_barrier(0);
                     if (DUAL) {
                         acc2[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr2, acc2[kb], 0, 0, 0);
