@@ -790,6 +790,63 @@ nmfx_status publish_obj(hipStream_t st, const double *partials, int count, doubl
     return NMFX_OK;
 }
 
+// ---- line-search objectives of nmfsc without a pass over V ---------------------------------------------------------------------
+// 0.5*||V - W*H||^2 is QUADRATIC in either factor, so along a line search that moves one of them (nmfsc.m:152-175: H -> Hnew, W fixed; :203-226 the
+// other way round) the objective of a candidate follows from the gradient the search already has:
+//     obj(X + D) - obj(X) = <grad, D> + 0.5 * sum_rows D(i,:) * G * D(i,:)'        G = W'*W (rows of H' move)  or  H*H' (rows of W move)
+// with grad = dH' = ((W*H - V)'*W) or dW = (W*H - V)*H' at the point the search starts from.  Every term is of the size of the difference itself -- no
+// ||V||^2-sized numbers to cancel -- so the accept test of nmfsc.m:164 / :215 is decided at least as sharply as by two fp32 evaluations of the
+// objective, for K*K*R multiply-adds on the VALU instead of a 2*m*n*K pass.  X, Xc, grad: R x K column-major (rows of W, or of the transposed copy
+// of H, are the K-vectors); one thread per row, D(i,:) in registers, G through LDS in row chunks.  partials[block] = 2*<grad, D> + sum D*G*D'
+// (so that the 0.5 of the objective readers gives the difference).
+template <int K>
+__global__ __launch_bounds__(256) void quad_rows_kernel(const float *__restrict__ X, const float *__restrict__ Xc, const float *__restrict__ grad, const float *__restrict__ G,
+                                                        long R, double *partials) {
+    constexpr int KC = 32;                                               // rows of G per workgroup (blockIdx.y): K/32 workgroups share a block of 256 rows
+    __shared__ double red[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i < R;
+    const int k0 = blockIdx.y * KC;
+    float d[K];
+    double t1 = 0.0;
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+        d[l] = ok ? Xc[i + R * l] - X[i + R * l] : 0.0f;
+        if (blockIdx.y == 0) t1 += ok ? (double)grad[i + R * l] * (double)d[l] : 0.0;   // (uniform)
+    }
+    float dk[KC];                                                        // D(i, k0 + kk): loaded again (k0 is a run-time value: d[k0 + kk] would send d[] to scratch),
+#pragma unroll                                                          // all of them up front -- inside the loop each pair of loads was an exposed round trip
+    for (int kk = 0; kk < KC; ++kk) dk[kk] = ok ? Xc[i + R * (k0 + kk)] - X[i + R * (k0 + kk)] : 0.0f;
+    double t2 = 0.0;
+    const float *__restrict__ Gk = G + (long)k0 * K;                     // wave-uniform addresses: the rows of G arrive through the scalar cache (s_load), not LDS
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(Gk + kk * K);   // G is symmetric: row k as stored
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int l = 0; l < K / 4; ++l) {
+            const float4 g = g4[l];
+            s0 = fmaf(g.x, d[4 * l], s0); s1 = fmaf(g.y, d[4 * l + 1], s1); s2 = fmaf(g.z, d[4 * l + 2], s2); s3 = fmaf(g.w, d[4 * l + 3], s3);
+        }
+        t2 += (double)dk[kk] * ((double)(s0 + s1) + (double)(s2 + s3));
+    }
+    const double tot = block_sum<4>(2.0 * t1 + t2, red);
+    if (threadIdx.x == 0) partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+int quad_rows_blocks(long R, int K) { return (int)((R + 255) / 256) * (K / 32); }
+bool quad_rows_supported(int K) { return K >= 32 && K <= 256 && K % 32 == 0; }
+nmfx_status quad_rows(hipStream_t st, const float *X, const float *Xc, const float *grad, const float *G, long R, int K, double *partials) {
+    const dim3 grid((unsigned)((R + 255) / 256), (unsigned)(K / 32)), block(256);
+#define NMFX_QR(KK) case KK: hipLaunchKernelGGL(quad_rows_kernel<KK>, grid, block, 0, st, X, Xc, grad, G, R, partials); break;
+    switch (K) {
+        NMFX_QR(32) NMFX_QR(64) NMFX_QR(96) NMFX_QR(128) NMFX_QR(160) NMFX_QR(192) NMFX_QR(224) NMFX_QR(256)
+        default: set_error("quad_rows: K = %d not supported", K); return NMFX_ERR_UNSUPPORTED;
+    }
+#undef NMFX_QR
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 __global__ void fill_kernel(float *p, long count, float v) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < count) p[idx] = v;

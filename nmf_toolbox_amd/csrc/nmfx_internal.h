@@ -210,6 +210,13 @@ nmfx_status finish_cost(hipStream_t st, const double *partials, int count, doubl
                         const double *pre_c = nullptr, double pre_a = 0.0, double pre_b = 0.0,    // scale * (sum(partials) + pre_a * *pre_c + pre_b)
                         double *out2 = nullptr,                                                   // second destination of the cost (the caller's cost vector)
                         const double *cvt_src = nullptr, float *cvt_dst = nullptr, int ncvt = 0);  // + cvt_dst[i] = (float)cvt_src[i]  (rowsum(H) into the tail of `packed`)
+// nmfsc line searches: partials[b] = 2*<grad, Xc - X> + sum_i (Xc - X)(i,:) * G * (Xc - X)(i,:)' over the rows of block b (aux.hip)
+int quad_rows_blocks(long R, int K);
+// the same on the K x n layout (columns are the K-vectors; small_mm.hip, G*D on the MFMA): partials[b] over 32 columns
+int quad_cols_blocks(long n);
+nmfx_status quad_cols(hipStream_t st, const float *H, const float *Hc, const float *grad, const float *G, int K, long n, double *partials);
+bool quad_rows_supported(int K);
+nmfx_status quad_rows(hipStream_t st, const float *X, const float *Xc, const float *grad, const float *G, long R, int K, double *partials);
 nmfx_status publish_obj(hipStream_t st, const double *partials, int count, double scale, const double *src, double *out, double *slot, unsigned long long seq);
 nmfx_status col_reduce_pow(hipStream_t st, const float *X, long rows, long ld, int ncols, float e, double *out);
 nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, float e);

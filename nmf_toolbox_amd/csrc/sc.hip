@@ -347,6 +347,26 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                        OpView{KK, nullptr, (long)K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, P_, m);
     };
+    // Line-search objectives from the quadratic expansion around the point the search starts from (aux.hip::quad_rows): no pass over V per try.  The
+    // value that is accepted this way is only used to go on searching; every cost that is REPORTED (and every begobj) still comes out of a residual pass.
+    static const bool no_quad = getenv("NMFX_SC_NO_QUAD") != nullptr;   // dev switch (A/B runs)
+    const bool quad = fast && !use64 && quad_rows_supported(K) && !no_quad;
+    DevBuf qparts;
+    if (quad) TRY(qparts.alloc(sizeof(double) * std::max(quad_cols_blocks(n), quad_rows_blocks(m, K))));
+    // *newobj = begobj + [obj(Xc) - obj(X)], X / Xc / grad R x K; over_ranks: the rows are this shard's (rows of H'), not replicated ones (rows of W)
+    // (cols: X / Xc / grad are K x n, the columns move -- the H search; else R x K, the rows move -- the W search)
+    auto quad_obj = [&](const float *X, const float *Xc, const float *grad, long R, double begobj, double *newobj, bool cols) -> nmfx_status {
+        {
+            PScope ps(pf, SC_OBJ);
+            if (cols) TRY(quad_cols(st, X, Xc, grad, KKb.as<float>(), K, R, qparts.as<double>()));
+            else TRY(quad_rows(st, X, Xc, grad, KKb.as<float>(), R, K, qparts.as<double>()));
+        }
+        const bool over_ranks = cols;   // the columns are this shard's; the rows of W are replicated
+        double diff = 0;
+        TRY(read_obj(st, qparts.as<double>(), cols ? quad_cols_blocks(R) : quad_rows_blocks(R, K), costd.as<double>(), &diff, over_ranks ? &comm : nullptr));
+        *newobj = begobj + diff;
+        return NMFX_OK;
+    };
     double stepH = p->sc_stepsize_H0 > 0 ? p->sc_stepsize_H0 : 1.0, stepW = p->sc_stepsize_W0 > 0 ? p->sc_stepsize_W0 : 1.0;   // nmfsc.m:133-134
     if (fast) {
         DevBuf Hcb;
@@ -368,10 +388,16 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         bool early = false;
         for (int it = 1; it <= p->maxiter && !early; ++it) {
             double cur_obj = r->cost[it - 1];
+            bool approx = false;   // cur_obj came out of the quadratic expansion: good for searching on, not for the cost vector
             if (!fixH) {
                 if (sH > 0) {
                     if (!have_dH) TRY(resid_h(Wd, Hcur, nullptr));                              // dH = W'*V_hat - W'*V   nmfsc.m:144-148
                     have_dH = false;
+                    const bool quadH = quad && !spec;
+                    if (quadH) {   // G = W'*W for the expansion (W is replicated on column shards)
+                        PScope ps(pf, SC_SMALL);
+                        TRY(kk_gemm(K, K, m, OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Wd, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+                    }
                     if (!use64) {
                         PScope ps(pf, SC_SMALL);
                         TRY(transpose_f32(st, Denb.as<float>(), K, n, G1.as<float>()));         // dH' (n x K): rows of H are contiguous there
@@ -387,6 +413,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                             TRY(transpose_f32(st, HnewT, n, K, Hcand));
                         }
                         if (spec) TRY(resid_w(Wd, Hcand, G2.as<float>(), &newobj, false));          // nmfsc.m:160-161 (+ dW at the candidate)
+                        else if (quadH) TRY(quad_obj(Hcur, Hcand, Denb.as<float>(), n, begobj, &newobj, true));   // nmfsc.m:160-161 through the expansion in H
                         else TRY(fast_obj(Wd, Hcand, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
                         stepH /= 2;                                                                 // nmfsc.m:169
@@ -396,6 +423,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     ++nH;
                     if (early) { ncost = it; break; }
                     stepH *= 1.2;                                                                   // nmfsc.m:178
+                    if (quadH) approx = true;
                     std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
                     cur_obj = newobj;
                     have_dW = spec;
@@ -413,13 +441,19 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
             }
             if (!fixW) {
                 if (sW > 0) {
-                    if (!have_dW) TRY(resid_w(Wd, Hcur, G2.as<float>(), cur_obj == cur_obj ? nullptr : &cur_obj));   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
+                    if (!have_dW) { TRY(resid_w(Wd, Hcur, G2.as<float>(), (cur_obj == cur_obj && !approx) ? nullptr : &cur_obj)); approx = false; }   // dW = V_hat*H' - V*H' (+ begobj)   nmfsc.m:193-200
                     else if (comm.active()) {
                         if (use64) TRY(comm.allreduce(g64w.p, (long)m * Kv, NMFX_F64, NMFX_REDUCE_SUM));
                         else TRY(comm.allreduce(G2.p, (long)mK, NMFX_F32, NMFX_REDUCE_SUM));
                     }
                     have_dW = false;
                     const bool spec_h = spec && it < p->maxiter;
+                    const bool quadW = quad && !spec_h;
+                    if (quadW) {   // G = H*H' for the expansion in W, summed over the column shards
+                        PScope ps(pf, SC_SMALL);
+                        TRY(kk_gemm(K, K, n, OpView{Hcur, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hcur, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KKb.as<float>(), K));
+                        if (comm.active()) TRY(comm.allreduce(KKb.p, (long)K * K, NMFX_F32, NMFX_REDUCE_SUM));
+                    }
                     const double begobj = cur_obj;
                     int tries = 0;
                     double newobj = 0;
@@ -430,6 +464,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                             TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, use64 ? nullptr : G2.as<float>(), -stepW, Wd, use64 ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
                         }
                         if (spec_h) TRY(resid_h(Wnew, Hcur, &newobj));                              // nmfsc.m:211-212 (+ dH at the candidate)
+                        else if (quadW) TRY(quad_obj(Wd, Wnew, G2.as<float>(), m, begobj, &newobj, false));   // nmfsc.m:211-212 through the expansion in W (every rank holds all rows of W)
                         else TRY(fast_obj(Wnew, Hcur, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
                         stepW /= 2;
@@ -441,6 +476,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     stepW *= 1.2;                                                                   // nmfsc.m:228
                     std::swap(Wd, Wnew);                                                            // nmfsc.m:229
                     cur_obj = newobj;
+                    approx = quadW;
                     have_dH = spec_h;
                 } else {
                     TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                    // V*H', V_hat*H'       nmfsc.m:194-195
@@ -449,7 +485,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     cur_obj = NAN;
                 }
             }
-            if (cur_obj == cur_obj) r->cost[it] = cur_obj;                                          // same (W, H) as the accepted objective
+            if (cur_obj == cur_obj && !approx) r->cost[it] = cur_obj;                               // same (W, H) as the accepted objective
             else if (lsH && it < p->maxiter) { TRY(resid_h(Wd, Hcur, &r->cost[it])); have_dH = true; }   // + the next iteration's dH
             else TRY(fast_obj(Wd, Hcur, &r->cost[it]));                                             // nmfsc.m:237-238
             if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244

@@ -156,7 +156,87 @@ __global__ __launch_bounds__(64 * (KB < 4 ? KB : 4)) void h_update_gram_kernel(f
     }
 }
 
+// The line-search objective of nmfsc's H search through the quadratic expansion (see aux.hip::quad_rows_kernel for the argument), on the K x n layout and
+// with G*D on the MFMA exactly as in h_update_gram: D = Hc - H for the workgroup's 32 columns, acc = G*D, then
+//     partials[block] = sum_{k, j} D(k, j) * (2*grad(k, j) + acc(k, j))          ( = 2*<grad, D> + <G*D, D> over the block's columns )
+template <int KB>
+__global__ __launch_bounds__(64 * (KB < 4 ? KB : 4)) void quad_cols_kernel(const float *__restrict__ H, const float *__restrict__ Hc, const float *__restrict__ grad,
+                                                                              const float *__restrict__ G, long n, double *__restrict__ partials) {
+    constexpr int K = 32 * KB, NW = KB < 4 ? KB : 4, NB = (KB + NW - 1) / NW;
+    __shared__ double red[NW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const long j0 = (long)blockIdx.x * 32;
+    const long jl = j0 + l31 < n ? j0 + l31 : n - 1;          // clamped: columns past the end are computed and dropped
+    const long ho = (long)K * jl + 4 * h;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = zero16();
+#pragma unroll 4
+    for (int q = 0; q < K / 8; ++q) {
+        const float4 xc = *reinterpret_cast<const float4 *>(Hc + ho + 8 * q), xb = *reinterpret_cast<const float4 *>(H + ho + 8 * q);
+        float y[4][NB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int kb = wave + NW * b;
+                y[r][b] = G[32 * (kb < KB ? kb : 0) + l31 + (long)K * (8 * q + 4 * h + r)];
+            }
+        const float xs[4] = {xc.x - xb.x, xc.y - xb.y, xc.z - xb.z, xc.w - xb.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[r], y[r][b], acc[b], 0, 0, 0);
+    }
+    // acc[b][e] = (G*D)(k, j), k = 32 kb + l31, j = j0 + (e & 3) + 8 (e >> 2) + 4 h
+    double t = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int kb = wave + NW * b;
+        if (kb >= KB) continue;
+        const int k = 32 * kb + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long j = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (j < n) {
+                const long idx = k + (long)K * j;
+                const float dd = Hc[idx] - H[idx];
+                t += (double)dd * (2.0 * (double)grad[idx] + (double)acc[b][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) red[wave] = t;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
 }  // namespace
+
+int quad_cols_blocks(long n) { return (int)((n + 31) / 32); }
+nmfx_status quad_cols(hipStream_t st, const float *H, const float *Hc, const float *grad, const float *G, int K, long n, double *partials) {
+    if (!h_update_gram_supported(K)) { set_error("quad_cols: K = %d", K); return NMFX_ERR_INVALID; }
+    dim3 grid((unsigned)((n + 31) / 32));
+#define NMFX_QC(KB) hipLaunchKernelGGL((quad_cols_kernel<KB>), grid, dim3(64 * (KB < 4 ? KB : 4)), 0, st, H, Hc, grad, G, n, partials)
+    switch (K / 32) {
+    case 1: NMFX_QC(1); break;
+    case 2: NMFX_QC(2); break;
+    case 3: NMFX_QC(3); break;
+    case 4: NMFX_QC(4); break;
+    case 5: NMFX_QC(5); break;
+    case 6: NMFX_QC(6); break;
+    case 7: NMFX_QC(7); break;
+    default: NMFX_QC(8); break;
+    }
+#undef NMFX_QC
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
 
 size_t gram_rc_scratch_bytes(int K1, int K2, long n) {
     const long nb = ((K1 + 127) / 128) * (long)((K2 + 127) / 128);
