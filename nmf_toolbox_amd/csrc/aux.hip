@@ -847,6 +847,21 @@ nmfx_status quad_rows(hipStream_t st, const float *X, const float *Xc, const flo
     return NMFX_OK;
 }
 
+// partials[block] = sum d .* (2*a + b) over the block's elements (fp64): the two inner products of the quadratic expansion when G*D came from a GEMM (cnmfsc)
+__global__ __launch_bounds__(256) void dot_2a_b_kernel(const float *__restrict__ d, const float *__restrict__ a, const float *__restrict__ b, long count, double *partials) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) s += (double)d[i] * (2.0 * (double)a[i] + (double)b[i]);
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+int dot_2a_b_blocks(long count) { const long b = (count + 2047) / 2048; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+nmfx_status dot_2a_b(hipStream_t st, const float *d, const float *a, const float *b, long count, double *partials) {
+    hipLaunchKernelGGL(dot_2a_b_kernel, dim3((unsigned)dot_2a_b_blocks(count)), dim3(256), 0, st, d, a, b, count, partials);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 __global__ void fill_kernel(float *p, long count, float v) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < count) p[idx] = v;

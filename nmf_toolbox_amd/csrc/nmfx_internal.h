@@ -213,6 +213,8 @@ nmfx_status finish_cost(hipStream_t st, const double *partials, int count, doubl
 // nmfsc line searches: partials[b] = 2*<grad, Xc - X> + sum_i (Xc - X)(i,:) * G * (Xc - X)(i,:)' over the rows of block b (aux.hip)
 int quad_rows_blocks(long R, int K);
 // the same on the K x n layout (columns are the K-vectors; small_mm.hip, G*D on the MFMA): partials[b] over 32 columns
+int dot_2a_b_blocks(long count);
+nmfx_status dot_2a_b(hipStream_t st, const float *d, const float *a, const float *b, long count, double *partials);   // partials[block] = sum d .* (2a + b)
 int quad_cols_blocks(long n);
 nmfx_status quad_cols(hipStream_t st, const float *H, const float *Hc, const float *grad, const float *G, int K, long n, double *partials);
 bool quad_rows_supported(int K);

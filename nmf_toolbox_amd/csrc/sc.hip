@@ -638,9 +638,16 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     const bool fusedsc = p->path != 1 && fused_supported_T(K, T) && fused_supported(K) && K <= 128 && m >= 64 && n >= 64 && m % 4 == 0 &&
                          (p->path == 2 || (!small64 && !small64h));
     if (p->path == 2 && !fusedsc) { set_error("cnmfsc: fused passes requested but the problem is not eligible (an instantiated (K, T) pair, m and n >= 64, m a multiple of 4)"); return NMFX_ERR_UNSUPPORTED; }
-    DevBuf Hpadb, slabsb, Qb;
+    DevBuf Hpadb, slabsb, Qb, DDb, Dlb, Zb, qpartsb;
     long cpsT = 0, cpsK = 0;
     int nsplitT = 1, nsplitK = 1;
+    // H line search: objectives from the quadratic expansion (see run_nmfsc): obj(H + D) - obj(H) = <dH, D> + 0.5*<Ds, (W_flat'*W_flat)*Ds>, Ds = D stacked with its
+    // shifts -- one KT x n x KT product on the stacked view, a shift-sum and two inner products instead of a 2*m*n*K*T pass per try
+    static const bool no_quad_c = getenv("NMFX_SC_NO_QUAD") != nullptr;   // dev switch (A/B runs)
+    const bool quadsc = fusedsc && !small64h && sH > 0 && !no_quad_c;
+    if (quadsc) {
+        TRY(DDb.alloc((size_t)KT * KT * 4)); TRY(Dlb.alloc(Kn * 4)); TRY(Zb.alloc(Kn * 4)); TRY(qpartsb.alloc(sizeof(double) * dot_2a_b_blocks((long)Kn)));
+    }
     if (fusedsc) {
         nsplitT = fused_split((m + 127) / 128, n, KT, &cpsT);
         nsplitK = fused_split((m + 127) / 128, n, K, &cpsK);
@@ -655,7 +662,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     const size_t gmax = std::max(Kn, mKT);
     TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * std::max<size_t>(gemm_grid_blocks(m, n), (size_t)((m + 127) / 128) * std::max(nsplitT, nsplitK)))); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
-    if (fusedsc) sb = std::max(sb, gemm_scratch_bytes(KT, n, m));
+    if (fusedsc) sb = std::max(sb, std::max(gemm_scratch_bytes(KT, n, m), std::max(gemm_scratch_bytes(KT, KT, m), gemm_scratch_bytes(KT, n, KT))));
     TRY(scratch.alloc(sb));
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax));
     TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0));
@@ -793,6 +800,15 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));              // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
                     TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
                 }
+                if (quadsc) {   // D = W0_flat' * W0_flat, once per search
+                    PScope ps(pf, SC_SMALL);
+                    GemmParams g; memset(&g, 0, sizeof(g));
+                    g.M = KT; g.N = KT; g.Kc = m;
+                    g.A = OpView{W0, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                    g.B = OpView{W0, nullptr, m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                    g.C = DDb.as<float>(); g.ldc = KT; g.epi = EPI_STORE; g.splitk = 1;
+                    TRY(gemm_auto(st, g, scratch.p, sb));
+                }
                 for (;;) {
                     ++tries;
                     {
@@ -802,6 +818,23 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
                     hpad_of = nullptr;                                                               // (Hnew was just rewritten)
                     double newobj;
+                    if (quadsc) {                                                                    // cnmfsc.m:180-181 through the expansion in H
+                        {
+                            PScope ps(pf, SC_OBJ);
+                            TRY(axpy_f32(st, (long)Kn, -1.0f, H, Hnew, Dlb.as<float>()));            // D = Hnew - H
+                            GemmParams g; memset(&g, 0, sizeof(g));
+                            g.M = KT; g.N = n; g.Kc = KT;
+                            g.A = OpView{DDb.as<float>(), nullptr, (long)KT, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                            g.B = OpView{Dlb.as<float>(), nullptr, (long)K, VIEW_HSTACK_KC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                            g.C = Qb.as<float>(); g.ldc = KT; g.epi = EPI_STORE; g.splitk = 1;
+                            TRY(gemm_auto(st, g, scratch.p, sb));
+                            TRY(shift_sum(st, Qb.as<float>(), K, T, n, n, Zb.as<float>()));          // Z(k, j) = sum_t ((W'W)*Ds)((t,k), j+t)
+                            TRY(dot_2a_b(st, Dlb.as<float>(), G2.as<float>(), Zb.as<float>(), (long)Kn, qpartsb.as<double>()));
+                        }
+                        double diff = 0;
+                        TRY(read_obj(st, qpartsb.as<double>(), dot_2a_b_blocks((long)Kn), costd.as<double>(), &diff));
+                        newobj = begobj + diff;
+                    } else
                     TRY(rfd(W0, Hnew, &newobj, false));                                              // cnmfsc.m:180-181 (V_hat of the accepted point is re-formed at cnmfsc.m:215, or at 269)
                     if (newobj <= begobj) break;
                     stepH /= 2;

@@ -16,14 +16,18 @@ def main():
     agg = defaultdict(dict)
     for db in dbs:
         c = sqlite3.connect(db)
-        q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name")
+        cols = [r[1] for r in c.execute("PRAGMA table_info(counters_collection)")]
+        if "grid_size" in cols:   # one template can play several roles in an iteration (big pass, K x K Gram product): told apart by their grids
+            q = ("select kernel_name || '  [grid ' || grid_size || ']', counter_name, count(*), avg(value) from counters_collection group by kernel_name, grid_size, counter_name")
+        else:
+            q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name")
         for k, cn, n, v in c.execute(q):
             agg[k][cn] = (n, v)
     print("# rocprofv3 PMC passes (separate runs per counter group)\n\ncommand: `%s`\n" % cmd)
     for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1]):
         if "nmfx::" not in k:
             continue
-        print("## `%s`\n" % k[:120])
+        print("## `%s`\n" % (k[:120] + (k[k.rfind("  [grid"):] if "  [grid" in k and k.rfind("  [grid") >= 120 else "")))
         print("| counter | dispatches | mean per dispatch |\n|---|---|---|")
         for cn, (n, v) in sorted(d.items()):
             print("| %s | %d | %.6g |" % (cn, n, v))
