@@ -800,7 +800,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));              // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
                     TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
                 }
-                if (quadsc) {   // D = W0_flat' * W0_flat, once per search
+                if (quadsc && (it > 1 || !(sW > 0))) {   // D = W0_flat' * W0_flat, once per search
                     PScope ps(pf, SC_SMALL);
                     GemmParams g; memset(&g, 0, sizeof(g));
                     g.M = KT; g.N = KT; g.Kc = m;
@@ -818,7 +818,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     TRY(transpose_f32(st, HnT.as<float>(), n, K, Hnew));
                     hpad_of = nullptr;                                                               // (Hnew was just rewritten)
                     double newobj;
-                    if (quadsc) {                                                                    // cnmfsc.m:180-181 through the expansion in H
+                    // (not in the first iteration when W was projected at cnmfsc.m:105-109: the reference then searches with W0 against a begobj and a
+                    // V_hat formed with the PROJECTED W -- the expansion would be around a point the search is not at)
+                    if (quadsc && (it > 1 || !(sW > 0))) {                                           // cnmfsc.m:180-181 through the expansion in H
                         {
                             PScope ps(pf, SC_OBJ);
                             TRY(axpy_f32(st, (long)Kn, -1.0f, H, Hnew, Dlb.as<float>()));            // D = Hnew - H
