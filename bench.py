@@ -492,6 +492,7 @@ def main():
                                 3: "fused cnmf passes, shift-sum in LDS + Gram denominators (V_hat never materialised)",
                                 4: "fused cnmf passes, shift-sum in LDS; R = V./V_hat in HBM, V_hat never",
                                 5: "KL with K > 256: S = W*H over column blocks on the stationary kernel, R = V./S in HBM, V_hat never",
+                                6: "euclidean with K > 256: numerators block by block on the stationary kernel, Gram-form cost, V_hat never",
                                 0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),

@@ -136,6 +136,9 @@ struct nmfx_engine {
                               // the V_hat buffer), the numerators R*H' run block by block on the same kernel, W'*R on the two-operand GEMM; the cost lags like
                               // the fused path's
     int klw_nb, klw_k0[8], klw_kb[8];   // its column blocks
+    bool eucw;                // euclidean nmf / constrainednmf with K > 256 (a sub-mode of `gram`): the numerators V*H' and W'*V block by block on the stationary kernel (the
+                              // latter over the transposed copy of V), the cost in Gram form out of the W update's column sums; the explicit residual behind it is the
+                              // S chain of klw with functor 10.  Shares klw_nb / klw_k0 / klw_kb / klw_hsplit and the V' / W' / slab buffers
     bool klw_vt;              // ... with the H step on the transposed copy of V: R' = V'./(H'*W') straight from the same kernels, then (R'*W)' -- every V / R tile
                               // read along its contiguous dimension, no two-operand GEMM (needs V' and the W' copy)
     int klw_hsplit;

@@ -8,6 +8,24 @@ using namespace nmfx;
 
 namespace {
 
+// per-source lambda / fixed flags (nmf.m:145-173 loops over the sources on one concatenated problem) as per-component vectors of length K >= K_total;
+// components past K_total are the zero padding of the fused kernels: fixed, never updated
+void expand_sources(const nmfx_problem *p, int K, std::vector<float> &lw, std::vector<float> &lh, std::vector<uint8_t> &fw, std::vector<uint8_t> &fh) {
+    const int Kt = p->K_total;
+    lw.assign(K, 0.f); lh.assign(K, 0.f); fw.assign(K, 0); fh.assign(K, 0);
+    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
+    for (int s = 0, k0 = 0; s < p->num_sources; ++s) {
+        const int Ks = p->K_s ? p->K_s[s] : Kt;
+        for (int k = k0; k < k0 + Ks; ++k) {
+            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
+            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
+            if (p->W_fixed) fw[k] = p->W_fixed[s];
+            if (p->H_fixed) fh[k] = p->H_fixed[s];
+        }
+        k0 += Ks;
+    }
+}
+
 nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const int64_t *seg = nullptr, int64_t nz = 0, const void *Z_init = nullptr,
                    void *Z_out = nullptr) {
     TRY(validate_problem(p, r, false, algorithm != 3));
@@ -20,27 +38,17 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     if (algorithm == 0 && p->divergence == NMFX_DIV_EUCLIDEAN_NOCOST) { set_error("nmf: unknown divergence (nmf.m:165-166)"); return NMFX_ERR_INVALID; }
     DeviceGuard dg_;
     TRY(check_device(p->device));
-    const int Kt = p->K_total, S = p->num_sources;
+    const int Kt = p->K_total;
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
     const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;   // fused IS / alpha-beta: K <= 128
-    const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || (dv == NMFX_DIV_KL && Kt <= 2048 && p->m >= 64 && p->n >= 64)) &&   // (KL above 256: column blocks, engine.klw)
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && p->m >= 64 && p->n >= 64)) &&   // (above 256: column blocks, engine.klw / eucw)
                      ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
-    std::vector<float> lw(K, 0.f), lh(K, 0.f);
-    std::vector<uint8_t> fw(K, 0), fh(K, 0);
-    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
-    for (int s = 0, k0 = 0; s < S; ++s) {
-        const int Ks = p->K_s ? p->K_s[s] : Kt;
-        for (int k = k0; k < k0 + Ks; ++k) {
-            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
-            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
-            if (p->W_fixed) fw[k] = p->W_fixed[s];
-            if (p->H_fixed) fh[k] = p->H_fixed[s];
-        }
-        k0 += Ks;
-    }
+    std::vector<float> lw, lh;
+    std::vector<uint8_t> fw, fh;
+    expand_sources(p, K, lw, lh, fw, fh);
     nmfx_engine_desc d{};
     d.m = p->m; d.n_local = p->n; d.K_total = K; d.T = p->T; d.divergence = p->divergence; d.alpha = p->alpha; d.beta = p->beta;
     d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
@@ -281,29 +289,19 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { set_error("hipDeviceEnablePeerAccess(%d -> %d): %s", M.dev[g], M.dev[h], hipGetErrorString(pe)); return NMFX_ERR_HIP; }
             (void)hipGetLastError();
         }
-    const int Kt = p->K_total, S = p->num_sources, dv = p->divergence;
+    const int Kt = p->K_total, dv = p->divergence;
     const long m = p->m, n = p->n;
     M.lo[0] = 0;
     for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
     long nmin = n;
     for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
     const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 128;
-    const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || (dv == NMFX_DIV_KL && Kt <= 2048 && m >= 64 && nmin >= 64)) && ((m >= 64 && nmin >= 64) || p->path == 2) &&
+    const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && m >= 64 && nmin >= 64)) && ((m >= 64 && nmin >= 64) || p->path == 2) &&
                      p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
-    std::vector<float> lw(K, 0.f), lh(K, 0.f);
-    std::vector<uint8_t> fw(K, 0), fh(K, 0);
-    for (int k = Kt; k < K; ++k) fw[k] = fh[k] = 1;
-    for (int s = 0, k0 = 0; s < S; ++s) {
-        const int Ks = p->K_s ? p->K_s[s] : Kt;
-        for (int k = k0; k < k0 + Ks; ++k) {
-            if (p->W_sparsity) lw[k] = (float)p->W_sparsity[s];
-            if (p->H_sparsity) lh[k] = (float)p->H_sparsity[s];
-            if (p->W_fixed) fw[k] = p->W_fixed[s];
-            if (p->H_fixed) fh[k] = p->H_fixed[s];
-        }
-        k0 += Ks;
-    }
+    std::vector<float> lw, lh;
+    std::vector<uint8_t> fw, fh;
+    expand_sources(p, K, lw, lh, fw, fh);
     const size_t mK = (size_t)m * K * T, mKt = (size_t)m * Kt * T;   // (cnmf: the T slices of W; K is never padded there)
     size_t packed_count = 0;
     int kind = -1;

@@ -169,6 +169,14 @@ Layout layout(nmfx_engine *e, void *ws) {
             if (needh > e->n_cost_partials) { e->n_cost_partials = needh; e->cost_partials = c.take<double>(needh); }
         }
     }
+    if (e->eucw) {
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * e->m * 256) : nullptr;
+        e->VT = c.take<float>((size_t)e->m * e->n);
+        e->WT = c.take<float>(mKT);
+        e->slabsH = e->klw_hsplit > 1 ? c.take<float>((size_t)e->klw_hsplit * Kn) : nullptr;
+        const int need = std::max((int)((e->m + 127) / 128) * e->nsplit_T, (int)((e->n + 127) / 128) * e->klw_hsplit);
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+    }
     L.total = c.off;
     L.packed_count = e->gram ? mKT + (size_t)e->KT * e->KT : (div_has_matrix_den(e->div) ? 2 * mKT : mKT + (size_t)e->KT);
     return L;
@@ -267,7 +275,11 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     static const bool no_klw = getenv("NMFX_KL_WIDE_OFF") != nullptr;   // dev switch (A/B runs): K > 256 on the materialised path
     e->klw = !e->fused && e->algo != 1 && e->T == 1 && e->div == NMFX_DIV_KL && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
              e->m >= 64 && e->n >= 64 && d->path != 1 && !no_klw;
-    if (e->klw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
+    static const bool no_eucw = getenv("NMFX_EUC_WIDE_OFF") != nullptr;   // dev switch (A/B runs): K > 256 in Gram form on the two-operand GEMM
+    e->eucw = e->gram && (e->algo == 0 || e->algo == 3) && e->T == 1 && e->div == NMFX_DIV_EUCLIDEAN && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
+              e->m >= 64 && e->n >= 64 && !no_vt && room_vt && !no_eucw;
+    if (e->eucw && !exact_cost_env) e->gram_cost = true;
+    if (e->klw || e->eucw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
         const int units = e->K / 32;
         e->klw_nb = (e->K + 255) / 256;
         for (int b = 0, k0 = 0; b < e->klw_nb; ++b) {
@@ -276,7 +288,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
             k0 += 32 * u;
         }
         e->nsplit_T = fused_split((e->m + 127) / 128, e->n, 256, &e->cps_T);
-        e->klw_vt = !no_vt && room_vt;
+        e->klw_vt = e->klw && !no_vt && room_vt;
         e->klw_hsplit = fused_split((e->n + 127) / 128, e->m, 256, &e->klw_hcps);
     }
     static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
@@ -627,7 +639,7 @@ nmfx_status klw_s_pass(nmfx_engine *e, bool store_R, bool with_cost) {
     return NMFX_OK;
 }
 // N(:, block) = R * H(block, :)' for every column block, R = V./S in the V_hat buffer: the W-step form without a first product
-nmfx_status klw_num_pass(nmfx_engine *e, float *out) {
+nmfx_status klw_num_pass(nmfx_engine *e, float *out, const float *D) {
     for (int b = 0; b < e->klw_nb; ++b) {
         const int kb = e->klw_kb[b];
         long cps = 0;
@@ -636,7 +648,7 @@ nmfx_status klw_num_pass(nmfx_engine *e, float *out) {
         FusedParams f;
         memset(&f, 0, sizeof(f));
         f.Y = e->H + e->klw_k0[b]; f.y_stride = e->K;
-        f.D = e->Vhat; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = kb; f.c_per_split = cps;
+        f.D = D; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = kb; f.c_per_split = cps;
         float *dst = out + (size_t)e->m * e->klw_k0[b];
         f.out = split == 1 ? dst : e->slabsT; f.slab_stride = e->m * (long)kb; f.os_r = 1; f.os_k = e->m;
         {
@@ -645,6 +657,48 @@ nmfx_status klw_num_pass(nmfx_engine *e, float *out) {
         }
         if (split > 1) { Scope s(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->slabsT, split, f.slab_stride, f.slab_stride, dst, 0)); }
     }
+    return NMFX_OK;
+}
+// euclidean, K > 256 (e->eucw): the explicit residual sum (V - W*H).^2 behind the Gram-form cost -- the S chain above with functor 10 closing it; run_if: the
+// device-side flag of the conditional launch
+nmfx_status eucw_cost_pass(nmfx_engine *e, const int *run_if) {
+    Scope s(e, run_if ? TAG_SMALL : TAG_FUSED_COST);
+    for (int b = 0; b < e->klw_nb; ++b) {
+        const bool last = b + 1 == e->klw_nb;
+        long cps = 0;
+        const int split = fused_split((e->m + 127) / 128, e->n, e->klw_kb[b], &cps);
+        FusedParams f;
+        memset(&f, 0, sizeof(f));
+        f.X = e->W + (size_t)e->m * e->klw_k0[b]; f.xs_r = 1; f.xs_k = e->m;
+        f.Y = e->H + e->klw_k0[b]; f.y_stride = e->K;
+        f.D = e->V; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->klw_kb[b]; f.c_per_split = cps;
+        f.Sin = b > 0 ? e->Vhat : nullptr;
+        f.Rout = last ? nullptr : e->Vhat;
+        f.cost_partials = last ? e->cost_partials : nullptr;
+        f.run_if = run_if;
+        TRY(launch_fused(e->st, f, split, true, last ? 10 : 7, false, 0));
+        if (last) e->n_cost_used = (int)((e->m + 127) / 128) * split;
+    }
+    return NMFX_OK;
+}
+// ... and its H-step numerator Gn(block, :) = (V' * W(:, block))' on the transposed copy of V (as the K <= 256 path does)
+nmfx_status eucw_hnum(nmfx_engine *e) {
+    {
+        Scope s(e, TAG_SMALL);
+        TRY(transpose_f32(e->st, e->W, e->m, e->K, e->WT));
+    }
+    const long Kn = (long)e->K * e->n;
+    const int split = e->klw_hsplit;
+    for (int b = 0; b < e->klw_nb; ++b) {
+        FusedParams g;
+        memset(&g, 0, sizeof(g));
+        g.Y = e->WT + e->klw_k0[b]; g.y_stride = e->K;
+        g.D = e->VT; g.ldd = e->n; g.R = e->n; g.Cn = e->m; g.K = e->klw_kb[b]; g.c_per_split = e->klw_hcps;
+        g.out = (split == 1 ? e->Gn : e->slabsH) + e->klw_k0[b]; g.slab_stride = Kn; g.os_r = e->K; g.os_k = 1;
+        Scope s(e, TAG_HNUM);
+        TRY(launch_fused(e->st, g, split, true, 0, true, 0));
+    }
+    if (split > 1) { Scope s(e, TAG_SMALL); TRY(reduce_slabs(e->st, e->slabsH, split, Kn, Kn, e->Gn, 0)); }
     return NMFX_OK;
 }
 // H step on the transposed copy of V: rows of V' (columns j of V) stationary, rows of W (the W' copy) streamed.  R' = V'./(H'*W') block by block into the V_hat
@@ -738,6 +792,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     e->V = V; e->W = W; e->Hext = H; e->H = H + (size_t)e->K * e->hL; e->packed = packed;
     // the transposed copy of V is optional: it is used when the workspace the caller brought has the room for it (nmfx_engine_workspace_bytes
     // asks for it when the device looked roomy at that moment; a caller that allocated less simply gets the path without it)
+    if (e->eucw && layout(e, nullptr).total > workspace_bytes) { e->eucw = false; e->gram_cost = false; }   // (sized without V': the plain Gram path)
     if ((e->use_vt || e->use_vtq || e->klw_vt) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = e->klw_vt = false;
     else if (!e->use_vt && !e->use_vtq && !e->klw_vt) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
         nmfx_engine probe = *e;
@@ -864,7 +919,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
         }
     }
     if (e->gram) {                 // no V_hat state on the Gram path
-        if (e->use_vtq) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
+        if (e->use_vtq || e->eucw) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
         if (e->gram_cost) {        // ||V||^2, once
             Scope s(e, TAG_SMALL);
             TRY(col_reduce(e->st, e->V, e->m, e->m, (int)e->n, 1, e->colV));
@@ -969,13 +1024,18 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         TRY(klw_s_pass(e, !e->all_fixW, true));
         TRY(klw_cost(e));
     }
-    e->wstep_gram = e->fusedT && e->gram_cost;   // the cost of the state this step starts from follows in wstep_finish (no host latch here: once the device flag
+    if (e->eucw && e->gram_cost && e->dist_seen && !e->sumvv_global_set) {
+        set_error("nmfx_engine: column shards in Gram-form cost mode need nmfx_engine_sumvv_set_global first");
+        return NMFX_ERR_INVALID;
+    }
+    e->wstep_gram = (e->fusedT || e->eucw) && e->gram_cost;   // the cost of the state this step starts from follows in wstep_finish (no host latch here: once the device flag
                                                  // is set the conditional residual pass simply runs every time -- the same work the un-lagged cost pass was)
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
     if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
-    else if (e->klw) TRY(klw_num_pass(e, e->packed));
+    else if (e->klw) TRY(klw_num_pass(e, e->packed, e->Vhat));
+    else if (e->eucw) TRY(klw_num_pass(e, e->packed, e->V));
     else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
     if (e->lagram) {   // Hs*Hs' from the T lag Grams L_d = sum_u H(:,u) H(:,u+d)' (K x T*K, contraction n, on the zero-padded copy) + boundary terms
         TRY(ensure_hpad(e));
@@ -1081,7 +1141,8 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             p.dndp = e->dndp; p.stats_only = 1;
             TRY(w_update(e->st, p));
             TRY(gram_decide(e->st, e->dndp, e->KT, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host));
-            TRY(fusedT_pass(e, FT_COST_EUC, nullptr, e->exact_flag));
+            if (e->eucw) TRY(eucw_cost_pass(e, e->exact_flag));
+            else TRY(fusedT_pass(e, FT_COST_EUC, nullptr, e->exact_flag));
             TRY(gram_cost_finish(e->st, e->dndp, e->KT, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->n_cost_used, useW ? e->l1W : nullptr, e->KT, e->lamW,
                                  useH ? e->l1H : nullptr, e->K, e->lamH, e->cost, e->cost_dst2));
             if (e->cost_dst2) e->cost_dst2_done = true;
@@ -1223,6 +1284,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         }
         e->hpad_valid = false;
         if (e->klw_vt) TRY(klw_hstep_vt(e));
+        else if (e->eucw) TRY(eucw_hnum(e));
         else if (e->qgemm) {
             // sum_t W_t' * lshift_t(V) as ONE well-shaped GEMM Q = W_flat' * V (KT x n, contraction m) + a shift-sum over t, instead of a
             // (K x n) GEMM with contraction T*m whose 64-row output starves the tiles
@@ -1324,7 +1386,7 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
     if (e->fusedT_kl || e->klw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
-    if (e->fusedT && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
+    if ((e->fusedT || e->eucw) && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
     if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
     else TRY(recon(e, !nocost));
@@ -1343,7 +1405,9 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     if (e->fused) return fused_wpass(e, false);
     if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
     if (e->klw) { TRY(klw_s_pass(e, false, true)); return klw_cost(e); }
-    if (e->fusedT && e->gram_cost) {
+    if ((e->fusedT || e->eucw) && e->gram_cost) {
+        if (e->eucw) TRY(eucw_cost_pass(e, nullptr));
+        else
         TRY(fusedT_pass(e, FT_COST_EUC, nullptr));
         Scope s(e, TAG_SMALL);
         e->cost_valid = true;
@@ -1352,7 +1416,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->gram ? 2 : 0)))); }   // 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->eucw ? 6 : (e->gram ? 2 : 0))))); }   // 6 euclidean with K > 256 in column blocks, 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
@@ -1425,7 +1489,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
-        if (e->fusedT || e->fusedT_kl || e->klw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
+        if (e->fusedT || e->fusedT_kl || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;

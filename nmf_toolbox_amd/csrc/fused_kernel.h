@@ -30,7 +30,8 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //       7 / 8 (cost-only form, W-step form): the first product in SEVERAL launches over column blocks of a factor wider than 256 (KL with K > 256,
 //         nmf.m:152-153,183-184 have no K limit).  Every launch starts its S tile from the partial sums of the launches before it (p.Sin, read like the
 //         V tile; nullptr = zeros) and contracts its own <= 256 components: 7 stores the raw partial S (p.Rout), 8 is the last block and goes on
-//         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes
+//         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes; 10 is the last block of a euclidean chain: the residual
+//         sum (V - S).^2 of the accumulated S (functor 1's terms), nothing stored
 //       9 (cost-only form, W-step form): R = max(D + S, 0) stored to p.Rout -- cnmfsc.m:262, V_hat = max(V_hat + dW_t * rshift_t(H), 0), in place (D = Rout = V_hat)
 //       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc keeps V_hat: its W branch updates it slice by slice)
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
-    constexpr bool S_IN = FUNC == 7 || FUNC == 8;   // S accumulated over several launches (column blocks of a wide factor)
-    constexpr int MF = FUNC == 8 ? 3 : FUNC;        // the element map
+    constexpr bool S_IN = FUNC == 7 || FUNC == 8 || FUNC == 10;   // S accumulated over several launches (column blocks of a wide factor)
+    constexpr int MF = FUNC == 8 ? 3 : (FUNC == 10 ? 1 : FUNC);   // the element map
     static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
     // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
@@ -270,11 +271,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 }
             } else {
                 if (u == 0) {
-                    if (FUNC == 1) { const float e = v - sacc[jb][reg]; tc = live ? fmaf(e, e, tc) : tc; }   // nmf.m:208
-                    if (DO_G2 || FUNC != 1) sacc[jb][reg] = live ? v : 0.0f;   // (cost-only form: S stays, for the optional store below)
+                    if (MF == 1) { const float e = v - sacc[jb][reg]; tc = live ? fmaf(e, e, tc) : tc; }   // nmf.m:208
+                    if (DO_G2 || MF != 1) sacc[jb][reg] = live ? v : 0.0f;   // (cost-only form: S stays, for the optional store below)
                 }
             }
-            if (((FUNC == 1 || FUNC == 6) && u == 0) || (MF == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
+            if (((MF == 1 || FUNC == 6) && u == 0) || (MF == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
         // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
         // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)

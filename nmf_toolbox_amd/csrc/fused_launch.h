@@ -56,6 +56,7 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 6: if constexpr (DO_G2 && EPI == 0) return launch_one<K, D_RC, 6, DO_G2, EPI, RAG>(st, p, nsplit); break;   // residual-form gradients (nmfsc)
     case 7: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 7, DO_G2, EPI, RAG>(st, p, nsplit); break;   // S over column blocks of a factor wider than 256
     case 8: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 8, DO_G2, EPI, RAG>(st, p, nsplit); break;
+    case 10: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 10, DO_G2, EPI, RAG>(st, p, nsplit); break;   // ... of a euclidean chain: residual cost
     case 9: if constexpr (!DO_G2 && D_RC && K <= 128) return launch_one<K, D_RC, 9, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:262 (K = components of one time slice)
     }
     set_error("launch_fused: unsupported functor %d", func);

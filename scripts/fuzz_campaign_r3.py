@@ -14,7 +14,7 @@ PAIRS = [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 
 t0 = time.time(); counts = {}; worst = dict(W=0.0, H=0.0, cost=0.0); bad = []
 cat = lambda x: np.concatenate([np.asarray(a).reshape(-1) for a in x]) if isinstance(x, (list, tuple)) else np.asarray(x).reshape(-1)
 while time.time() - t0 < budget:
-    kind = str(rs.choice(["klw", "klw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost"]))
+    kind = str(rs.choice(["klw", "klw", "eucw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost"]))
     tries_ok = True
     if kind == "klw":
         K = int(rs.choice([257, 288, 300, 320, 384, 400, 448, 512, 520, 640]))
@@ -37,6 +37,19 @@ while time.time() - t0 < budget:
             ref = O.lnmf(V, K, c2); got = A.lnmf(V, K, dict(c2, **extra)); kind = "klw_lnmf"
         else:
             ref = O.nmf(V, Ks, cfg); got = A.nmf(V, Ks, dict(cfg, **extra))
+        tag = (kind, m, n, K, extra, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
+    elif kind == "eucw":   # euclidean above K = 256 (column blocks, Gram-form cost and its switch), one GPU or shards
+        K = int(rs.choice([257, 288, 300, 320, 384, 400, 448, 512, 520, 640]))
+        m, n = int(rs.randint(64, 500)), int(rs.randint(200, 1500))
+        V, W0, H0 = synth(m, n, K, planted=bool(rs.rand() < 0.5))
+        cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=int(rs.randint(1, 12)), tolerance=1e-300)
+        if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.1), float(rs.rand() * 0.1)
+        r = rs.rand()
+        if r < 0.15: cfg["W_fixed"] = True
+        elif r < 0.3: cfg["H_fixed"] = True
+        extra = {}
+        if rs.rand() < 0.3 and n >= 400: extra["nmfx_gpus"] = [0] * int(rs.randint(2, 5))
+        ref = O.nmf(V, K, cfg); got = A.nmf(V, K, dict(cfg, **extra))
         tag = (kind, m, n, K, extra, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
     elif kind == "multi_cnmf":
         K, T = PAIRS[rs.randint(len(PAIRS))] if rs.rand() < 0.7 else (int(rs.randint(3, 20)), int(rs.randint(2, 6)))

@@ -758,6 +758,39 @@ def test_nmf_kl_K_above_256_in_column_blocks(gpu_lib, m, n, K, algo):
         _check(got2, ref2)
 
 
+@pytest.mark.parametrize("m,n,K,planted", [(512, 768, 320, False), (300, 1000, 257, False), (640, 512, 512, True), (257, 4160, 288, True), (384, 1024, 800, False)])
+def test_nmf_euclidean_K_above_256_in_column_blocks(gpu_lib, m, n, K, planted):
+    """nmf.m:149-150,180-181 with K > 256: V*H' and W'*V block by block on the stationary kernel (the latter over the transposed copy of V), denominators from
+    K x K Gram products, the cost in Gram form out of the W update's column sums -- engine path 6, cost lag 2.  Planted data drive the residual below 5 % of
+    ||V||^2, where the device-side switch turns the explicit residual on: the S chain of functors 7 / 10.  Also: any K through the blocking call, the stop
+    rule handing back the state of the iteration it fired on, column shards, and the two-operand GEMM path (nmfx_path = 1) as a second opinion."""
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
+    V, W0, H0 = synth(m, n, K, planted=planted)
+    if K % 32 == 0:
+        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence="euclidean", use_dist=False)
+        assert e.path_kind == 6 and e.cost_lag == 2
+        e.close()
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=10, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.nmf(V, K, cfg)
+    got = gpu_lib.nmf(V, K, cfg)
+    _check(got, ref)
+    if planted:
+        assert ref[2][-1] < 0.05 * 0.5 * float((V ** 2).sum())                # ... so the explicit residual pass did take over on the way
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0, 0, 0])), ref)            # three column shards of one GPU
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1)), ref)
+    again = gpu_lib.nmf(V, K, cfg)
+    assert np.array_equal(again[0], got[0]) and np.array_equal(again[1], got[1]) and np.array_equal(again[2], got[2])   # run to run
+    probe = O.nmf(V, K, dict(cfg, maxiter=14, tolerance=1e-300))[2]
+    dec = -np.diff(probe)
+    if np.all(dec[:8] > 0) and dec[5] > dec[6]:
+        cfg2 = dict(cfg, maxiter=14, tolerance=float(0.5 * (dec[5] + dec[6])))
+        ref2 = O.nmf(V, K, cfg2)
+        got2 = gpu_lib.nmf(V, K, cfg2)
+        assert len(got2[2]) == len(ref2[2]) < 14
+        _check(got2, ref2)
+
+
 # ---- IS and alpha-beta on the fused kernels (two element maps / two accumulator sets per pass, K <= 128): split and un-split epilogues,
 # ragged shapes, padded K, sources with sparsity / fixed flags; against the oracle and against the generic (materialised V_hat) path ----
 @pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5)), ("ab", (2.0, -0.5)), ("ab", (1.0, 0.5)), ("ab", (1.5, -1.5))])
