@@ -240,8 +240,8 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_INVALID;
     }
     // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
-    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps and two accumulator sets per pass: K <= 128
-    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 128;
+    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps and two accumulator sets per pass: K <= 192 (registers)
+    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 192;
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
                           e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
     if (d->path == 2 && !eligible && e->algo != 1) {   // cnmf: see the fused shift-sum passes below

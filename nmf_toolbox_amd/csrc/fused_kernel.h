@@ -23,7 +23,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 }
 
 // FUNC: 0 R=V, no S | 1 R=V, S only for the euclidean cost | 2 R=V./S (KL) | 3 R=V./S + KL cost
-//       4 IS (nmf.m:155-156,186-187,212): TWO element maps per pass, A = V./S.^2 and B = 1./S, two accumulator sets (K <= 128)
+//       4 IS (nmf.m:155-156,186-187,212): TWO element maps per pass, A = V./S.^2 and B = 1./S, two accumulator sets (K <= 192)
 //       5 alpha-beta, alpha ~= 0 (nmf.m:162-163,193-194,214): A = V.^alpha .* S.^(beta-1), B = S.^(alpha+beta-1); D holds V.^alpha
 //       6 R = S - V (the residual) + euclidean cost: the gradients of nmfsc.m:144-148,194-200 in ONE contraction, dH = W'*(W*H - V) /
 //         dW = (W*H - V)*H', instead of the difference of two separately rounded products (which cancels as the fit improves)
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S && PROBE == 0;
     constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
-    static_assert(!DUAL || (K <= 128 && TT == 1), "dual-map kernels: K <= 128 (two accumulator sets + the stationary operand must fit 512 VGPRs)");
+    static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
     // LDS float offset of contraction index kq (a multiple of 4 or of 32, never straddling a block of KH) relative to the row of streamed index c

@@ -51,8 +51,8 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 1: return launch_one<K, D_RC, 1, DO_G2, EPI, RAG>(st, p, nsplit);
     case 2: if (DO_G2) return launch_one<K, D_RC, 2, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 3: return launch_one<K, D_RC, 3, DO_G2, EPI, RAG>(st, p, nsplit);
-    case 4: if constexpr (K <= 128) return launch_one<K, D_RC, 4, DO_G2, EPI, RAG>(st, p, nsplit); break;   // dual-map divergences: two accumulator sets
-    case 5: if constexpr (K <= 128) return launch_one<K, D_RC, 5, DO_G2, EPI, RAG>(st, p, nsplit); break;
+    case 4: if constexpr (K <= 192) return launch_one<K, D_RC, 4, DO_G2, EPI, RAG>(st, p, nsplit); break;   // dual-map divergences: two accumulator sets
+    case 5: if constexpr (K <= 192) return launch_one<K, D_RC, 5, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 6: if constexpr (DO_G2 && EPI == 0) return launch_one<K, D_RC, 6, DO_G2, EPI, RAG>(st, p, nsplit); break;   // residual-form gradients (nmfsc)
     case 7: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 7, DO_G2, EPI, RAG>(st, p, nsplit); break;   // S over column blocks of a factor wider than 256
     case 8: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 8, DO_G2, EPI, RAG>(st, p, nsplit); break;

@@ -134,7 +134,7 @@ struct FusedParams {
 };
 bool fused_supported(int K);
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
-// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 128) | 6 R=S-V + euclidean cost (do_g2, slabs out)
+// func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 192) | 6 R=S-V + euclidean cost (do_g2, slabs out)
 //       | 7 / 8 (do_g2=false): S over column blocks of a wide factor, see fused_kernel.h;  do_g2=false: cost-only pass
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 

@@ -794,7 +794,7 @@ def test_nmf_euclidean_K_above_256_in_column_blocks(gpu_lib, m, n, K, planted):
 # ---- IS and alpha-beta on the fused kernels (two element maps / two accumulator sets per pass, K <= 128): split and un-split epilogues,
 # ragged shapes, padded K, sources with sparsity / fixed flags; against the oracle and against the generic (materialised V_hat) path ----
 @pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5)), ("ab", (2.0, -0.5)), ("ab", (1.0, 0.5)), ("ab", (1.5, -1.5))])
-@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 15), (384, 640, 128, 10), (128, 8192, 32, 4), (513, 300, 40, 8), (129, 131, 96, 8), (2049, 257, 100, 4)])
+@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 15), (384, 640, 128, 10), (128, 8192, 32, 4), (513, 300, 40, 8), (129, 131, 96, 8), (2049, 257, 100, 4), (384, 1024, 192, 8), (300, 700, 150, 6)])   # the last two: K above 128 (two accumulator sets still fit up to 192)
 def test_nmf_fused_is_and_alpha_beta(gpu_lib, div, ab, m, n, K, iters):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K)
