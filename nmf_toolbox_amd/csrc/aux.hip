@@ -544,7 +544,10 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
                                                           int cnmf_rule, double *f_out, int kvalid) {
     const int c = blockIdx.x, k = c % K, t = c / K;
     if (fix && fix[k]) return;
-    if (kvalid > 0 && k >= kvalid) return;   // zero padding components (nmfx_engine_desc.K_valid): 0 * (1/0) must not turn into NaN
+    if (kvalid > 0 && k >= kvalid) {         // zero padding components (nmfx_engine_desc.K_valid): 0 * (1/0) must not turn into NaN
+        if (cnmf_rule == 1 && f_out && t == 0 && threadIdx.x == 0) f_out[k] = 1.0;   // (cnmf.m:165 rescales row k of H by it: the zero row stays zero)
+        return;
+    }
     float *w = W + m * c;
     if (cnmf_rule == 1) {
         double s = 0.0;

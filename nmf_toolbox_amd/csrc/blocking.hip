@@ -43,9 +43,13 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
     const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 192;   // fused IS / alpha-beta: K <= 192
-    const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && p->m >= 64 && p->n >= 64)) &&   // (above 256: column blocks, engine.klw / eucw)
-                     ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
-    const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
+    const int Kup = (Kt + 31) / 32 * 32;
+    // cnmf: the same zero padding opens the fused shift-sum passes to any K whose padded size is an instantiated (K, T) pair (K = 20, T = 8 runs as (32, 8))
+    const bool pad_cnmf = algorithm == 1 && Kt % 32 != 0 && p->T > 1 && fused_supported_T(Kup, p->T) && p->m >= 64 && p->n >= 64 && p->path != 1 &&
+                          (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dv == NMFX_DIV_EUCLIDEAN_NOCOST) && getenv("NMFX_CNMF_NO_FUSED") == nullptr;
+    const bool pad = pad_cnmf || (algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && p->m >= 64 && p->n >= 64)) &&   // (above 256: column blocks, engine.klw / eucw)
+                     ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok));
+    const int K = pad ? Kup : Kt;
     std::vector<float> lw, lh;
     std::vector<uint8_t> fw, fh;
     expand_sources(p, K, lw, lh, fw, fh);
@@ -74,8 +78,14 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
     DevBuf tmp;   // K x cols staging of the un-padded row-interleaved arrays (H, Z)
     if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
-    TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0));   // the first K columns of the m x K_pad array
-    if (pad) NMFX_HIP(hipMemsetAsync(W.as<float>() + mKt, 0, (mKT - mKt) * 4, st));
+    if (pad && p->T > 1) {   // cnmf: every time slice m x K of W is padded on its own
+        const size_t sl = (size_t)p->m * Kt, slp = (size_t)p->m * K;
+        NMFX_HIP(hipMemsetAsync(W.as<float>(), 0, mKT * 4, st));
+        for (int t = 0; t < p->T; ++t) TRY(upload(st, static_cast<const char *>(p->W_init) + t * sl * dsize(p->dtype), p->dtype, W.as<float>() + t * slp, sl, 1.0));
+    } else {
+        TRY(upload(st, p->W_init, p->dtype, W.as<float>(), mKt, 1.0));   // the first K columns of the m x K_pad array
+        if (pad) NMFX_HIP(hipMemsetAsync(W.as<float>() + mKt, 0, (mKT - mKt) * 4, st));
+    }
     if (algorithm != 3) {
         if (pad) {
             TRY(upload(st, p->H_init, p->dtype, tmp.as<float>(), Ktn, 1.0));
@@ -158,7 +168,10 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         r->cost_len = p->maxiter;
     }
     const auto t2 = std::chrono::steady_clock::now();   // (the last cost read-back has synchronised the iterations)
-    if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt);
+    if (pad && p->T > 1) {
+        const size_t sl = (size_t)p->m * Kt, slp = (size_t)p->m * K;
+        for (int t = 0; t < p->T && s == NMFX_OK; ++t) s = download(st, W.as<float>() + t * slp, p->dtype, static_cast<char *>(r->W) + t * sl * dsize(p->dtype), sl);
+    } else if (s == NMFX_OK) s = download(st, W.as<float>(), p->dtype, r->W, mKt);
     if (s == NMFX_OK && pad) {
         s = repack_rows(st, H.as<float>(), K, tmp.as<float>(), Kt, p->n);
         if (s == NMFX_OK) s = download(st, tmp.as<float>(), p->dtype, r->H, Ktn);

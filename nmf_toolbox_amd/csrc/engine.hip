@@ -213,7 +213,6 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     }
     e->K = d->K_total;
     e->K_valid = (d->K_valid > 0 && d->K_valid < d->K_total) ? d->K_valid : 0;
-    if (e->K_valid && d->algorithm == 1) { set_error("nmfx_engine: K padding is not defined for cnmf"); return NMFX_ERR_INVALID; }
     e->T = d->T;
     e->KT = d->K_total * d->T;
     e->div = d->divergence;

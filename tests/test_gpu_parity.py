@@ -306,6 +306,31 @@ def test_cnmf_gram_form_matches_materialised_and_oracle(gpu_lib, div, m, n, K, T
     _check(gram, mat)
 
 
+@pytest.mark.parametrize("div", ["euclidean", "kl", "frobenius"])
+@pytest.mark.parametrize("m,n,K,T", [(513, 700, 20, 8), (129, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16)])
+def test_cnmf_any_K_on_the_fused_passes(gpu_lib, div, m, n, K, T):
+    """cnmf with K that is not a multiple of 32: the blocking call pads every time slice of W (and the rows of H) with zero, fixed components up to an
+    instantiated (K, T) pair -- K = 20, T = 8 runs as (32, 8) -- so spectrogram-sized problems with any number of bases take the fused shift-sum passes
+    (nmfx_path = 2 refuses anything else).  The padding adds exact zeros to every product, is skipped by the slab normalisation (cnmf.m:161-165, 196-199:
+    0/0) and is stripped on the way out; against the oracle, the GEMM path, and with sparsity / fixed factors / two sources."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
+    assert got[0].shape == (m, K, T) and got[1].shape == (K, n)
+    _check(got, ref)
+    _check(gpu_lib.cnmf(V, K, T, cfg), ref)                       # the default takes the same route
+    _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1)), ref)
+    if K >= 7 and div != "frobenius":
+        k1 = K // 3
+        cfg2 = dict(divergence=div, W_init=[W0[:, :k1], W0[:, k1:]], H_init=[H0[:k1], H0[k1:]], W_sparsity=[0.02, 0.0], H_fixed=[False, True], maxiter=5, tolerance=1e-12)
+        ref2 = O.cnmf(V, [k1, K - k1], T, cfg2)
+        got2 = gpu_lib.cnmf(V, [k1, K - k1], T, dict(cfg2, nmfx_path=2))
+        assert rel_fro(np.concatenate(got2[0], 1), np.concatenate(ref2[0], 1)) <= 1e-5 and rel_fro(np.vstack(got2[1]), np.vstack(ref2[1])) <= 1e-5
+        assert rel_fro(got2[2], ref2[2]) <= 1e-6
+
+
 # ---- cnmfsc (SURVEY 8(f) row f1): convolutive NMF with Hoyer sparseness, reference quirks included ---------------------
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.0), (0.0, 0.5), (0.3, 0.0), (0.4, 0.6)])
 @pytest.mark.parametrize("m,n,K,T", [(96, 200, 6, 4), (128, 256, 8, 1)])
