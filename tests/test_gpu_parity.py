@@ -863,13 +863,14 @@ def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
     _check(gpu_lib.nmf(V, Ks, cfg), ref, cost_tol=1e-5)
     _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_gpus=[0, 0, 0])), ref, cost_tol=1e-5)          # [N | P] through the peer exchange on three shards
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.nmf(V, 160, dict(divergence="is", maxiter=1, nmfx_path=2))                   # two accumulator sets: K <= 128 only
+        gpu_lib.nmf(V, 224, dict(divergence="is", maxiter=1, nmfx_path=2))                   # two accumulator sets: K <= 192 only (224 spills)
 
 
 # ---- cnmf on the register-stationary kernels (fused_kernel TT > 1): every instantiated (K, T) pair, aligned and ragged shapes, sparsity,
 # fixed factors, 'frobenius' (no cost); against the oracle and against the GEMM formulations -----------------------------------------
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
-@pytest.mark.parametrize("K,T", [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4)])
+@pytest.mark.parametrize("K,T", [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4),
+                                 (32, 3), (32, 5), (32, 6), (64, 3), (32, 10), (32, 12), (64, 5), (64, 6)])          # second line: round 3
 @pytest.mark.parametrize("m,n", [(256, 512), (129, 333), (640, 65)])
 def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n, div):
     from oracle import nmf_oracle as O
@@ -899,4 +900,4 @@ def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.cnmf(V, 64, 4, dict(divergence="is", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean / kl
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.cnmf(V[:, :300], 48, 4, dict(maxiter=1, nmfx_path=2))                                   # (48, 4) is not instantiated
+        gpu_lib.cnmf(V[:, :300], 48, 7, dict(maxiter=1, nmfx_path=2))                                   # no (K, 7) pair is instantiated, padded or not
