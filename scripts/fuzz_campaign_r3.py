@@ -14,7 +14,7 @@ PAIRS = [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 
 t0 = time.time(); counts = {}; worst = dict(W=0.0, H=0.0, cost=0.0); bad = []
 cat = lambda x: np.concatenate([np.asarray(a).reshape(-1) for a in x]) if isinstance(x, (list, tuple)) else np.asarray(x).reshape(-1)
 while time.time() - t0 < budget:
-    kind = str(rs.choice(["klw", "klw", "eucw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost"]))
+    kind = str(rs.choice(["klw", "klw", "eucw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost", "cnmf_pad", "is_wide"]))
     tries_ok = True
     if kind == "klw":
         K = int(rs.choice([257, 288, 300, 320, 384, 400, 448, 512, 520, 640]))
@@ -51,6 +51,30 @@ while time.time() - t0 < budget:
         if rs.rand() < 0.3 and n >= 400: extra["nmfx_gpus"] = [0] * int(rs.randint(2, 5))
         ref = O.nmf(V, K, cfg); got = A.nmf(V, K, dict(cfg, **extra))
         tag = (kind, m, n, K, extra, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
+    elif kind == "cnmf_pad":   # cnmf with any K padded onto an instantiated (K, T) pair, the round-3 context lengths included
+        T = int(rs.choice([2, 3, 4, 5, 6, 8, 10, 12, 16]))
+        kmax = {2: 128, 3: 64, 4: 128, 5: 64, 6: 64, 8: 64, 10: 32, 12: 32, 16: 32}[T]
+        K = int(rs.randint(2, kmax + 1))
+        m, n = int(rs.randint(64, 600)), int(rs.randint(max(64, 2 * T), 1200))
+        div = str(rs.choice(["euclidean", "kl", "frobenius"]))
+        V, W0, H0 = synth(m, n, K, T=T)
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=int(rs.randint(1, 9)), tolerance=1e-300, nmfx_path=2)
+        if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.05), float(rs.rand() * 0.05)
+        r = rs.rand()
+        if r < 0.15: cfg["W_fixed"] = True
+        elif r < 0.3: cfg["H_fixed"] = True
+        ref = O.cnmf(V, K, T, cfg); got = A.cnmf(V, K, T, cfg)
+        tag = (kind, m, n, K, T, div, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
+    elif kind == "is_wide":    # IS / alpha-beta on the dual-map kernels above K = 128
+        K = int(rs.choice([130, 150, 160, 176, 192]))
+        m, n = int(rs.randint(64, 500)), int(rs.randint(64, 1200))
+        div = str(rs.choice(["is", "ab"]))
+        V, W0, H0 = synth(m, n, K)
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=int(rs.randint(1, 7)), tolerance=1e-300, nmfx_path=2)
+        if div == "ab": cfg["alpha"], cfg["beta"] = [(0.5, 1.5), (2.0, -0.5), (1.0, 0.5), (1.5, 0.2)][rs.randint(4)]
+        if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.05), float(rs.rand() * 0.05)
+        ref = O.nmf(V, K, cfg); got = A.nmf(V, K, cfg)
+        tag = (kind, m, n, K, div, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
     elif kind == "multi_cnmf":
         K, T = PAIRS[rs.randint(len(PAIRS))] if rs.rand() < 0.7 else (int(rs.randint(3, 20)), int(rs.randint(2, 6)))
         N = int(rs.randint(2, 6))
@@ -113,7 +137,7 @@ while time.time() - t0 < budget:
     fin = same_len and np.all(np.isfinite(ref[2])) and np.linalg.norm(ref[2]) > 0
     e = dict(W=rel_fro(cat(got[0]), cat(ref[0])), H=rel_fro(cat(got[1]), cat(ref[1])), cost=(rel_fro(got[2], ref[2]) if fin else (0.0 if same_len else 1.0)))
     for k in worst: worst[k] = max(worst[k], e[k])
-    lim_c = 1e-5 if (kind == "multi_nmf" and tag[4] == "is") else 1e-6
+    lim_c = 1e-5 if ((kind == "multi_nmf" and tag[4] == "is") or kind == "is_wide") else 1e-6
     if not (e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= lim_c and tries_ok):
         bad.append((tag, e, tries_ok)); print("BAD", tag, e, "tries_ok", tries_ok, flush=True)
 print("seed", seed, "cases", counts, "worst", worst, "bad", len(bad))
