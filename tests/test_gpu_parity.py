@@ -307,7 +307,7 @@ def test_cnmf_gram_form_matches_materialised_and_oracle(gpu_lib, div, m, n, K, T
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl", "frobenius"])
-@pytest.mark.parametrize("m,n,K,T", [(513, 700, 20, 8), (129, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16)])
+@pytest.mark.parametrize("m,n,K,T", [(513, 700, 20, 8), (129, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16), (256, 700, 20, 2), (200, 500, 96, 4), (130, 400, 33, 10)])   # (the last three: the nearest pair is not the next multiple of 32, or does not exist)
 def test_cnmf_any_K_on_the_fused_passes(gpu_lib, div, m, n, K, T):
     """cnmf with K that is not a multiple of 32: the blocking call pads every time slice of W (and the rows of H) with zero, fixed components up to an
     instantiated (K, T) pair -- K = 20, T = 8 runs as (32, 8) -- so spectrogram-sized problems with any number of bases take the fused shift-sum passes
@@ -317,6 +317,11 @@ def test_cnmf_any_K_on_the_fused_passes(gpu_lib, div, m, n, K, T):
     V, W0, H0 = synth(m, n, K, T=T)
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
     ref = O.cnmf(V, K, T, cfg)
+    if (K, T) == (33, 10):                                        # 33 > 32 = the only instantiated K for T = 10: refused by name, served by the GEMM path by default
+        with pytest.raises(Exception, match="not eligible"):
+            gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
+        _check(gpu_lib.cnmf(V, K, T, cfg), ref)
+        return
     got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
     assert got[0].shape == (m, K, T) and got[1].shape == (K, n)
     _check(got, ref)
