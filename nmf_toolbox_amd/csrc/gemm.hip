@@ -352,7 +352,10 @@ int gemm_pick_split(long M, long N, long Kc) {
 
 // slabs of the VALU kernel for tiny products (tiny_gemm_kernel below): a small output over a long contraction needs the contraction split
 // finely to put a few hundred waves on the chip
-static bool tiny_size(long M, long N, long Kc) { return M > 0 && N > 0 && Kc > 0 && 2.0 * (double)M * (double)N * (double)Kc <= (double)(1 << 25); }
+static bool tiny_size(long M, long N, long Kc) {
+    static const double lim = getenv("NMFX_GEMM_TINY_LOG2") ? std::ldexp(1.0, atoi(getenv("NMFX_GEMM_TINY_LOG2"))) : (double)(1 << 25);   // dev switch (accuracy experiments: every plain product fp64-accumulated)
+    return M > 0 && N > 0 && Kc > 0 && 2.0 * (double)M * (double)N * (double)Kc <= lim;
+}
 static long tiny_split(long M, long N, long Kc, long *per) {
     long S = 1;
     *per = Kc;
