@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libnmfx.so")
-SOURCES = ["fused_cnmf_a.hip", "fused_cnmf_b.hip", "fused_cnmf_c.hip", "fused_cnmf_e.hip", "fused_cnmf_d.hip", "gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "small_mm.hip", "engine.hip", "host_io.hip", "blocking.hip", "sc.hip", "multi_sc.hip"]
+SOURCES = ["fused_cnmf_a.hip", "fused_cnmf_b.hip", "fused_cnmf_c.hip", "fused_cnmf_e.hip", "fused_cnmf_d.hip", "fused_cnmf_g.hip", "fused_cnmf_f.hip", "gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "small_mm.hip", "engine.hip", "host_io.hip", "blocking.hip", "sc.hip", "multi_sc.hip"]
 ARCH = "gfx950"
 
 

@@ -29,7 +29,8 @@ bool fused_supported(int K) { return K >= 32 && K <= 256 && K % 32 == 0; }
 // (Kh, T) pairs instantiated in fused_cnmf_*.hip: Kh*T <= 512 (the register-stationary operand / the accumulators take Kh*T/2 VGPRs)
 bool fused_supported_T(int Kh, int T) {
     static const int ok[][2] = {{64, 8}, {64, 4}, {32, 8}, {32, 16}, {64, 2}, {32, 4}, {128, 2}, {128, 4},
-                                {32, 3}, {32, 5}, {32, 6}, {64, 3}, {32, 10}, {32, 12}, {64, 5}, {64, 6}};   // round 3: context lengths 3, 5, 6, 10, 12
+                                {32, 3}, {32, 5}, {32, 6}, {64, 3}, {32, 10}, {32, 12}, {64, 5}, {64, 6},    // round 3: context lengths 3, 5, 6, 10, 12 ...
+                                {32, 7}, {32, 9}, {32, 11}, {64, 7}, {32, 13}, {32, 14}, {32, 15}, {128, 3}, {256, 2}};   // ... and the rest up to 16 (K <= 32), 8 (K <= 64)
     for (const auto &c : ok) if (c[0] == Kh && c[1] == T) return true;
     return false;
 }
@@ -40,7 +41,7 @@ NMFX_DECL(launch_fused_k32_96); NMFX_DECL(launch_fused_k128_192); NMFX_DECL(laun
 NMFX_DECL(launch_fused_rag_k32_96); NMFX_DECL(launch_fused_rag_k128_192); NMFX_DECL(launch_fused_rag_k224_256);
 #undef NMFX_DECL
 #define NMFX_DECL_T(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2)
-NMFX_DECL_T(launch_fused_cnmf_a); NMFX_DECL_T(launch_fused_cnmf_b); NMFX_DECL_T(launch_fused_cnmf_c); NMFX_DECL_T(launch_fused_cnmf_d); NMFX_DECL_T(launch_fused_cnmf_e);
+NMFX_DECL_T(launch_fused_cnmf_a); NMFX_DECL_T(launch_fused_cnmf_b); NMFX_DECL_T(launch_fused_cnmf_c); NMFX_DECL_T(launch_fused_cnmf_d); NMFX_DECL_T(launch_fused_cnmf_e); NMFX_DECL_T(launch_fused_cnmf_f); NMFX_DECL_T(launch_fused_cnmf_g);
 #undef NMFX_DECL_T
 
 // nsplit: number of contraction ranges (grid.y); c_per_split must be a multiple of 64.  R (stationary rows) and Cn (streamed extent)
@@ -61,6 +62,8 @@ nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool 
         if (kh == 32 && (p.T == 8 || p.T == 16)) return launch_fused_cnmf_b(st, p, nsplit, func, do_g2);
         if ((kh == 32 && (p.T == 3 || p.T == 5 || p.T == 6)) || (kh == 64 && p.T == 3)) return launch_fused_cnmf_d(st, p, nsplit, func, do_g2);
         if ((kh == 32 && (p.T == 10 || p.T == 12)) || (kh == 64 && (p.T == 5 || p.T == 6))) return launch_fused_cnmf_e(st, p, nsplit, func, do_g2);
+        if ((kh == 32 && (p.T == 7 || p.T == 9 || p.T == 11)) || (kh == 64 && p.T == 7)) return launch_fused_cnmf_f(st, p, nsplit, func, do_g2);
+        if ((kh == 32 && (p.T == 13 || p.T == 14 || p.T == 15)) || (kh == 128 && p.T == 3) || (kh == 256 && p.T == 2)) return launch_fused_cnmf_g(st, p, nsplit, func, do_g2);
         return launch_fused_cnmf_c(st, p, nsplit, func, do_g2);
     }
     if (!fused_supported(p.K)) { set_error("launch_fused: K=%d not supported (multiples of 32 up to 256)", p.K); return NMFX_ERR_UNSUPPORTED; }

@@ -52,8 +52,8 @@ while time.time() - t0 < budget:
         ref = O.nmf(V, K, cfg); got = A.nmf(V, K, dict(cfg, **extra))
         tag = (kind, m, n, K, extra, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
     elif kind == "cnmf_pad":   # cnmf with any K padded onto an instantiated (K, T) pair, the round-3 context lengths included
-        T = int(rs.choice([2, 3, 4, 5, 6, 8, 10, 12, 16]))
-        kmax = {2: 128, 3: 64, 4: 128, 5: 64, 6: 64, 8: 64, 10: 32, 12: 32, 16: 32}[T]      # the largest instantiated K for that context length: anything below pads up to a pair
+        T = int(rs.randint(2, 17))
+        kmax = {2: 256, 3: 128, 4: 128, 5: 64, 6: 64, 7: 64, 8: 64}.get(T, 32)      # the largest instantiated K for that context length: anything below pads up to a pair
         K = int(rs.randint(2, kmax + 1))
         m, n = int(rs.randint(64, 600)), int(rs.randint(max(64, 2 * T), 1200))
         div = str(rs.choice(["euclidean", "kl", "frobenius"]))

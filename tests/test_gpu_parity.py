@@ -307,7 +307,7 @@ def test_cnmf_gram_form_matches_materialised_and_oracle(gpu_lib, div, m, n, K, T
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl", "frobenius"])
-@pytest.mark.parametrize("m,n,K,T", [(513, 700, 20, 8), (129, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16), (256, 700, 20, 2), (200, 500, 96, 4), (130, 400, 33, 10)])   # (the last three: the nearest pair is not the next multiple of 32, or does not exist)
+@pytest.mark.parametrize("m,n,K,T", [(513, 700, 20, 8), (129, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16), (256, 700, 20, 2), (200, 500, 96, 4), (130, 400, 33, 10), (300, 900, 150, 2), (257, 600, 30, 13)])   # (the last three: the nearest pair is not the next multiple of 32, or does not exist)
 def test_cnmf_any_K_on_the_fused_passes(gpu_lib, div, m, n, K, T):
     """cnmf with K that is not a multiple of 32: the blocking call pads every time slice of W (and the rows of H) with zero, fixed components up to an
     instantiated (K, T) pair -- K = 20, T = 8 runs as (32, 8) -- so spectrogram-sized problems with any number of bases take the fused shift-sum passes
@@ -875,7 +875,8 @@ def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
 # fixed factors, 'frobenius' (no cost); against the oracle and against the GEMM formulations -----------------------------------------
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
 @pytest.mark.parametrize("K,T", [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4),
-                                 (32, 3), (32, 5), (32, 6), (64, 3), (32, 10), (32, 12), (64, 5), (64, 6)])          # second line: round 3
+                                 (32, 3), (32, 5), (32, 6), (64, 3), (32, 10), (32, 12), (64, 5), (64, 6),           # from here: round 3
+                                 (32, 7), (32, 9), (32, 11), (64, 7), (32, 13), (32, 14), (32, 15), (128, 3), (256, 2)])
 @pytest.mark.parametrize("m,n", [(256, 512), (129, 333), (640, 65)])
 def test_cnmf_fused_shift_sum_passes(gpu_lib, K, T, m, n, div):
     from oracle import nmf_oracle as O
@@ -905,4 +906,4 @@ def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.cnmf(V, 64, 4, dict(divergence="is", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean / kl
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.cnmf(V[:, :300], 48, 7, dict(maxiter=1, nmfx_path=2))                                   # no (K, 7) pair is instantiated, padded or not
+        gpu_lib.cnmf(V[:, :300], 100, 7, dict(maxiter=1, nmfx_path=2))                                  # no pair with T = 7 reaches K = 100, padded or not
