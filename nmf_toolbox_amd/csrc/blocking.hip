@@ -318,6 +318,9 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     std::vector<float> lw, lh;
     std::vector<uint8_t> fw, fh;
     expand_sources(p, K, lw, lh, fw, fh);
+    // every shard must run the same kernels (the packed layout and the summation order of the replicated W update depend on them): the fused paths want at
+    // least 64 columns, so one short shard sends all of them to the general kernels
+    const int shard_path = (p->path == 0 && nmin < 64) ? 1 : p->path;
     const size_t mK = (size_t)m * K * T, mKt = (size_t)m * Kt * T;   // (cnmf: the T slices of W; K is never padded there)
     size_t packed_count = 0;
     int kind = -1;
@@ -335,7 +338,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         d.m = m; d.n_local = nl; d.K_total = K; d.T = T; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
         d.halo_left = (int)hL; d.halo_right = (int)hR; d.n_valid = nl + hR;
         d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
-        d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = p->path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
+        d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = shard_path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
         size_t wsb = 0, pc = 0;
         TRY(nmfx_engine_workspace_bytes(&d, &wsb));
         TRY(nmfx_engine_packed_count(&d, &pc));

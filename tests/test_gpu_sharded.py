@@ -770,3 +770,19 @@ def test_blocking_api_n_gpus_nmfsc_stop_rule_errors_and_determinism(gpu_lib):
         gpu_lib.nmfsc(*([synth(256, 600, 300)[0]] + [300]), dict(H_sparsity=0.5, maxiter=2, nmfx_gpus=[0, 0]))
     with pytest.raises(Exception):
         gpu_lib.nmfsc(V, K, dict(cfg, nmfx_gpus=[0, 7]))                             # no such device on a 1-GPU box
+
+
+@pytest.mark.parametrize("alg,div", [("cnmf", "kl"), ("cnmf", "euclidean"), ("nmf", "kl"), ("nmf", "euclidean")])
+def test_blocking_api_n_gpus_one_short_shard(gpu_lib, alg, div):
+    """n = 319 on 5 shards: 64, 64, 64, 64 and 63 columns -- the last one is below what the fused kernels take.  Every shard must then run the same (general)
+    kernels: the packed layout and the W update's summation order depend on the path (found by scripts/fuzz_campaign_r3.py: 'shards picked different kernel
+    paths')."""
+    from oracle import nmf_oracle as O
+    m, n, K, T = 128, 319, 32, 4
+    V, W0, H0 = synth(m, n, K, T=T if alg == "cnmf" else None)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12)
+    if alg == "cnmf":
+        ref, got = O.cnmf(V, K, T, cfg), gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_gpus=[0] * 5))
+    else:
+        ref, got = O.nmf(V, K, cfg), gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0] * 5))
+    assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
