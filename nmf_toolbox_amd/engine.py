@@ -193,6 +193,13 @@ class Engine:
         d.algorithm = {"nmf": 0, "cnmf": 1, "lnmf": 2}[algorithm]
         self.stop_le = algorithm == "lnmf"                 # lnmf.m:84
         d.path = int(path)
+        if self.dist is not None and d.path == 0:
+            # every rank must run the same kernels (the packed layout and the summation order of the replicated W update depend on them): the fused paths
+            # want at least 64 local columns, so one short shard sends all ranks to the general kernels (as the blocking multi-GPU call does)
+            nmin = torch.tensor([float(self.n)], dtype=torch.float64, device=self.V.device)
+            self.dist.all_reduce(nmin, op=self.dist.ReduceOp.MIN, group=group)
+            if float(nmin.item()) < 64:
+                d.path = 1
         d.halo_left, d.halo_right = self.hL, self.hR
         d.n_valid = int(n_valid) if n_valid is not None else self.n + self.hR
         self.desc = d
