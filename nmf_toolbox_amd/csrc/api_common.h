@@ -206,6 +206,13 @@ void host_minmax(const void *host, int dtype, size_t count, double *vmin, double
 struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0; };
 IoStats &io_stats();
 nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true);
+// Streams and events of the single-process multi-GPU drivers come out of a process-wide pool and go back to it, never destroyed: a MATLAB session calls
+// nmf() many times, and creating / destroying 8 streams + 32 events per call at a high call rate is what a rare host-heap corruption inside the runtime's
+// teardown went with (scripts/fuzz_campaign_r3.py multi_edge).  Callers drain a stream before they hand it back.
+nmfx_status pool_stream(int device, hipStream_t *st);
+nmfx_status pool_event(int device, hipEvent_t *ev);
+void unpool_stream(int device, hipStream_t st);
+void unpool_event(int device, hipEvent_t ev);
 nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r);   // multi_sc.hip
 void sc_thread_cleanup();                                              // sc.hip
 

@@ -206,6 +206,14 @@ struct MultiDev {
     DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
     long lo[NMFX_MAX_GPUS + 1];
     long hL[NMFX_MAX_GPUS] = {}, hR[NMFX_MAX_GPUS] = {};   // cnmf: T-1 halo columns of H on each inner edge (and of V on the right one)
+    // host side of the small device <-> host scalars (per-shard cost partials, ||V||^2): pinned.  They used to be async copies into a std::vector / the
+    // stack; a rare host-heap corruption ("free(): invalid pointer", scripts/fuzz_campaign_r3.py multi_edge, only with the NumPy oracle's threads alive in
+    // the same process) went away with them -- asynchronous copies into a few bytes of pageable heap are staged by the runtime
+    double *hpin = nullptr;
+    nmfx_status init_host() {
+        if (!hpin) NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&hpin), sizeof(double) * (NMFX_MAX_GPUS + 2), hipHostMallocPortable));
+        return NMFX_OK;
+    }
     ~MultiDev() {
         for (int g = 0; g < ndev; ++g) {   // an error path may leave work in flight that reads the peers' buffers: drain every stream before anything is freed
             (void)hipSetDevice(dev[g]);
@@ -214,12 +222,10 @@ struct MultiDev {
         for (int g = 0; g < ndev; ++g) {
             (void)hipSetDevice(dev[g]);
             if (eng[g]) nmfx_engine_destroy(eng[g]);
-            if (evP[g]) (void)hipEventDestroy(evP[g]);
-            if (evR[g]) (void)hipEventDestroy(evR[g]);
-            if (evG[g]) (void)hipEventDestroy(evG[g]);
-            if (evH[g]) (void)hipEventDestroy(evH[g]);
-            if (st[g]) (void)hipStreamDestroy(st[g]);
+            unpool_event(dev[g], evP[g]); unpool_event(dev[g], evR[g]); unpool_event(dev[g], evG[g]); unpool_event(dev[g], evH[g]);
+            unpool_stream(dev[g], st[g]);   // (drained above)
         }
+        if (hpin) (void)hipHostFree(hpin);
     }
 };
 
@@ -290,6 +296,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     if (hh > 0 && p->n / N < hh) { set_error("cnmf on %d devices: every shard needs at least T-1 = %d columns", N, hh); return NMFX_ERR_INVALID; }
     DeviceGuard dg_;
     MultiDev M;
+    TRY(M.init_host());
     for (int g = 0; g < N; ++g) {
         M.dev[g] = p->device_ids ? p->device_ids[g] : g;
         TRY(check_device(M.dev[g]));
@@ -327,11 +334,8 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         M.ndev = g + 1;
-        NMFX_HIP(hipStreamCreateWithFlags(&M.st[g], hipStreamNonBlocking));
-        NMFX_HIP(hipEventCreateWithFlags(&M.evP[g], hipEventDisableTiming));
-        NMFX_HIP(hipEventCreateWithFlags(&M.evR[g], hipEventDisableTiming));
-        NMFX_HIP(hipEventCreateWithFlags(&M.evG[g], hipEventDisableTiming));
-        NMFX_HIP(hipEventCreateWithFlags(&M.evH[g], hipEventDisableTiming));
+        TRY(pool_stream(M.dev[g], &M.st[g]));
+        TRY(pool_event(M.dev[g], &M.evP[g])); TRY(pool_event(M.dev[g], &M.evR[g])); TRY(pool_event(M.dev[g], &M.evG[g])); TRY(pool_event(M.dev[g], &M.evH[g]));
         const long nl = M.lo[g + 1] - M.lo[g];
         const long hL = M.hL[g] = g > 0 ? hh : 0, hR = M.hR[g] = g < N - 1 ? hh : 0;   // H = [left halo | own columns | right halo], V = [own | right halo]
         nmfx_engine_desc d{};
@@ -370,7 +374,8 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     const int lagk = nmfx_engine_cost_lag(M.eng[0]);   // 1: cost(it-1) after wstep_partial(it); 2: after wstep_finish(it) (Gram-form cost); 0: cost(it) after hstep(it)
     const bool lag = lagk != 0;
     {   // Gram-form cost: every shard's mode decision uses the GLOBAL ||V||^2
-        double vv = 0.0, part = 0.0;
+        double vv = 0.0;
+        double &part = M.hpin[NMFX_MAX_GPUS], &vvp = M.hpin[NMFX_MAX_GPUS + 1];
         for (int g = 0; g < N; ++g) {
             NMFX_HIP(hipSetDevice(M.dev[g]));
             TRY(nmfx_engine_sumvv_local(M.eng[g], M.costh[g].as<double>()));
@@ -380,14 +385,15 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         }
         for (int g = 0; g < N; ++g) {
             NMFX_HIP(hipSetDevice(M.dev[g]));
-            NMFX_HIP(hipMemcpyAsync(M.costh[g].p, &vv, sizeof(double), hipMemcpyHostToDevice, M.st[g]));
+            vvp = vv;
+            NMFX_HIP(hipMemcpyAsync(M.costh[g].p, &vvp, sizeof(double), hipMemcpyHostToDevice, M.st[g]));
             TRY(nmfx_engine_sumvv_set_global(M.eng[g], M.costh[g].as<double>()));
             NMFX_HIP(hipStreamSynchronize(M.st[g]));   // vv is a stack variable
         }
     }
     DevBuf Wbak;   // Gram-form cost + stop rule: device 0's W as it was before the update that produced cost(it-1)
     if (lagk == 2 && p->tolerance >= 0) { NMFX_HIP(hipSetDevice(M.dev[0])); TRY(Wbak.alloc(mK * 4)); }
-    std::vector<double> hc(N);
+    double *hc = M.hpin;   // pinned: the 8-byte read-backs land by DMA, not through the runtime's staging of pageable memory (see MultiDev::hpin)
     auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
         for (int g = 0; g < N; ++g) {
             NMFX_HIP(hipSetDevice(M.dev[g]));

@@ -102,7 +102,45 @@ void widen(const float *src, int dtype, void *dst, size_t off, size_t n) {
 
 thread_local IoStats g_io;
 
+struct ResPool {
+    std::mutex mu;
+    std::vector<hipStream_t> st[NMFX_MAX_GPUS];
+    std::vector<hipEvent_t> ev[NMFX_MAX_GPUS];
+};
+ResPool g_res;
+
 }  // namespace
+
+nmfx_status pool_stream(int device, hipStream_t *st) {
+    if (device < 0 || device >= NMFX_MAX_GPUS) { set_error("pool_stream: device %d out of range", device); return NMFX_ERR_INVALID; }
+    {
+        std::lock_guard<std::mutex> lk(g_res.mu);
+        if (!g_res.st[device].empty()) { *st = g_res.st[device].back(); g_res.st[device].pop_back(); return NMFX_OK; }
+    }
+    NMFX_HIP(hipSetDevice(device));
+    NMFX_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    return NMFX_OK;
+}
+nmfx_status pool_event(int device, hipEvent_t *ev) {
+    if (device < 0 || device >= NMFX_MAX_GPUS) { set_error("pool_event: device %d out of range", device); return NMFX_ERR_INVALID; }
+    {
+        std::lock_guard<std::mutex> lk(g_res.mu);
+        if (!g_res.ev[device].empty()) { *ev = g_res.ev[device].back(); g_res.ev[device].pop_back(); return NMFX_OK; }
+    }
+    NMFX_HIP(hipSetDevice(device));
+    NMFX_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return NMFX_OK;
+}
+void unpool_stream(int device, hipStream_t st) {
+    if (!st || device < 0 || device >= NMFX_MAX_GPUS) return;
+    std::lock_guard<std::mutex> lk(g_res.mu);
+    g_res.st[device].push_back(st);
+}
+void unpool_event(int device, hipEvent_t ev) {
+    if (!ev || device < 0 || device >= NMFX_MAX_GPUS) return;
+    std::lock_guard<std::mutex> lk(g_res.mu);
+    g_res.ev[device].push_back(ev);
+}
 
 IoStats &io_stats() { return g_io; }
 

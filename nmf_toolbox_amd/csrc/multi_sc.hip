@@ -126,10 +126,8 @@ struct ScMulti {
         }
         for (int g = 0; g < C.N; ++g) {
             (void)hipSetDevice(C.dev[g]);
-            if (C.evA[g]) (void)hipEventDestroy(C.evA[g]);
-            if (C.evB[g]) (void)hipEventDestroy(C.evB[g]);
-            if (C.evC[g]) (void)hipEventDestroy(C.evC[g]);
-            if (C.st[g]) (void)hipStreamDestroy(C.st[g]);
+            unpool_event(C.dev[g], C.evA[g]); unpool_event(C.dev[g], C.evB[g]); unpool_event(C.dev[g], C.evC[g]);
+            unpool_stream(C.dev[g], C.st[g]);   // (drained above)
         }
     }
 };
@@ -173,10 +171,8 @@ nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r) {
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(C.dev[g]));
         C.N = g + 1;
-        NMFX_HIP(hipStreamCreateWithFlags(&C.st[g], hipStreamNonBlocking));
-        NMFX_HIP(hipEventCreateWithFlags(&C.evA[g], hipEventDisableTiming));
-        NMFX_HIP(hipEventCreateWithFlags(&C.evB[g], hipEventDisableTiming));
-        NMFX_HIP(hipEventCreateWithFlags(&C.evC[g], hipEventDisableTiming));
+        TRY(pool_stream(C.dev[g], &C.st[g]));
+        TRY(pool_event(C.dev[g], &C.evA[g])); TRY(pool_event(C.dev[g], &C.evB[g])); TRY(pool_event(C.dev[g], &C.evC[g]));
         const long nl = lo[g + 1] - lo[g];
         TRY(M.V[g].alloc((size_t)m * nl * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nl * 4)); TRY(M.tmp[g].alloc(SMALL_BYTES));
         C.tmp[g] = M.tmp[g].p;

@@ -1,7 +1,7 @@
 """One-off fuzz campaign for the paths that are new in round 3 (not part of the suite): KL with K > 256 in column blocks (one GPU and column shards, nmf /
 lnmf, sources, sparsity, fixed flags), cnmf / nmfsc / nmf on N shards behind the blocking call, cnmfsc on the fused passes, the Gram-form cost of the
 euclidean fused paths over residual levels -- against the float64 oracle.   scripts/fuzz_campaign_r3.py <seed> <seconds>"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from conftest import synth, rel_fro
@@ -10,11 +10,12 @@ from oracle import nmf_oracle as O
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
 rs = np.random.RandomState(seed)
+KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["klw", "klw", "eucw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost", "cnmf_pad", "is_wide", "multi_edge"]
 PAIRS = [(64, 8), (64, 4), (64, 2), (32, 4), (32, 8), (32, 16), (128, 2), (128, 4)]
 t0 = time.time(); counts = {}; worst = dict(W=0.0, H=0.0, cost=0.0); bad = []
 cat = lambda x: np.concatenate([np.asarray(a).reshape(-1) for a in x]) if isinstance(x, (list, tuple)) else np.asarray(x).reshape(-1)
 while time.time() - t0 < budget:
-    kind = str(rs.choice(["klw", "klw", "eucw", "multi_cnmf", "multi_nmfsc", "multi_nmf", "cnmfsc", "gramcost", "cnmf_pad", "is_wide"]))
+    kind = str(rs.choice(KINDS))
     tries_ok = True
     if kind == "klw":
         K = int(rs.choice([257, 288, 300, 320, 384, 400, 448, 512, 520, 640]))
@@ -75,6 +76,33 @@ while time.time() - t0 < budget:
         if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.05), float(rs.rand() * 0.05)
         ref = O.nmf(V, K, cfg); got = A.nmf(V, K, cfg)
         tag = (kind, m, n, K, div, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
+    elif kind == "multi_edge":   # the blocking multi-GPU call on awkward geometry: tiny and uneven shards, ragged m, any K, nmf / cnmf / lnmf
+        N = int(rs.randint(2, 9))
+        alg = str(rs.choice(["nmf", "cnmf", "lnmf"]))
+        T = int(rs.randint(2, 6)) if alg == "cnmf" else 1
+        m = int(rs.randint(8, 300))
+        n = int(rs.randint(N * max(T, 2), 700))
+        K = int(rs.randint(2, 70))
+        div = "kl" if alg == "lnmf" else str(rs.choice(["euclidean", "kl", "is"] if alg == "nmf" else ["euclidean", "kl"]))
+        V, W0, H0 = synth(m, n, K, T=(T if alg == "cnmf" else None))
+        it = int(rs.randint(1, 7))
+        if os.environ.get("NMFX_FUZZ_VERBOSE"): print("case", alg, m, n, K, T, div, N, it, flush=True)
+        skip = os.environ.get("NMFX_FUZZ_SKIP", "")      # repro aid: "gpu" runs the oracle alone, "oracle" the library alone
+        if alg == "cnmf":
+            cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=it, tolerance=1e-300)
+            ref = O.cnmf(V, K, T, cfg) if skip != "oracle" else None
+            got = A.cnmf(V, K, T, dict(cfg, nmfx_gpus=[0] * N)) if skip != "gpu" else ref
+        elif alg == "lnmf":
+            cfg = dict(W_init=W0 / W0.sum(0), H_init=H0, maxiter=it, tolerance=1e-300)
+            ref = O.lnmf(V, K, cfg) if skip != "oracle" else None
+            got = A.lnmf(V, K, dict(cfg, nmfx_gpus=[0] * N)) if skip != "gpu" else ref
+        else:
+            cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=it, tolerance=1e-300)
+            if rs.rand() < 0.4: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.1), float(rs.rand() * 0.1)
+            ref = O.nmf(V, K, cfg) if skip != "oracle" else None
+            got = A.nmf(V, K, dict(cfg, nmfx_gpus=[0] * N)) if skip != "gpu" else ref
+        if ref is None: ref = got
+        tag = (kind, alg, m, n, K, T, div, N, it)
     elif kind == "multi_cnmf":
         K, T = PAIRS[rs.randint(len(PAIRS))] if rs.rand() < 0.7 else (int(rs.randint(3, 20)), int(rs.randint(2, 6)))
         N = int(rs.randint(2, 6))
@@ -137,7 +165,7 @@ while time.time() - t0 < budget:
     fin = same_len and np.all(np.isfinite(ref[2])) and np.linalg.norm(ref[2]) > 0
     e = dict(W=rel_fro(cat(got[0]), cat(ref[0])), H=rel_fro(cat(got[1]), cat(ref[1])), cost=(rel_fro(got[2], ref[2]) if fin else (0.0 if same_len else 1.0)))
     for k in worst: worst[k] = max(worst[k], e[k])
-    lim_c = 1e-5 if ((kind == "multi_nmf" and tag[4] == "is") or kind == "is_wide") else 1e-6
+    lim_c = 1e-5 if ((kind == "multi_nmf" and tag[4] == "is") or kind == "is_wide" or (kind == "multi_edge" and tag[6] == "is")) else 1e-6
     if not (e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= lim_c and tries_ok):
         bad.append((tag, e, tries_ok)); print("BAD", tag, e, "tries_ok", tries_ok, flush=True)
 print("seed", seed, "cases", counts, "worst", worst, "bad", len(bad))
