@@ -329,22 +329,24 @@ def test_cnmf_shards_with_halos_equal_oracle(gpu_lib, div, nshards, m, n, K, T):
     assert rel_fro(Wg.reshape(W.shape), W) < 1e-5 and rel_fro(Hg, H) < 1e-5 and rel_fro(np.array(costs), c0) < 1e-6
 
 
-def _cnmf_dist_worker(rank, world, port, q):
+def _cnmf_dist_worker(rank, world, port, q, K=8, T=5, div="kl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nmf_toolbox_amd.engine import Engine, colmajor_to_torch, shard_columns, torch_to_colmajor
-    m, n, K, T = 128, 333, 8, 5
+    m, n = 128, 333
     V, W0, H0 = synth(m, n, K, T=T)
     lo, hi = shard_columns(n, world, rank)
     h = T - 1
     hL, hR = (h if rank > 0 else 0), (h if rank < world - 1 else 0)
     dev = "cuda:0"
     e = Engine(colmajor_to_torch(V[:, lo:hi + hR], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo - hL:hi + hR], dev),
-               divergence="kl", T=T, algorithm="cnmf", halo=(hL, hR))
+               divergence=div, T=T, algorithm="cnmf", halo=(hL, hR))
     assert e.dist is not None and e.has_halos
+    if K % 32 == 0:       # an instantiated pair: the fused passes on both shards; with KL the cost lags one pass (out of the next S pass)
+        assert e.path_kind == (4 if div == "kl" else 3) and e.cost_lag == (1 if div == "kl" else 0)
     e.init()
     cost = torch.zeros(8, dtype=torch.float64, device=dev)
     e.iterate(8, cost)
@@ -354,23 +356,25 @@ def _cnmf_dist_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_cnmf_distributed_halo_exchange_two_processes(gpu_lib):
-    """the real point-to-point halo exchange (torch.distributed batch_isend_irecv), two processes on cuda:0 over gloo"""
+@pytest.mark.parametrize("K,T,div", [(8, 5, "kl"), (32, 4, "kl"), (64, 2, "euclidean")])
+def test_cnmf_distributed_halo_exchange_two_processes(gpu_lib, K, T, div):
+    """the real point-to-point halo exchange (torch.distributed batch_isend_irecv), two processes on cuda:0 over gloo -- on the general kernels (K = 8) and on
+    the fused shift-sum passes, where KL brings a lagged cost through run_sharded_iterations together with the halos"""
     import torch.multiprocessing as mp
     from oracle import nmf_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cnmf_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_cnmf_dist_worker, args=(r, 2, port, q, K, T, div)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    m, n, K, T = 128, 333, 8, 5
+    m, n = 128, 333
     V, W0, H0 = synth(m, n, K, T=T)
-    W, H, c0 = O.cnmf(V, K, T, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=8, tolerance=1e-300))
+    W, H, c0 = O.cnmf(V, K, T, dict(divergence=div, W_init=W0, H_init=H0, maxiter=8, tolerance=1e-300))
     assert np.array_equal(res[0][1], res[1][1])
     assert rel_fro(res[0][1].reshape(W.shape), W) < 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) < 1e-5
     assert rel_fro(res[0][3], c0) < 1e-6 and rel_fro(res[1][3], c0) < 1e-6
