@@ -192,20 +192,20 @@ def _free_port():
     return p
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, K=64, div="kl", n_chunks=2, kind=1, lag=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nmf_toolbox_amd.engine import Engine, colmajor_to_torch, shard_columns, torch_to_colmajor
-    m, n, K = 256, 1024, 64
+    m, n = 256, 1024
     V, W0, H0 = synth(m, n, K)
     lo, hi = shard_columns(n, world, rank)
     dev = "cuda:0"
-    e = Engine(colmajor_to_torch(V[:, lo:hi], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo:hi], dev), divergence="kl",
-               n_chunks=2)                          # also exercises the row-chunked, async all-reduce form of the W step
-    assert e.dist is not None and e.rank == rank and e.n_chunks == 2
+    e = Engine(colmajor_to_torch(V[:, lo:hi], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo:hi], dev), divergence=div,
+               n_chunks=n_chunks)                   # (2: also exercises the row-chunked, async all-reduce form of the W step)
+    assert e.dist is not None and e.rank == rank and e.n_chunks == n_chunks and e.path_kind == kind and e.cost_lag == lag
     e.init()
     cost = torch.zeros(10, dtype=torch.float64, device=dev)
     e.iterate(10, cost)
@@ -215,22 +215,25 @@ def _dist_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_torch_distributed_loop_two_processes(gpu_lib):
+@pytest.mark.parametrize("K,div,n_chunks,kind,lag", [(64, "kl", 2, 1, 1), (64, "euclidean", 1, 1, 2), (320, "kl", 1, 5, 1), (320, "euclidean", 1, 6, 2)])
+def test_torch_distributed_loop_two_processes(gpu_lib, K, div, n_chunks, kind, lag):
+    """run_sharded_iterations with real processes (gloo, both on cuda:0): the fused KL kernels with row chunks, the euclidean fused path with its Gram-form cost
+    (lag 2, the global ||V||^2 all-reduced at init), and K > 256 in column blocks for both divergences (paths 5 and 6)"""
     import torch.multiprocessing as mp
     from oracle import nmf_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, K, div, n_chunks, kind, lag)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    m, n, K = 256, 1024, 64
+    m, n = 256, 1024
     V, W0, H0 = synth(m, n, K)
-    W, H, c0 = O.nmf(V, K, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=10, tolerance=1e-300))
+    W, H, c0 = O.nmf(V, K, dict(divergence=div, W_init=W0, H_init=H0, maxiter=10, tolerance=1e-300))
     assert np.array_equal(res[0][1], res[1][1])
     assert rel_fro(res[0][1], W) < 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) < 1e-5
     assert rel_fro(res[0][3], c0) < 1e-6 and rel_fro(res[1][3], c0) < 1e-6
