@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|tiny] [--overlap 0|2|4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(a plain `python bench.py --gpus N` with N > 1 starts that second command itself: self_launch)
 
 A "step" is one full multiplicative-update iteration (W step, H step, V_hat refresh, cost) on synthetic V
 that is already resident in HBM.  Default workload = the configuration the metric is quoted on
@@ -296,6 +297,25 @@ def bench_blocking(args):
     print(json.dumps(out), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside any launcher: re-run this very command line under torch.distributed.run with N ranks on
+    127.0.0.1 and a free port, pass rank 0's JSON line through (the children inherit stdout), and return their exit status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")                # torchrun would set 1 (and print a banner about it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,9 +344,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's torchrun command would
+        return self_launch(args.gpus)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        # a launcher's WORLD_SIZE is what actually runs; say so instead of dying on the first contact with a multi-GPU node
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: using the launcher's world size" % (args.gpus, world), file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # dev aid for 1-GPU boxes: NMFX_BENCH_BACKEND=gloo NMFX_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 over gloo (RCCL refuses

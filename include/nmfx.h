@@ -256,7 +256,10 @@ nmfx_status nmfx_engine_set_rank0(nmfx_engine *e, int32_t is_rank0);
 /* Where the cost of iteration i becomes available: 0 after hstep(i); 1 after wstep_partial(i+1) (fused KL passes: a by-product of the next
  * W-step pass); 2 after wstep_finish(i+1) (euclidean fused path: the cost in Gram form, 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')>, out of the
  * column sums the W update forms anyway -- nmf.m:149-150's diagonal terms -- so the W-step pass needs no W*H product; when the residual gets too
- * small for fp32 to resolve that difference (cost < 5 % of 0.5*||V||^2) a device-side flag switches the explicit residual pass back on). */
+ * small for fp32 to resolve that difference (cost < 5 % of 0.5*||V||^2) a device-side flag switches the explicit residual pass back on).
+ * An engine of lag 2 may, from some iteration on, deliver the cost at point 1 already (it goes back to the one-pass kernel two W updates after the flag
+ * was set -- a fixed distance, so the switch falls on the same iteration on every rank and in every run); nmfx_engine_cost_lag keeps returning 2 and
+ * reading at point 2 -- after wstep_finish(i+1), BEFORE the next wstep_partial -- is right in both regimes. */
 int32_t nmfx_engine_cost_lag(nmfx_engine *e);
 /* Column shards + Gram-form cost: the mode decision needs the GLOBAL ||V||^2 and must be identical on every rank.  After nmfx_engine_init,
  * nmfx_engine_sumvv_local copies this shard's ||V_local||^2 (fp64) to dst_dev (0.0 when the engine has no such mode); the caller sums it over the
@@ -269,6 +272,9 @@ nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *segments_h
 /* column shards without halos: everything between two all-reduces of `packed` in one call -- wstep_finish, hstep and, unless
  * `last`, the next iteration's wstep_partial (one host call per iteration next to the collective) */
 nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last);
+/* the same with the read point of a lag-2 engine inside: right after its wstep_finish the cost of the previous iteration is copied (8 bytes, device to
+ * device, on the engine's stream) to lag2_cost_dst_dev when that is not NULL -- the wstep_partial that follows may overwrite the engine's cost */
+nmfx_status nmfx_engine_between_allreduces_cost(nmfx_engine *e, int32_t last, double *lag2_cost_dst_dev);
 /* convenience for one GPU: `iters` full iterations, costs written to the DEVICE array dev_cost_out[iters] (may be NULL) */
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "nmfx_engine_iterate", "nmfx_engine_profile", "nmfx_engine_profile_ntags", "nmfx_engine_profile_tag_name",
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
-    "nmfx_engine_between_allreduces", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing", "nmfx_sc_iteration_seconds", "nmfx_engine_cost_lag", "nmfx_engine_sumvv_local", "nmfx_engine_sumvv_set_global",
+    "nmfx_engine_between_allreduces", "nmfx_engine_between_allreduces_cost", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing", "nmfx_sc_iteration_seconds", "nmfx_engine_cost_lag", "nmfx_engine_sumvv_local", "nmfx_engine_sumvv_set_global",
 ]
 
 
@@ -112,6 +112,7 @@ def load():
     for name in ("nmfx_engine_init", "nmfx_engine_wstep_partial", "nmfx_engine_wstep_finish", "nmfx_engine_hstep", "nmfx_engine_cost_pass"):
         getattr(lib, name).argtypes = [C.c_void_p]
     lib.nmfx_engine_between_allreduces.argtypes = [C.c_void_p, C.c_int32]
+    lib.nmfx_engine_between_allreduces_cost.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.nmfx_engine_wstep_partial_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.nmfx_engine_packed_chunk.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.nmfx_engine_cost_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

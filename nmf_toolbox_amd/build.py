@@ -42,17 +42,23 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, sanitize: bool = False) -> str:
+    """sanitize: the HOST pass of every translation unit with -fsanitize=address,undefined (device code objects unchanged: GPU ASan is not available on
+    this pool) into libnmfx_asan.so + the campaign driver tests/host_asan/fuzz_multi -- test infrastructure, never loaded by the package"""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INC, "nmfx.h"), os.path.abspath(__file__)]   # + this file: the flags live here
-    objdir = os.path.join(CSRC, "_obj")
+    objdir = os.path.join(CSRC, "_obj_asan" if sanitize else "_obj")
+    out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else OUT
+    # (-g / -fno-omit-frame-pointer for the HOST pass only: handed to the device pass as well they change the gfx950 code objects -- frame pointer, CFI spills --
+    # and the register-stationary kernels then return garbage: measured, profiles/r4_01_host_asan.md)
+    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-Xarch_host", "-g", "-Xarch_host", "-fno-omit-frame-pointer"] if sanitize else []
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _newer([src] + hdrs, obj):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed",
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed"] + san + [
                    "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if os.path.basename(src).startswith("fused_"):
                 # the biggest tile bodies (K = Kh*T = 512: 512 MFMAs; the dual-map kernels at K = 96 / 128) are past clang's default
@@ -66,18 +72,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), 8)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    if force or _newer(objs, OUT):
+    if force or _newer(objs, out):
         tl = _torch_lib_dir()
         libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
-        cmd = ["g++", "-shared", "-o", OUT] + objs
+        if sanitize:   # clang links the sanitizer runtimes into the EXECUTABLE; the shared object keeps its references to them undefined
+            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fsanitize=address,undefined", "-o", out] + objs
+        else:
+            cmd = ["g++", "-shared", "-o", out] + objs
         for d in libdirs:
             cmd += ["-L" + d]
-        cmd += ["-lamdhip64", "-Wl,-rpath," + ":".join(libdirs), "-Wl,--no-undefined", "-lstdc++", "-lm"]
+        cmd += ["-lamdhip64", "-Wl,-rpath," + ":".join(libdirs)] + ([] if sanitize else ["-Wl,--no-undefined"]) + ["-lstdc++", "-lm"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    if sanitize:
+        drv_src = os.path.join(os.path.dirname(HERE), "tests", "host_asan", "fuzz_multi.cpp")
+        drv = os.path.join(os.path.dirname(drv_src), "fuzz_multi")
+        if force or _newer([drv_src, out], drv):
+            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", INC, drv_src, "-o", drv,
+                   "-L" + HERE, "-lnmfx_asan", "-Wl,-rpath," + HERE + ":" + ":".join(([_torch_lib_dir()] if _torch_lib_dir() else []) + ["/opt/rocm/lib"]), "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, sanitize="--sanitize" in sys.argv))

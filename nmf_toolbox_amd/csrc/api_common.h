@@ -170,12 +170,13 @@ struct nmfx_engine {
     // turns the explicit residual pass back on (conditional launch) -- deterministic, no host round trip, identical on every rank.
     bool gram_cost;           // the engine can run in this mode (euclidean, fused, W not all fixed)
     bool wstep_gram;          // the W step in flight runs in this mode (set by wstep_partial, read by wstep_finish)
-    bool classic;             // host-side latch: the flag has been seen set (or the caller chunks the W step): the one-pass kernel with the cost inside again
+    bool classic;             // host-side latch: the decision of two W updates ago had the flag set (or the caller chunks the W step): the one-pass kernel with the cost inside again
+    unsigned decide_seq;      // gram_decide launches since init: decision s publishes (s+1) << 1 | flag into exact_flag_host[s & 7]
     bool dist_seen, sumvv_global_set;   // column shards: the decision needs the GLOBAL ||V||^2 (nmfx_engine_sumvv_ptr); without it the mode stays off
     double *sumVV;            // device [2]: ||V_local||^2, ||V_global||^2
     double *dndp;             // device [2*K]: column sums dn = cs(W.*P), dp = cs(W.*N) of the last W update
     int *exact_flag;          // device
-    int *exact_flag_host;     // host-mapped mirror (owned: hipHostMalloc)
+    int *exact_flag_host;     // host-mapped, 16 ints (owned: hipHostMalloc): slots [0, 8) receive the stamped decisions
     // constrainednmf (algo 3): H = Z*A with A the 0/1 label matrix of label-sorted samples; segment c = columns [seg[c], seg[c+1])
     float *Z;
     long nz;
@@ -187,7 +188,8 @@ namespace nmfx {
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } }
     nmfx_status alloc(size_t bytes) {
         hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
         if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); p = nullptr; return NMFX_ERR_NOMEM; }

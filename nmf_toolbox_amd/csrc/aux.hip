@@ -494,22 +494,25 @@ nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
 }
 
 // ---- euclidean cost in Gram form -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gram_decide_kernel(const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag) {
+__global__ __launch_bounds__(256) void gram_decide_kernel(const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_slot, int stamp) {
     __shared__ double red[4];
     double sn = 0.0, sp = 0.0;
     for (int c = threadIdx.x; c < nc; c += 256) { sn += dndp[c]; sp += dndp[nc + c]; }
     sn = block_sum<4>(sn, red);
     sp = block_sum<4>(sp, red);
-    if (threadIdx.x == 0 && *exact_flag == 0) {
-        const double half_vv = 0.5 * sumVV[1], data = half_vv - sp + 0.5 * sn;
-        if (!(data >= ratio_min * half_vv)) {   // (NaN lands here too)
-            *exact_flag = 1;
-            if (host_flag) __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        int flag = *exact_flag;
+        if (flag == 0) {
+            const double half_vv = 0.5 * sumVV[1], data = half_vv - sp + 0.5 * sn;
+            if (!(data >= ratio_min * half_vv)) { flag = 1; *exact_flag = 1; }   // (NaN lands here too)
         }
+        // the state of the flag AFTER decision number `stamp`, for the host: it latches on the decision of a fixed, earlier W update (engine.hip::gram_active),
+        // never on "whatever the flag happens to be when the host looks"
+        if (host_slot) __hip_atomic_store(host_slot, (stamp << 1) | flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag) {
-    hipLaunchKernelGGL(gram_decide_kernel, dim3(1), dim3(256), 0, st, dndp, nc, sumVV, ratio_min, exact_flag, host_flag);
+nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_slot, int stamp) {
+    hipLaunchKernelGGL(gram_decide_kernel, dim3(1), dim3(256), 0, st, dndp, nc, sumVV, ratio_min, exact_flag, host_slot, stamp);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -65,8 +65,15 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     TRY(nmfx_engine_workspace_bytes(&d, &ws_bytes));
     TRY(nmfx_engine_packed_count(&d, &packed_count));
     const size_t mn = (size_t)p->m * p->n, mKT = (size_t)p->m * K * p->T, Kn = (size_t)K * p->n;
-    DevBuf V, W, H, Z, ws, packed;
+    DevBuf V, W, H, Z, ws, packed, Wbak, dcost, tmp;   // (tmp: K x cols staging of the un-padded row-interleaved arrays H, Z)
     TRY(V.alloc(mn * 4)); TRY(W.alloc(mKT * 4)); TRY(H.alloc(Kn * 4)); TRY(packed.alloc(packed_count * 4));
+    // everything else this call will ever allocate comes BEFORE the workspace: a workspace that only just fits must not starve them afterwards (the retry below
+    // is for the workspace alone)
+    const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
+    if (p->tolerance < 0) TRY(dcost.alloc(sizeof(double) * p->maxiter));
+    else if (dv == NMFX_DIV_EUCLIDEAN || dv == NMFX_DIV_EUCLIDEAN_NOCOST) TRY(Wbak.alloc(mKT * 4));   // engines of cost lag 2 (known for sure only once the engine exists)
+    if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
+    if (algorithm == 3) TRY(Z.alloc((size_t)K * nz * 4));
     if (ws.alloc(ws_bytes) != NMFX_OK) {   // no room for the workspace with the transposed copy of V: the same problem without it (said in the descriptor, not guessed)
         (void)hipGetLastError();
         d.flags |= 1;
@@ -78,9 +85,6 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     io = IoStats{};
     const auto t0 = std::chrono::steady_clock::now();
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, 1.0));
-    const size_t mKt = (size_t)p->m * Kt * p->T, Ktn = (size_t)Kt * p->n;
-    DevBuf tmp;   // K x cols staging of the un-padded row-interleaved arrays (H, Z)
-    if (pad) TRY(tmp.alloc(std::max(Ktn, (size_t)Kt * (size_t)(algorithm == 3 ? nz : 0)) * 4));
     if (pad && p->T > 1) {   // cnmf: every time slice m x K of W is padded on its own
         const size_t sl = (size_t)p->m * Kt, slp = (size_t)p->m * K;
         NMFX_HIP(hipMemsetAsync(W.as<float>(), 0, mKT * 4, st));
@@ -95,14 +99,21 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
             TRY(repack_rows(st, tmp.as<float>(), Kt, H.as<float>(), K, p->n));
         } else TRY(upload(st, p->H_init, p->dtype, H.as<float>(), Kn, 1.0));
     } else {   // H = Z*A is formed on the device by nmfx_engine_init (constrainednmf.m:174-177)
-        TRY(Z.alloc((size_t)K * nz * 4));
         if (pad) {
             TRY(upload(st, Z_init, p->dtype, tmp.as<float>(), (size_t)Kt * nz, 1.0));
             TRY(repack_rows(st, tmp.as<float>(), Kt, Z.as<float>(), K, nz));
         } else TRY(upload(st, Z_init, p->dtype, Z.as<float>(), (size_t)K * nz, 1.0));
     }
+    // (declared after the buffers: on every return path the stream is drained and the engine destroyed BEFORE the buffers its kernels use are freed)
+    struct EngineOwner {
+        nmfx_engine *e = nullptr;
+        hipStream_t st = nullptr;
+        ~EngineOwner() { if (e) { (void)hipStreamSynchronize(st); nmfx_engine_destroy(e); } }
+    } own;
+    own.st = st;
     nmfx_engine *e = nullptr;
     TRY(nmfx_engine_create(&d, V.as<float>(), W.as<float>(), H.as<float>(), ws.p, ws_bytes, packed.as<float>(), &e));
+    own.e = e;
     nmfx_status s = algorithm == 3 ? nmfx_engine_set_constraint(e, seg, nz, Z.as<float>()) : NMFX_OK;
     NMFX_HIP(hipStreamSynchronize(st));   // (nmfx_engine_create has drained the stream already: this only closes the ingest clock)
     const auto t1 = std::chrono::steady_clock::now();
@@ -124,18 +135,16 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     bool stopped = false;
     const int lagk = e ? nmfx_engine_cost_lag(e) : 0;   // where cost(it-1) turns up: 1 after wstep_partial(it), 2 after wstep_finish(it), 0: cost(it) after hstep(it)
     const bool lag = lagk != 0;
-    DevBuf Wbak, dcost;
     if (s == NMFX_OK && p->tolerance < 0) {
         // stop rule disabled (NMFX extension): nothing is decided on the host, so nothing is read back per iteration -- the costs land in a device
         // vector and come home once
-        s = dcost.alloc(sizeof(double) * p->maxiter);
-        if (s == NMFX_OK) s = nmfx_engine_iterate(e, p->maxiter, dcost.as<double>());
+        s = nmfx_engine_iterate(e, p->maxiter, dcost.as<double>());
         if (s == NMFX_OK && hipMemcpy(r->cost, dcost.p, sizeof(double) * p->maxiter, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cost readback failed"); s = NMFX_ERR_HIP; }
         if (s == NMFX_OK) r->iters_run = p->maxiter;
         it = p->maxiter;
         stopped = true;   // (nothing left to finish below)
     }
-    if (s == NMFX_OK && lagk == 2 && !stopped) s = Wbak.alloc(mKT * 4);
+    if (s == NMFX_OK && lagk == 2 && !stopped && !Wbak.p) s = Wbak.alloc(mKT * 4);
     for (it = stopped ? p->maxiter : 0; s == NMFX_OK && it < p->maxiter; ++it) {
         if ((s = nmfx_engine_wstep_partial(e)) != NMFX_OK) break;
         if (lagk == 1 && it > 0) {
@@ -184,7 +193,9 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
         if (s == NMFX_OK) s = download(st, H.as<float>(), p->dtype, r->H, Kn);
         if (s == NMFX_OK && algorithm == 3) s = download(st, Z.as<float>(), p->dtype, Z_out, (size_t)K * nz);
     }
+    (void)hipStreamSynchronize(st);
     nmfx_engine_destroy(e);
+    own.e = nullptr;
     const auto t3 = std::chrono::steady_clock::now();
     auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     io.ingest_s = sec(t0, t1); io.iterate_s = sec(t1, t2); io.egress_s = sec(t2, t3);
@@ -203,7 +214,7 @@ struct MultiDev {
     hipStream_t st[NMFX_MAX_GPUS] = {};
     hipEvent_t evP[NMFX_MAX_GPUS] = {}, evR[NMFX_MAX_GPUS] = {}, evG[NMFX_MAX_GPUS] = {}, evH[NMFX_MAX_GPUS] = {};
     nmfx_engine *eng[NMFX_MAX_GPUS] = {};
-    DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS];
+    DevBuf V[NMFX_MAX_GPUS], W[NMFX_MAX_GPUS], H[NMFX_MAX_GPUS], ws[NMFX_MAX_GPUS], packed[NMFX_MAX_GPUS], costh[NMFX_MAX_GPUS], tmp[NMFX_MAX_GPUS];
     long lo[NMFX_MAX_GPUS + 1];
     long hL[NMFX_MAX_GPUS] = {}, hR[NMFX_MAX_GPUS] = {};   // cnmf: T-1 halo columns of H on each inner edge (and of V on the right one)
     // host side of the small device <-> host scalars (per-shard cost partials, ||V||^2): pinned.  They used to be async copies into a std::vector / the
@@ -329,8 +340,12 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     // least 64 columns, so one short shard sends all of them to the general kernels
     const int shard_path = (p->path == 0 && nmin < 64) ? 1 : p->path;
     const size_t mK = (size_t)m * K * T, mKt = (size_t)m * Kt * T;   // (cnmf: the T slices of W; K is never padded there)
-    size_t packed_count = 0;
+    size_t packed_count = 0, wsb[NMFX_MAX_GPUS] = {};
     int kind = -1;
+    nmfx_engine_desc dd[NMFX_MAX_GPUS];
+    DevBuf Wbak;   // Gram-form cost + stop rule: device 0's W as it was before the update that produced cost(it-1)
+    // pass 1: streams, events and every buffer except the workspaces.  The workspaces come last and ALL at once, because whether they hold the transposed copy
+    // of V is one decision for the whole call (the kernel path, and with it the summation order of the replicated W update, follows from the descriptor)
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         M.ndev = g + 1;
@@ -338,32 +353,52 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         TRY(pool_event(M.dev[g], &M.evP[g])); TRY(pool_event(M.dev[g], &M.evR[g])); TRY(pool_event(M.dev[g], &M.evG[g])); TRY(pool_event(M.dev[g], &M.evH[g]));
         const long nl = M.lo[g + 1] - M.lo[g];
         const long hL = M.hL[g] = g > 0 ? hh : 0, hR = M.hR[g] = g < N - 1 ? hh : 0;   // H = [left halo | own columns | right halo], V = [own | right halo]
-        nmfx_engine_desc d{};
+        nmfx_engine_desc &d = dd[g];
+        d = nmfx_engine_desc{};
         d.m = m; d.n_local = nl; d.K_total = K; d.T = T; d.divergence = dv; d.alpha = p->alpha; d.beta = p->beta;
         d.halo_left = (int)hL; d.halo_right = (int)hR; d.n_valid = nl + hR;
         d.lamW_col = lw.data(); d.lamH_row = lh.data(); d.fixW_col = fw.data(); d.fixH_row = fh.data();
         d.device = M.dev[g]; d.stream = M.st[g]; d.algorithm = algorithm; d.path = shard_path; d.K_valid = pad ? Kt : 0; d.col_offset = M.lo[g];
-        size_t wsb = 0, pc = 0;
-        TRY(nmfx_engine_workspace_bytes(&d, &wsb));
+        size_t pc = 0;
         TRY(nmfx_engine_packed_count(&d, &pc));
         if (g == 0) packed_count = pc;
         else if (pc != packed_count) { set_error("n_gpus: shards disagree on the packed layout"); return NMFX_ERR_INVALID; }
-        DevBuf tmp;
         const long nh = hL + nl + hR;
-        TRY(M.V[g].alloc((size_t)m * (nl + hR) * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nh * 4)); TRY(M.ws[g].alloc(wsb));
+        TRY(M.V[g].alloc((size_t)m * (nl + hR) * 4)); TRY(M.W[g].alloc(mK * 4)); TRY(M.H[g].alloc((size_t)K * nh * 4));
         TRY(M.packed[g].alloc(pc * 4)); TRY(M.costh[g].alloc(64));
+        if (pad) TRY(M.tmp[g].alloc((size_t)Kt * nl * 4));
+        if (g == 0 && p->tolerance >= 0 && (dv == NMFX_DIV_EUCLIDEAN || dv == NMFX_DIV_EUCLIDEAN_NOCOST)) TRY(Wbak.alloc(mK * 4));
+    }
+    // pass 2: the workspaces, with the transposed copy of V; if ONE of them does not fit, every shard runs without it (flags bit 0 on all of them)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool ok = true;
+        for (int g = 0; g < N && ok; ++g) {
+            NMFX_HIP(hipSetDevice(M.dev[g]));
+            dd[g].flags = attempt == 0 ? 0 : 1;
+            TRY(nmfx_engine_workspace_bytes(&dd[g], &wsb[g]));
+            if (M.ws[g].alloc(wsb[g]) != NMFX_OK) {
+                if (attempt == 1) return NMFX_ERR_NOMEM;   // (the message of the failed allocation stands)
+                (void)hipGetLastError();
+                ok = false;
+            }
+        }
+        if (ok) break;
+        for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); M.ws[g].release(); }
+    }
+    // pass 3: ingest and engines
+    for (int g = 0; g < N; ++g) {
+        NMFX_HIP(hipSetDevice(M.dev[g]));
+        const long nl = M.lo[g + 1] - M.lo[g], hL = M.hL[g], hR = M.hR[g], nh = hL + nl + hR;
         const char *Vh = static_cast<const char *>(p->V) + (size_t)m * M.lo[g] * dsize(p->dtype);           // a column block is a contiguous slab
         const char *Hh = static_cast<const char *>(p->H_init) + (size_t)Kt * (M.lo[g] - hL) * dsize(p->dtype);
         TRY(upload(M.st[g], Vh, p->dtype, M.V[g].as<float>(), (size_t)m * (nl + hR), 1.0));
         TRY(upload(M.st[g], p->W_init, p->dtype, M.W[g].as<float>(), mKt, 1.0));
         if (pad) {
             NMFX_HIP(hipMemsetAsync(M.W[g].as<float>() + mKt, 0, (mK - mKt) * 4, M.st[g]));
-            TRY(tmp.alloc((size_t)Kt * nl * 4));
-            TRY(upload(M.st[g], Hh, p->dtype, tmp.as<float>(), (size_t)Kt * nl, 1.0));
-            TRY(repack_rows(M.st[g], tmp.as<float>(), Kt, M.H[g].as<float>(), K, nl));
-            NMFX_HIP(hipStreamSynchronize(M.st[g]));
+            TRY(upload(M.st[g], Hh, p->dtype, M.tmp[g].as<float>(), (size_t)Kt * nl, 1.0));
+            TRY(repack_rows(M.st[g], M.tmp[g].as<float>(), Kt, M.H[g].as<float>(), K, nl));
         } else TRY(upload(M.st[g], Hh, p->dtype, M.H[g].as<float>(), (size_t)K * nh, 1.0));
-        TRY(nmfx_engine_create(&d, M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb, M.packed[g].as<float>(), &M.eng[g]));
+        TRY(nmfx_engine_create(&dd[g], M.V[g].as<float>(), M.W[g].as<float>(), M.H[g].as<float>(), M.ws[g].p, wsb[g], M.packed[g].as<float>(), &M.eng[g]));
         TRY(nmfx_engine_set_rank0(M.eng[g], g == 0));
         if (hL || hR) TRY(nmfx_engine_defer_hstep_finish(M.eng[g], 1));   // V_hat / cost only once the neighbours' new columns are in
         const int kd = nmfx_engine_is_fused(M.eng[g]);
@@ -391,8 +426,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             NMFX_HIP(hipStreamSynchronize(M.st[g]));   // vv is a stack variable
         }
     }
-    DevBuf Wbak;   // Gram-form cost + stop rule: device 0's W as it was before the update that produced cost(it-1)
-    if (lagk == 2 && p->tolerance >= 0) { NMFX_HIP(hipSetDevice(M.dev[0])); TRY(Wbak.alloc(mK * 4)); }
+    if (lagk == 2 && p->tolerance >= 0 && !Wbak.p) { NMFX_HIP(hipSetDevice(M.dev[0])); TRY(Wbak.alloc(mK * 4)); }
     double *hc = M.hpin;   // pinned: the 8-byte read-backs land by DMA, not through the runtime's staging of pageable memory (see MultiDev::hpin)
     auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
         for (int g = 0; g < N; ++g) {
@@ -452,13 +486,11 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         const long nl = M.lo[g + 1] - M.lo[g];
-        DevBuf tmp;
         if (g == 0) TRY(download(M.st[g], M.W[g].as<float>(), p->dtype, r->W, mKt));
         char *Hh = static_cast<char *>(r->H) + (size_t)Kt * M.lo[g] * dsize(p->dtype);
         if (pad) {
-            TRY(tmp.alloc((size_t)Kt * nl * 4));
-            TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, tmp.as<float>(), Kt, nl));
-            TRY(download(M.st[g], tmp.as<float>(), p->dtype, Hh, (size_t)Kt * nl));
+            TRY(repack_rows(M.st[g], M.H[g].as<float>(), K, M.tmp[g].as<float>(), Kt, nl));
+            TRY(download(M.st[g], M.tmp[g].as<float>(), p->dtype, Hh, (size_t)Kt * nl));
         } else TRY(download(M.st[g], M.H[g].as<float>() + (size_t)K * M.hL[g], p->dtype, Hh, (size_t)K * nl));
     }
     return NMFX_OK;
@@ -489,7 +521,9 @@ nmfx_status nmfx_reconstruct(int64_t m, int64_t n, int32_t K, int32_t T, int32_t
     TRY(check_device(device));
     const size_t mn = (size_t)m * n, mKT = (size_t)m * K * T, Kn = (size_t)K * n;
     DevBuf Wd, Hd, Vd;
-    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4));    hipStream_t st = nullptr;
+    TRY(Wd.alloc(mKT * 4)); TRY(Hd.alloc(Kn * 4)); TRY(Vd.alloc(mn * 4));
+    hipStream_t st = nullptr;
+    StreamDrain drain_(st);
     TRY(upload(st, W, dtype, Wd.as<float>(), mKT, 1.0));
     TRY(upload(st, H, dtype, Hd.as<float>(), Kn, 1.0));
     GemmParams g;
@@ -515,9 +549,10 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
     DevBuf Wd, Ws, Hd, Hs, cog, ord;
     TRY(Wd.alloc(wb)); TRY(Ws.alloc(wb)); TRY(cog.alloc(sizeof(int) * K)); TRY(ord.alloc(sizeof(int) * K));
     hipStream_t st = nullptr;
+    std::vector<int> cg(K), order(K);
+    StreamDrain drain_(st);   // (after the vectors and the buffers: drained before they die on any return path)
     NMFX_HIP(hipMemcpyAsync(Wd.p, W, wb, hipMemcpyHostToDevice, st));
     TRY(center_of_gravity(st, Wd.p, dtype == NMFX_F64, m, K, cog.as<int>()));
-    std::vector<int> cg(K), order(K);
     NMFX_HIP(hipMemcpyAsync(cg.data(), cog.p, sizeof(int) * K, hipMemcpyDeviceToHost, st));
     NMFX_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < K; ++k) order[k] = k;
@@ -526,7 +561,9 @@ nmfx_status nmfx_sort_dictionary(int64_t m, int32_t K, int64_t n, int32_t dtype,
     TRY(permute(st, Wd.p, Ws.p, dtype == NMFX_F64, m, K, ord.as<int>(), 0));
     NMFX_HIP(hipMemcpyAsync(W_sorted, Ws.p, wb, hipMemcpyDeviceToHost, st));
     if (H) {
-        TRY(Hd.alloc(hb)); TRY(Hs.alloc(hb));
+        nmfx_status sa = Hd.alloc(hb);
+        if (sa == NMFX_OK) sa = Hs.alloc(hb);
+        if (sa != NMFX_OK) return sa;
         NMFX_HIP(hipMemcpyAsync(Hd.p, H, hb, hipMemcpyHostToDevice, st));
         TRY(permute(st, Hd.p, Hs.p, dtype == NMFX_F64, K, n, ord.as<int>(), 1));
         NMFX_HIP(hipMemcpyAsync(H_sorted, Hs.p, hb, hipMemcpyDeviceToHost, st));
@@ -556,6 +593,7 @@ nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s
     DevBuf X, it;
     TRY(X.alloc(tot * dsize(dtype))); TRY(it.alloc(sizeof(int) * count));
     hipStream_t st = nullptr;
+    StreamDrain drain_(st);
     // the vectors stay in the caller's precision: float64 input is projected in float64 end to end (projfunc.m computes in double)
     NMFX_HIP(hipMemcpyAsync(X.p, s, tot * dsize(dtype), hipMemcpyHostToDevice, st));
     if (dtype == NMFX_F64) TRY(projfunc_cols_f64(st, X.as<double>(), N, count, k1, k2, nn, it.as<int>()));

@@ -476,11 +476,30 @@ int fused_split(long blocks, long extent, int K, long *c_per_split) {
 namespace {
 
 constexpr double GRAM_COST_RATIO_MIN = 0.05;   // cost / (0.5*||V||^2) below which the explicit residual pass takes over (error bound there: 3e-9*2/0.05 = 1.2e-7 relative)
-// is THIS W step in Gram-cost mode?  Host-side and the same on every rank: capability, not latched to classic, and (on shards) the global norm known
+// is THIS W step in Gram-cost mode?  Host-side and the same on every rank AND in every run: capability, not latched to classic, (on shards) the global norm
+// known -- and the flag as it stood after the decision of TWO W updates ago.  gram_decide publishes the state of the flag after every decision with a
+// sequence stamp; W step j waits for the stamp of decision j-2 (the work of a whole iteration is queued behind it, so the wait never drains the device) and
+// latches on exactly that value.  Decision j-1 may or may not have run by then -- it is never looked at, so neither host timing nor the rank can change where
+// the engine switches kernels (round 3 read "whatever the flag is now": ranks could switch at different iterations and mix cost partials of two modes).
 inline bool gram_active(nmfx_engine *e) {
     if (!e->gram_cost || e->classic) return false;
     if (e->dist_seen && !e->sumvv_global_set) return false;
-    if (__atomic_load_n(e->exact_flag_host, __ATOMIC_ACQUIRE) != 0) { e->classic = true; return false; }   // lazily seen: from now on the one-pass kernel with the cost inside
+    if (e->decide_seq >= 2) {
+        const unsigned want = e->decide_seq - 2;
+        const int stamp = (int)((want + 1) & 0x3fffffffu);
+        int *slot = e->exact_flag_host + (want & 7u);
+        int v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+        for (unsigned long spins = 0; (v >> 1) != stamp; ++spins) {
+            if ((spins & 0xfffffu) == 0xfffffu && hipStreamQuery(e->st) != hipErrorNotReady) {   // the stream is idle (or dead) and the stamp is not there: do not hang on it
+                v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+                if ((v >> 1) != stamp) { (void)hipGetLastError(); v = 0; }
+                break;
+            }
+            __builtin_ia32_pause();
+            v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+        }
+        if (v & 1) { e->classic = true; return false; }   // from now on the one-pass kernel with the cost inside
+    }
     return true;
 }
 
@@ -824,12 +843,17 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     if (he == hipSuccess) he = hipMemcpyAsync(e->fixW, fw.data(), e->K, hipMemcpyHostToDevice, e->st);
     if (he == hipSuccess) he = hipMemcpyAsync(e->fixH, fh.data(), e->K, hipMemcpyHostToDevice, e->st);
     if (he == hipSuccess) he = hipStreamSynchronize(e->st);  // host vectors go out of scope
-    if (he != hipSuccess) { set_error("nmfx_engine_create: %s", hipGetErrorString(he)); delete e; return NMFX_ERR_HIP; }
+    if (he != hipSuccess) {
+        set_error("nmfx_engine_create: %s", hipGetErrorString(he));
+        if (hipStreamSynchronize(e->st) != hipSuccess) (void)hipGetLastError();   // (a copy queued before the one that failed may still be reading the vectors)
+        delete e;
+        return NMFX_ERR_HIP;
+    }
     if (e->all_fixW) e->gram_cost = false;   // no W update, no column statistics
     if (e->gram_cost) {
         he = hipHostMalloc(reinterpret_cast<void **>(&e->exact_flag_host), 64, hipHostMallocMapped | hipHostMallocPortable);
         if (he != hipSuccess) { (void)hipGetLastError(); e->exact_flag_host = nullptr; e->gram_cost = false; }
-        else *e->exact_flag_host = 0;
+        else memset(e->exact_flag_host, 0, 64);
     }
     *out = e;
     return NMFX_OK;
@@ -855,6 +879,7 @@ nmfx_status nmfx_engine_set_constraint(nmfx_engine *e, const int64_t *seg_host, 
     NMFX_HIP(hipSetDevice(e->device));
     if (e->seg_dev) { (void)hipFree(e->seg_dev); e->seg_dev = nullptr; }
     std::vector<long> sg(seg_host, seg_host + nz + 1);
+    StreamDrain drain_(e->st);
     NMFX_HIP(hipMalloc(&e->seg_dev, sizeof(long) * (nz + 1)));
     NMFX_HIP(hipMemcpyAsync(e->seg_dev, sg.data(), sizeof(long) * (nz + 1), hipMemcpyHostToDevice, e->st));
     NMFX_HIP(hipStreamSynchronize(e->st));
@@ -906,8 +931,8 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
                 NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
                 NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
-                *e->exact_flag_host = 0;
-                e->classic = false;
+                memset(e->exact_flag_host, 0, 64);
+                e->classic = false; e->decide_seq = 0;
             }
             if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
                 TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
@@ -925,8 +950,8 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
             NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
             NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
-            *e->exact_flag_host = 0;
-            e->classic = false;
+            memset(e->exact_flag_host, 0, 64);
+            e->classic = false; e->decide_seq = 0;
             e->cost_valid = false;
         }
         return NMFX_OK;
@@ -1099,7 +1124,8 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
                 }
                 p.dndp = e->dndp; p.stats_only = 1;
                 TRY(w_update(e->st, p));
-                TRY(gram_decide(e->st, e->dndp, e->K, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host));
+                TRY(gram_decide(e->st, e->dndp, e->K, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host + (e->decide_seq & 7u), (int)((e->decide_seq + 1) & 0x3fffffffu)));
+                e->decide_seq++;
             }
             e->chunk_parts = 0;
             TRY(fused_wpass_rows(e, false, 0, e->m, nullptr, false, e->exact_flag));   // returns at once while the flag is clear
@@ -1139,7 +1165,8 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
             p.dndp = e->dndp; p.stats_only = 1;
             TRY(w_update(e->st, p));
-            TRY(gram_decide(e->st, e->dndp, e->KT, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host));
+            TRY(gram_decide(e->st, e->dndp, e->KT, e->sumVV, GRAM_COST_RATIO_MIN, e->exact_flag, e->exact_flag_host + (e->decide_seq & 7u), (int)((e->decide_seq + 1) & 0x3fffffffu)));
+            e->decide_seq++;
             if (e->eucw) TRY(eucw_cost_pass(e, e->exact_flag));
             else TRY(fusedT_pass(e, FT_COST_EUC, nullptr, e->exact_flag));
             TRY(gram_cost_finish(e->st, e->dndp, e->KT, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->n_cost_used, useW ? e->l1W : nullptr, e->KT, e->lamW,
@@ -1425,13 +1452,17 @@ nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
 
 // the whole stretch between two all-reduces of a column-sharded run as ONE call: replicated W update, local H step, and (unless
 // `last`) the next iteration's W-step partial.  Not for cnmf shards, whose H step is split around the halo exchange.
-nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) {
+nmfx_status nmfx_engine_between_allreduces_cost(nmfx_engine *e, int32_t last, double *lag2_cost_dst_dev) {
     if (e->hL || e->hR) { set_error("nmfx_engine_between_allreduces: not for shards with halos"); return NMFX_ERR_UNSUPPORTED; }
     TRY(nmfx_engine_wstep_finish(e));
+    // engines of cost lag 2: the cost of the PREVIOUS iteration is in e->cost exactly here -- written by this wstep_finish (Gram form) or, once the engine has
+    // latched to the one-pass kernel, by the wstep_partial before it -- and the next wstep_partial below may overwrite it: hand it out now
+    if (lag2_cost_dst_dev) NMFX_HIP(hipMemcpyAsync(lag2_cost_dst_dev, e->cost, sizeof(double), hipMemcpyDeviceToDevice, e->st));
     TRY(nmfx_engine_hstep(e));
     if (!last) TRY(nmfx_engine_wstep_partial(e));
     return NMFX_OK;
 }
+nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last) { return nmfx_engine_between_allreduces_cost(e, last, nullptr); }
 
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out) {
     const bool lag = nmfx_engine_cost_lag(e) != 0;   // the cost of iteration i is a by-product of iteration i+1's W step

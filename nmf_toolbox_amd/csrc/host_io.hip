@@ -109,11 +109,18 @@ struct ResPool {
 };
 ResPool g_res;
 
+// NMFX_NO_POOL=1 (development switch, read once): streams and events are created per call and destroyed when handed back, as in round 3 before the pool --
+// the configuration the host-sanitizer campaign runs in (tests/host_asan/, profiles/r4_*): the pool must not be what keeps a lifetime bug from showing
+bool pool_off() {
+    static const bool off = [] { const char *e = getenv("NMFX_NO_POOL"); return e && e[0] == '1'; }();
+    return off;
+}
+
 }  // namespace
 
 nmfx_status pool_stream(int device, hipStream_t *st) {
     if (device < 0 || device >= NMFX_MAX_GPUS) { set_error("pool_stream: device %d out of range", device); return NMFX_ERR_INVALID; }
-    {
+    if (!pool_off()) {
         std::lock_guard<std::mutex> lk(g_res.mu);
         if (!g_res.st[device].empty()) { *st = g_res.st[device].back(); g_res.st[device].pop_back(); return NMFX_OK; }
     }
@@ -123,7 +130,7 @@ nmfx_status pool_stream(int device, hipStream_t *st) {
 }
 nmfx_status pool_event(int device, hipEvent_t *ev) {
     if (device < 0 || device >= NMFX_MAX_GPUS) { set_error("pool_event: device %d out of range", device); return NMFX_ERR_INVALID; }
-    {
+    if (!pool_off()) {
         std::lock_guard<std::mutex> lk(g_res.mu);
         if (!g_res.ev[device].empty()) { *ev = g_res.ev[device].back(); g_res.ev[device].pop_back(); return NMFX_OK; }
     }
@@ -133,11 +140,13 @@ nmfx_status pool_event(int device, hipEvent_t *ev) {
 }
 void unpool_stream(int device, hipStream_t st) {
     if (!st || device < 0 || device >= NMFX_MAX_GPUS) return;
+    if (pool_off()) { (void)hipStreamDestroy(st); return; }
     std::lock_guard<std::mutex> lk(g_res.mu);
     g_res.st[device].push_back(st);
 }
 void unpool_event(int device, hipEvent_t ev) {
     if (!ev || device < 0 || device >= NMFX_MAX_GPUS) return;
+    if (pool_off()) { (void)hipEventDestroy(ev); return; }
     std::lock_guard<std::mutex> lk(g_res.mu);
     g_res.ev[device].push_back(ev);
 }

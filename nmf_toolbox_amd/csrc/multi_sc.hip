@@ -143,6 +143,13 @@ nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r) {
     const long m = p->m, n = p->n;
     if (N > NMFX_MAX_GPUS || N > n) { set_error("n_gpus = %d: at most %d devices and one column per device", N, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
     if (p->sc_resume) { set_error("nmfsc: sc_resume belongs to the device-level entry point"); return NMFX_ERR_INVALID; }
+    // column shards run nmfx_nmfsc_dev, which takes the fused kernels only: say so HERE, before anything is uploaded or a thread is started (nmf / cnmf fall back
+    // to the general kernels for short shards; nmfsc has no sharded general path)
+    if (p->path == 1 || K > 256 || ((m < 64 || n / N < 64) && p->path != 2)) {
+        set_error("nmfsc on %d devices: fused kernels only -- K <= 256 (got %d), m >= 64 (got %ld) and at least 64 columns per device (got %ld); use fewer devices or n_gpus = 1",
+                  N, K, m, n / N);
+        return NMFX_ERR_UNSUPPORTED;
+    }
     double vmin = INFINITY, vmax = -INFINITY;   // nmfsc.m:57-62 on the whole matrix
     host_minmax(p->V, p->dtype, (size_t)m * n, &vmin, &vmax);
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }

@@ -20,6 +20,14 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Declared AFTER the host vectors / device buffers an entry point copies to or from asynchronously: whichever way the function is left -- an NMFX_HIP / TRY
+// early return included -- the stream is drained before that memory goes away, so no DMA is ever in flight into (or out of) a dead std::vector or a freed buffer
+struct StreamDrain {
+    hipStream_t st;
+    explicit StreamDrain(hipStream_t s) : st(s) {}
+    ~StreamDrain() { if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError(); }
+};
+
 // Collectives are the CALLER's: libnmfx never links RCCL.  A Comm wraps the all-reduce callback handed to nmfx_nmfsc_dev
 // (torch.distributed in the Python driver, ncclAllReduce in a MEX shim); inactive on one GPU.
 struct Comm {
@@ -178,9 +186,10 @@ struct WUpdateParams {
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 // Euclidean cost in Gram form, from the column statistics of the W update:  0.5*||V - W*H||^2 = 0.5*sumVV - sum(dp) + 0.5*sum(dn).
-// gram_decide: sets *exact_flag (sticky; mirrored into the host-mapped *host_flag when given) once that value drops below ratio_min * 0.5*sumVV[1]
-// -- below it fp32 products no longer resolve the cost to the contract and the explicit residual pass takes over (launched with run_if = exact_flag).
-nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_flag);
+// gram_decide: sets *exact_flag (sticky) once that value drops below ratio_min * 0.5*sumVV[1] -- below it fp32 products no longer resolve the cost to the
+// contract and the explicit residual pass takes over (launched with run_if = exact_flag).  The state of the flag after THIS decision goes to the host-mapped
+// *host_slot as (stamp << 1) | flag (stamp > 0 numbers the decisions of an engine; the host reads the slot of a fixed earlier decision, engine.hip::gram_active).
+nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double *sumVV, double ratio_min, int *exact_flag, int *host_slot, int stamp);
 // cost = (*exact_flag ? 0.5*sum(partials) : 0.5*sumVV[0] + (rank0 ? 0.5*sum(dn) - sum(dp) : 0)) + lambda terms     -> out, out2
 nmfx_status gram_cost_finish(hipStream_t st, const double *dndp, int nc, const double *sumVV, int rank0, const int *exact_flag, const double *partials, int nparts,
                              const double *l1W, int nW, const float *lamW, const double *l1H, int K, const float *lamH, double *out, double *out2);

@@ -405,6 +405,7 @@ nmfx_status projfunc_cols_dist(hipStream_t st, float *X, long len, int count, lo
     double *state = red + 4L * count;
     const double N = (double)N_total;
     std::vector<double> host(4 * (size_t)count);
+    StreamDrain drain_(st);   // the read-backs below land in `host`: nothing may still be in flight into it when it dies, whichever way this function is left
     hipLaunchKernelGGL(pfd_init_kernel, g, b, 0, st, src ? src : X, len, nn, v_scratch, flags, red, state, dir, dir64, mu);
     NMFX_HIP(hipGetLastError());
     nmfx_status rc = comm.allreduce(red, 4L * count, NMFX_F64, NMFX_REDUCE_SUM);

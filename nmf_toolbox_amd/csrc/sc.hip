@@ -349,6 +349,10 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     };
     // Line-search objectives from the quadratic expansion around the point the search starts from (aux.hip::quad_rows): no pass over V per try.  The
     // value that is accepted this way is only used to go on searching; every cost that is REPORTED (and every begobj) still comes out of a residual pass.
+    // Deviation from a literal port, stated: the accept test of nmfsc.m:164 / :215 is decided on begobj + expansion instead of on an evaluated objective.  The two
+    // agree in exact arithmetic; where the expansion says the candidate is within QUAD_TIE of begobj -- closer than an fp32 evaluation of the objective resolves
+    // either way -- the objective IS evaluated at the candidate and decides, so a near-tie is settled the way the reference settles it.
+    constexpr double QUAD_TIE = 2e-7;
     static const bool no_quad = getenv("NMFX_SC_NO_QUAD") != nullptr;   // dev switch (A/B runs)
     const bool quad = fast && !use64 && quad_rows_supported(K) && !no_quad;
     DevBuf qparts;
@@ -405,16 +409,20 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     const double begobj = cur_obj;                                              // nmfsc.m:149
                     int tries = 0;
                     double newobj = 0;
+                    bool tie = false;
                     for (;;) {
                         ++tries;
+                        tie = false;
                         TRY(step_project_H(HTd, use64 ? nullptr : G1.as<float>(), use64 ? g64h.as<double>() : nullptr, -stepH, HnewT));   // nmfsc.m:154-157
                         {
                             PScope ps(pf, SC_SMALL);
                             TRY(transpose_f32(st, HnewT, n, K, Hcand));
                         }
                         if (spec) TRY(resid_w(Wd, Hcand, G2.as<float>(), &newobj, false));          // nmfsc.m:160-161 (+ dW at the candidate)
-                        else if (quadH) TRY(quad_obj(Hcur, Hcand, Denb.as<float>(), n, begobj, &newobj, true));   // nmfsc.m:160-161 through the expansion in H
-                        else TRY(fast_obj(Wd, Hcand, &newobj));
+                        else if (quadH) {
+                            TRY(quad_obj(Hcur, Hcand, Denb.as<float>(), n, begobj, &newobj, true));   // nmfsc.m:160-161 through the expansion in H
+                            if (std::fabs(newobj - begobj) <= QUAD_TIE * std::fabs(begobj)) { TRY(fast_obj(Wd, Hcand, &newobj)); tie = true; }   // near-tie: the evaluated objective decides
+                        } else TRY(fast_obj(Wd, Hcand, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:164
                         stepH /= 2;                                                                 // nmfsc.m:169
                         if (stepH < 1e-200) { early = true; break; }                                // nmfsc.m:170-174
@@ -423,7 +431,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     ++nH;
                     if (early) { ncost = it; break; }
                     stepH *= 1.2;                                                                   // nmfsc.m:178
-                    if (quadH) approx = true;
+                    if (quadH && !tie) approx = true;
                     std::swap(HTd, HnewT); std::swap(Hcur, Hcand);                                  // nmfsc.m:179
                     cur_obj = newobj;
                     have_dW = spec;
@@ -457,15 +465,19 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     const double begobj = cur_obj;
                     int tries = 0;
                     double newobj = 0;
+                    bool tie = false;
                     for (;;) {
                         ++tries;
+                        tie = false;
                         {
                             PScope ps(pf, SC_PROJ);
                             TRY(projfunc_cols(st, Wnew, m, Kv, L1a, 1.0, 1, nullptr, use64 ? nullptr : G2.as<float>(), -stepW, Wd, use64 ? g64w.as<double>() : nullptr));   // nmfsc.m:205-208
                         }
                         if (spec_h) TRY(resid_h(Wnew, Hcur, &newobj));                              // nmfsc.m:211-212 (+ dH at the candidate)
-                        else if (quadW) TRY(quad_obj(Wd, Wnew, G2.as<float>(), m, begobj, &newobj, false));   // nmfsc.m:211-212 through the expansion in W (every rank holds all rows of W)
-                        else TRY(fast_obj(Wnew, Hcur, &newobj));
+                        else if (quadW) {
+                            TRY(quad_obj(Wd, Wnew, G2.as<float>(), m, begobj, &newobj, false));   // nmfsc.m:211-212 through the expansion in W (every rank holds all rows of W)
+                            if (std::fabs(newobj - begobj) <= QUAD_TIE * std::fabs(begobj)) { TRY(fast_obj(Wnew, Hcur, &newobj)); tie = true; }
+                        } else TRY(fast_obj(Wnew, Hcur, &newobj));
                         if (newobj <= begobj) break;                                                // nmfsc.m:215
                         stepW /= 2;
                         if (stepW < 1e-200) { early = true; break; }                                // nmfsc.m:221-225
@@ -476,7 +488,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
                     stepW *= 1.2;                                                                   // nmfsc.m:228
                     std::swap(Wd, Wnew);                                                            // nmfsc.m:229
                     cur_obj = newobj;
-                    approx = quadW;
+                    approx = quadW && !tie;
                     have_dH = spec_h;
                 } else {
                     TRY(fast_w_terms(Wd, Hcur, G1.as<float>(), G2.as<float>()));                    // V*H', V_hat*H'       nmfsc.m:194-195

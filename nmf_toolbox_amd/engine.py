@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 
 DIV_CODES = {"euclidean": _lib.DIV_EUCLIDEAN, "kl": _lib.DIV_KL, "kl_divergence": _lib.DIV_KL, "is": _lib.DIV_IS,
-             "is_divergence": _lib.DIV_IS, "frobenius": _lib.DIV_EUCLIDEAN_NOCOST}
+             "is_divergence": _lib.DIV_IS, "ab": _lib.DIV_AB, "ab_divergence": _lib.DIV_AB, "frobenius": _lib.DIV_EUCLIDEAN_NOCOST}
 
 
 def colmajor_to_torch(a, device):
@@ -101,9 +101,9 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None, tole
             if lagk == 1 and it > 0 and cost_out is not None:
                 emit(it - 1)
             allreduce_packed()
-            backend.between_allreduces(it == iters - 1)
-            if lagk == 2 and it > 0 and cost_out is not None:
-                emit(it - 1)                                  # (the next wstep_partial inside between_allreduces leaves the engine's cost alone in this mode)
+            # lag 2: cost(it-1) is complete right after the wstep_finish inside this call and the wstep_partial that follows it there may overwrite it (an
+            # engine that has gone back to the one-pass kernel produces cost(it) in that pass): the copy into cost_out happens inside the call, between the two
+            backend.between_allreduces(it == iters - 1, cost_out[it - 1:it] if (lagk == 2 and it > 0 and cost_out is not None) else None)
             if not lag and cost_out is not None:
                 emit(it)
             continue
@@ -160,7 +160,7 @@ class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
     def __init__(self, V, W, H, divergence="euclidean", T=1, algorithm="nmf", lamW=None, lamH=None, fixW=None, fixH=None,
-                 group=None, use_dist=None, path=0, halo=(0, 0), n_valid=None, n_chunks=None):
+                 group=None, use_dist=None, path=0, halo=(0, 0), n_valid=None, n_chunks=None, alpha=1.0, beta=1.0, no_vt=False):
         import torch
         self.torch = torch
         if not (V.is_cuda and W.is_cuda and H.is_cuda):
@@ -181,7 +181,8 @@ class Engine:
         d = _lib.EngineDesc()
         d.m, d.n_local, d.K_total, d.T = self.m, self.n, self.K, self.T
         d.divergence = DIV_CODES[divergence] if isinstance(divergence, str) else int(divergence)
-        d.alpha = d.beta = 1.0
+        is_ab = d.divergence == _lib.DIV_AB                      # nmf.m:255-266: alpha / beta are used for 'ab' only, every other divergence forces (1, 1)
+        d.alpha, d.beta = (float(alpha), float(beta)) if is_ab else (1.0, 1.0)
         self._keep = []
         for name, val, dt in (("lamW_col", lamW, np.float32), ("lamH_row", lamH, np.float32), ("fixW_col", fixW, np.uint8), ("fixH_row", fixH, np.uint8)):
             if val is not None:
@@ -202,12 +203,33 @@ class Engine:
                 d.path = 1
         d.halo_left, d.halo_right = self.hL, self.hR
         d.n_valid = int(n_valid) if n_valid is not None else self.n + self.hR
+        d.flags = 1 if (no_vt or os.environ.get("NMFX_NO_VT")) else 0
         self.desc = d
         nbytes, count = C.c_size_t(0), C.c_size_t(0)
-        _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
         _lib.check(self.lib.nmfx_engine_packed_count(C.byref(d), C.byref(count)))
-        self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.V.device)
         self.packed = torch.zeros(count.value, dtype=torch.float32, device=self.V.device)
+        # the workspace may hold a transposed copy of V (euclidean paths; nmfx_engine_desc.flags bit 0 = without).  If it does not fit HERE, every rank gives it
+        # up together: the kernel path -- and the summation order of the replicated W update -- follows from the descriptor, which must be the same everywhere
+        for attempt in range(2):
+            _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
+            failed = 0.0
+            try:
+                self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.V.device)
+            except (torch.OutOfMemoryError, RuntimeError) as ex:
+                if "out of memory" not in str(ex).lower():
+                    raise
+                self.workspace, failed = None, 1.0
+            if self.dist is not None:
+                ft = torch.tensor([failed], dtype=torch.float64, device=self.V.device)
+                self.dist.all_reduce(ft, op=self.dist.ReduceOp.MAX, group=group)
+                failed = float(ft.item())
+            if not failed:
+                break
+            self.workspace = None
+            if attempt == 1 or d.flags & 1:
+                raise _lib.NmfxError(_lib.NMFX_ERR_NOMEM, "Engine: the workspace (%d bytes) does not fit on a rank, even without the transposed copy of V" % nbytes.value)
+            torch.cuda.empty_cache()
+            d.flags |= 1
         self.cost_buf = None
         h = C.c_void_p()
         _lib.check(self.lib.nmfx_engine_create(C.byref(d), self.V.data_ptr(), self.W.data_ptr(), self.H.data_ptr(), self.workspace.data_ptr(),
@@ -269,8 +291,8 @@ class Engine:
     def hstep_finish(self):
         _lib.check(self.lib.nmfx_engine_hstep_finish(self.h))
 
-    def between_allreduces(self, last):
-        _lib.check(self.lib.nmfx_engine_between_allreduces(self.h, 1 if last else 0))
+    def between_allreduces(self, last, lag2_cost_dst=None):
+        _lib.check(self.lib.nmfx_engine_between_allreduces_cost(self.h, 1 if last else 0, lag2_cost_dst.data_ptr() if lag2_cost_dst is not None else None))
 
     def cost_pass(self):
         _lib.check(self.lib.nmfx_engine_cost_pass(self.h))

@@ -32,6 +32,8 @@ class NumpyShard:
         tail = mk if layout == "generic" and div != "kl" else (self.K * self.K if (layout in ("fused", "gram") and div == "euclidean") else self.K)
         self.packed = torch.zeros(mk + tail, dtype=torch.float64)
         self.cost_local = 0.0
+        self.latch_at = None      # "gram" layout: from W step number latch_at on the engine is back on the one-pass kernel -- the cost of the previous iteration then
+        self.wsteps = 0           # comes out of wstep_partial (point 1) while cost_lag keeps saying 2 (include/nmfx.h, nmfx_engine_cost_lag)
         self.W *= 1.0 / np.sqrt((self.W ** 2).sum(0))[None, :]                       # nmf.m:130-134
 
     def _cost(self):
@@ -47,7 +49,9 @@ class NumpyShard:
         S = self.W @ self.H
         A = self.V / S if self.div == "kl" else self.V
         N = A @ self.H.T
-        if self.cost_lag == 1:
+        self.classic = self.cost_lag == 2 and self.latch_at is not None and self.wsteps >= self.latch_at
+        self.wsteps += 1
+        if self.cost_lag == 1 or self.classic:
             self._cost()
         p = self.packed.numpy()
         p[:mk] = N.ravel(order="F")
@@ -94,7 +98,7 @@ class NumpyShard:
             P = p[mk:].reshape(self.m, self.K, order="F")
         W = self.W
         dn, dp = (W * P).sum(0), (W * N).sum(0)
-        if self.cost_lag == 2:
+        if self.cost_lag == 2 and not getattr(self, "classic", False):
             # 0.5*||V - W*H||^2 = 0.5*||V||^2 - <W, V*H'> + 0.5*<W, W*(H*H')> of the state this step started from: the all-reduced sums make the
             # cross terms global, so rank 0 alone carries them; every rank adds its own 0.5*||V_local||^2 and lambda_H*|H_local|
             c = 0.5 * np.sum(self.V ** 2) + float(np.sum(self.lamH * np.abs(self.H).sum(1)))
@@ -132,8 +136,10 @@ class NumpyShard:
 class NumpyShardMerged(NumpyShard):
     """the same phases behind the one-call-per-iteration entry point (nmfx_engine_between_allreduces)"""
 
-    def between_allreduces(self, last):
+    def between_allreduces(self, last, lag2_cost_dst=None):
         self.wstep_finish()
+        if lag2_cost_dst is not None:
+            self._copy_cost(lag2_cost_dst)
         self.hstep()
         if not last:
             if not self.cost_lags:
@@ -143,7 +149,7 @@ class NumpyShardMerged(NumpyShard):
                 self.cost_local = saved
 
 
-def _worker(rank, world, port, div, layout, iters, q, n_chunks=1, tolerance=None):
+def _worker(rank, world, port, div, layout, iters, q, n_chunks=1, tolerance=None, latch_at=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -158,6 +164,7 @@ def _worker(rank, world, port, div, layout, iters, q, n_chunks=1, tolerance=None
     cls = NumpyShardMerged if n_chunks == 0 else NumpyShard          # n_chunks == 0 selects the merged-call loop
     n_chunks = max(n_chunks, 1)
     be = cls(V[:, lo:hi], W0, H0[:, lo:hi], div, layout, lamW, lamH, fixW, fixH, rank == 0, n_chunks)
+    be.latch_at = latch_at
     cost = torch.zeros(iters, dtype=torch.float64)
     ran = run_sharded_iterations(be, iters, dist, None, cost, tolerance)
     q.put((rank, lo, hi, be.W, be.H, cost.numpy()[:ran].copy()))
@@ -181,10 +188,17 @@ def _cases():
     yield "euclidean", "gram", 0, None
     for div, layout in (("euclidean", "generic"), ("euclidean", "fused"), ("kl", "fused"), ("euclidean", "gram")):
         yield div, layout, 1, 0.05              # the stop rule of nmf.m:221-224 inside the sharded loop
+    # a lag-2 engine that goes back to the one-pass kernel at W step 5 (the Gram-form cost's switch): from there on the cost turns up one phase earlier, and the
+    # merged loop's next wstep_partial would overwrite it before the round-3 loop read it (advisor, round 3) -- both loops, and with the stop rule
+    yield "euclidean", "gram", 0, None, 5
+    yield "euclidean", "gram", 1, None, 5
+    yield "euclidean", "gram", 1, 0.05, 5
 
 
-@pytest.mark.parametrize("div,layout,n_chunks,tolerance", list(_cases()))
-def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks, tolerance):
+@pytest.mark.parametrize("case", list(_cases()))
+def test_sharded_loop_matches_unsharded_oracle(case):
+    div, layout, n_chunks, tolerance = case[:4]
+    latch_at = case[4] if len(case) > 4 else None
     from oracle import nmf_oracle as O
     world, iters = 2, 12 if tolerance is None else 40
     if tolerance is not None:       # a tolerance that makes nmf.m:221 fire around iteration 10 of this problem: between two consecutive decreases of the cost
@@ -197,7 +211,7 @@ def test_sharded_loop_matches_unsharded_oracle(div, layout, n_chunks, tolerance)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q, n_chunks, tolerance)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, div, layout, iters, q, n_chunks, tolerance, latch_at)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

@@ -793,3 +793,24 @@ def test_blocking_api_n_gpus_one_short_shard(gpu_lib, alg, div):
     else:
         ref, got = O.nmf(V, K, cfg), gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0] * 5))
     assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
+
+
+@pytest.mark.parametrize("workload", ["tiny", "c4"])
+def test_bench_self_launches_two_ranks(gpu_lib, workload):
+    """`python3 bench.py --gpus 2` as a PLAIN command (how the driver starts the 1-GPU run): bench.py starts its own two ranks under torch.distributed.run.
+    On the 1-GPU box both ranks share cuda:0 over gloo (RCCL refuses two ranks on one device); the line must say world_size_seen 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMFX_BENCH_BACKEND="gloo", NMFX_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["all_ranks_same_path"] and out["value"] > 0
+    assert out["cost_monotone"] and len(out["per_rank_ms_per_step"]["all"]) == 2
