@@ -51,7 +51,9 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
     out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else OUT
     # (-g / -fno-omit-frame-pointer for the HOST pass only: handed to the device pass as well they change the gfx950 code objects -- frame pointer, CFI spills --
     # and the register-stationary kernels then return garbage: measured, profiles/r4_01_host_asan.md)
-    san = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-Xarch_host", "-g", "-Xarch_host", "-fno-omit-frame-pointer"] if sanitize else []
+    # -fno-sanitize=function: UBSan's indirect-call check and HIP's kernel handles do not mix -- `auto kern = some_kernel<...>; hipLaunchKernelGGL(kern, ...)`
+    # (every templated launch of this library) is then silently NOT launched (hipcc 7.2; reproduced in 40 lines, profiles/r4_01_host_asan.md)
+    san = ["-fsanitize=address,undefined", "-fno-sanitize=function", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-Xarch_host", "-g", "-Xarch_host", "-fno-omit-frame-pointer"] if sanitize else []
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -76,7 +78,7 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
         tl = _torch_lib_dir()
         libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
         if sanitize:   # clang links the sanitizer runtimes into the EXECUTABLE; the shared object keeps its references to them undefined
-            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fsanitize=address,undefined", "-o", out] + objs
+            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-shared", "-fsanitize=address,undefined", "-fno-sanitize=function", "-o", out] + objs
         else:
             cmd = ["g++", "-shared", "-o", out] + objs
         for d in libdirs:
@@ -89,7 +91,7 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
         drv_src = os.path.join(os.path.dirname(HERE), "tests", "host_asan", "fuzz_multi.cpp")
         drv = os.path.join(os.path.dirname(drv_src), "fuzz_multi")
         if force or _newer([drv_src, out], drv):
-            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", INC, drv_src, "-o", drv,
+            cmd = ["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=function", "-fno-omit-frame-pointer", "-I", INC, drv_src, "-o", drv,
                    "-L" + HERE, "-lnmfx_asan", "-Wl,-rpath," + HERE + ":" + ":".join(([_torch_lib_dir()] if _torch_lib_dir() else []) + ["/opt/rocm/lib"]), "-lpthread"]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -19,12 +19,45 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unistd.h>
+#include <pthread.h>
+#include <signal.h>
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/common_interface_defs.h>
+#define HAVE_SAN_STACK 1
+#endif
+#endif
 
 #include "nmfx.h"
 
 namespace {
 
 std::atomic<bool> g_stop{false};
+std::atomic<long> g_progress{0};     // library calls finished so far (watchdog)
+char g_current[256] = "";            // the call in flight
+pthread_t g_main;
+
+// a call that does not come back: say which one it is and where the calling thread stands, then give up (exit code 3)
+void on_usr1(int) {
+    fprintf(stderr, "WATCHDOG: main thread stuck in: %s\n", g_current);
+#ifdef HAVE_SAN_STACK
+    __sanitizer_print_stack_trace();
+#endif
+    fflush(stdout); fflush(stderr);
+    _exit(3);
+}
+void watchdog() {
+    long last = -1;
+    int quiet = 0;
+    while (!g_stop.load()) {
+        std::this_thread::sleep_for(std::chrono::seconds(5));
+        const long now = g_progress.load();
+        quiet = now == last ? quiet + 1 : 0;
+        last = now;
+        if (quiet >= 12) { pthread_kill(g_main, SIGUSR1); std::this_thread::sleep_for(std::chrono::seconds(30)); _exit(4); }   // 60 s without a finished call
+    }
+}
 
 // what the float64 NumPy oracle did to the heap between two library calls: many short-lived blocks from a few bytes to a few MiB, written to
 void churn(unsigned seed) {
@@ -81,6 +114,8 @@ Out run(const Case &c, const std::vector<double> &V, const std::vector<double> &
     p.maxiter = c.it; p.tolerance = c.tol; p.device = 0;
     p.sc_W_sparsity = c.sW; p.sc_H_sparsity = c.sH;
     p.n_gpus = N; p.device_ids = ids;
+    snprintf(g_current, sizeof(g_current), "alg %d %ldx%ld K %d T %d div %d N %d it %d f32 %d lamW %g tol %g sW %g sH %g", c.alg, (long)c.m, (long)c.n, c.K, c.T, c.div, N, c.it,
+             (int)f32, c.lamW, c.tol, c.sW, c.sH);
     nmfx_result r;
     memset(&r, 0, sizeof(r));
     r.W = f32 ? (void *)Wo.data() : (void *)o.W.data(); r.H = f32 ? (void *)Ho.data() : (void *)o.H.data(); r.cost = o.cost.data();
@@ -92,6 +127,7 @@ Out run(const Case &c, const std::vector<double> &V, const std::vector<double> &
     case 2: o.rc = nmfx_lnmf(&p, &r); break;
     default: o.rc = nmfx_nmfsc(&p, &r); break;
     }
+    g_progress.fetch_add(1);
     if (o.rc != NMFX_OK) o.err = nmfx_last_error();
     o.cost_len = r.cost_len;
     if (f32) { o.W.assign(Wo.begin(), Wo.end()); o.H.assign(Ho.begin(), Ho.end()); }
@@ -111,8 +147,11 @@ int main(int argc, char **argv) {
     const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 12u;
     const std::string kinds = argc > 3 ? argv[3] : "esx1";
     if (nmfx_device_count() < 1) { fprintf(stderr, "fuzz_multi: no MI355X visible (%s)\n", nmfx_last_error()); return 2; }
+    g_main = pthread_self();
+    signal(SIGUSR1, on_usr1);
     std::vector<std::thread> bg;
     for (unsigned t = 0; t < 4; ++t) bg.emplace_back(churn, seed * 131 + t);
+    if (!getenv("FUZZ_NO_WATCHDOG")) bg.emplace_back(watchdog);
     std::mt19937 rng(seed);
     auto ri = [&](int lo, int hi) { return lo + (int)(rng() % (unsigned)(hi - lo)); };   // [lo, hi)
     const auto t0 = std::chrono::steady_clock::now();
@@ -143,6 +182,7 @@ int main(int argc, char **argv) {
         if (c.alg == 2) for (int k = 0; k < c.K; ++k) { double s = 0; for (long i = 0; i < c.m; ++i) s += W0[(size_t)k * c.m + i]; for (long i = 0; i < c.m; ++i) W0[(size_t)k * c.m + i] /= s; }
         const bool f32 = ri(0, 4) == 0;
         ++ncase;
+        if (ncase % 200 == 0) { printf("... %ld cases, %ld calls, bad %ld\n", ncase, ncalls, nbad); fflush(stdout); }
         if (kind == 'x') {   // error paths: every one of them must leave nothing in flight into host memory (ASan / the churn threads would see it)
             const int which = ri(0, 5);
             int32_t bad_ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -182,5 +222,8 @@ int main(int argc, char **argv) {
     for (auto &t : bg) t.join();
     printf("fuzz_multi seed %u kinds %s: %ld cases, %ld library calls, %ld expected errors, worst shard-vs-one-device deviation %.3g, bad %ld, pool %s\n", seed, kinds.c_str(), ncase,
            ncalls, nerr_expected, worst, nbad, (getenv("NMFX_NO_POOL") && getenv("NMFX_NO_POOL")[0] == '1') ? "OFF" : "on");
-    return nbad ? 1 : 0;
+    fflush(stdout);
+    // (no static destructors: the HSA runtime's own teardown trips an internal CHECK of the ROCm ASan runtime at exit -- "dev_runtime_unloaded_" -- which has
+    // nothing to do with the calls above and would turn every clean run into exit code 1)
+    _exit(nbad ? 1 : 0);
 }
