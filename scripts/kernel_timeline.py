@@ -10,7 +10,8 @@ names = [r["Kernel_Name"] for r in rows]
 dur = collections.Counter()
 for r in rows: dur[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 top = dur.most_common(1)[0][0]
-idx = [i for i, n in enumerate(names) if n == top]
+dmax = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"] == top)
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"] == top and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 0.3 * dmax]   # (the same template also runs tiny products)
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 a, b = idx[-1 - 2 * per], idx[-1 - per]
 t0 = int(rows[a]["Start_Timestamp"])

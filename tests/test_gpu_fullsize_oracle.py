@@ -106,6 +106,21 @@ def test_c5_nmfsc(gpu_lib):
     _report("C5 8192x8192 K=128 nmfsc sH=0.5", got, ref, tg, tc)
 
 
+def test_c5_full_nmfsc(gpu_lib):
+    """BASELINE config 5 IN FULL: nmfsc.m (nmfsc.m:141-245), V = 8192 x 32768, K = 128, H_sparsity 0.5, 3 outer iterations against the float64 oracle on the
+    host cores: identical line-search try counts (H and W), W / H / W*H within 1e-5, the cost vector within 1e-6."""
+    from oracle import nmf_oracle as O
+    m, n, K = 8192, 32768, 128
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=3, tolerance=1e-300)
+    i0, i1 = {}, {}
+    got, ref, tg, tc = _both(lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
+    print("\n[C5 full] line-search tries H: HIP %s oracle %s; W: HIP %s oracle %s" % (i1["triesH"], i0["triesH"], i1["triesW"], i0["triesW"]))
+    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    assert len(got[2]) == 4                                   # nmfsc.m:137-139,238: the initial objective + one entry per outer iteration
+    _report("C5 8192x32768 K=128 nmfsc sH=0.5 (full size)", got, ref, tg, tc)
+
+
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
 def test_default_100_iterations(gpu_lib, div):
     """The reference's defaults (nmf.m:404-411): maxiter = 100, tolerance = 1e-3, stop rule active, at 2048 x 8192, K = 128.
