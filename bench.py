@@ -53,6 +53,40 @@ WORKLOADS = {
 CPU_SAMPLE_COLS = {"c3": 4096, "c2": 8192, "c2is": 8192, "c4": 4096, "c4kl": 4096, "tiny": 1024}
 
 
+PMC_KERNEL_SOURCES = ("fused_kernel.h", "fused_launch.h", "fused.hip", "gemm_pipe.h", "gemm_common.h")
+
+
+def kernel_sources_sha16():
+    """sha256 over the sources of the kernels profiles/pmc_traffic.json describes (the fused passes, the pipelined GEMM): the PMC passes are separate
+    rocprofv3 runs, so their per-launch HBM bytes are only worth printing while the kernels are the ones that were measured"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nmf_toolbox_amd", "csrc")
+    for f in PMC_KERNEL_SOURCES:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_for(workload):
+    """(dict tag -> HBM bytes per launch, source note) from profiles/pmc_traffic.json -- or ({}, why not) when the file is missing or was measured on other kernel sources"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return {}, None
+    want = pm.get("_kernel_sources_sha16")
+    try:
+        have = kernel_sources_sha16()
+    except Exception:
+        have = None
+    if want is None or have is None or want != have:
+        return {}, ("profiles/pmc_traffic.json is STALE (measured on kernel sources %s, this tree has %s): traffic withheld -- re-run scripts/pmc_passes.sh and "
+                    "profiles/pmc_stamp.py" % (want, have))
+    return pm.get(workload, {}), ("profiles/pmc_traffic.json: HBM bytes per launch from a separate rocprofv3 --pmc pass of the same command (FETCH_SIZE x2 gfx950 correction "
+                                  "+ WRITE_SIZE) on these kernel sources (sha16 %s), not measured in this run" % have)
+
+
 def cpu_baseline(alg, div, m, n, K, T, name="c3"):
     """Reference CPU path: oracle (float64 literal restatement, same GEMM list as nmf.m) on a bounded column sample."""
     from oracle import nmf_oracle as O
@@ -139,14 +173,9 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
             name = max(tags, key=lambda k: tags[k][0])
             avg_ms = tags[name][0] / tags[name][1]
             ach = work[name][0] / (avg_ms * 1e-3) / 1e12
-            traffic, tsrc = None, None
-            try:   # HBM bytes per launch of the dominant kernel from the separate --pmc passes (not measured in this run)
-                pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json"))).get(args.workload, {})
-                hit = [v for k, v in pm.items() if name.startswith(k)]
-                if hit:
-                    traffic, tsrc = hit[0], "profiles/pmc_traffic.json: HBM bytes per launch from a separate rocprofv3 --pmc pass of the same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run"
-            except Exception:
-                pass
+            pm, tsrc = pmc_traffic_for(args.workload)   # HBM bytes per launch of the dominant kernel from the separate --pmc passes (not measured in this run)
+            hit = [v for k, v in pm.items() if name.startswith(k)]
+            traffic = hit[0] if hit else None
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         traffic=traffic, traffic_source=tsrc, avg_launch_ms=round(avg_ms, 4), launches=int(tags[name][1]), flops_per_launch=work[name][0],
                         algorithmic_bytes_per_launch=work[name][1], phases_ms_per_step=phases)
@@ -490,16 +519,10 @@ def main():
             d = tags[name]
             avg_ms = d["ms_total"] / d["launches"]
             ach = d["flops"] / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc) and world == 1:   # the PMC passes were taken on the whole problem: they say nothing about a shard's launch
-                try:
-                    traffic = json.load(open(pmc)).get(args.workload, {}).get(name)
-                except Exception:
-                    traffic = None
+            pm, tsrc = pmc_traffic_for(args.workload) if world == 1 else ({}, None)   # the PMC passes were taken on the whole problem: they say nothing about a shard's launch
+            traffic = pm.get(name)
             roof = dict(bound="mfma", kernel=name, achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        traffic=traffic, traffic_source=("profiles/pmc_traffic.json: HBM bytes per launch from a separate rocprofv3 --pmc pass of the same command "
-                                                         "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run") if traffic is not None else None,
+                        traffic=traffic, traffic_source=tsrc,
                         avg_launch_ms=round(avg_ms, 4), launches=d["launches"], flops_per_launch=d["flops"],
                         algorithmic_bytes_per_launch=d["bytes"],
                         phases_ms_per_step={k: round(v["ms_total"] / args.steps, 4) for k, v in prof.items() if v["launches"] > 0})

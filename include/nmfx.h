@@ -166,6 +166,14 @@ nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s
 nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t count, double k1, double k2, int32_t nn, const float *src_dev,
                               const float *dir_dev, double mu, int32_t *usediters_dev);
 
+/* nmfsc.m:57-62 on a DEVICE-resident column shard, for callers of nmfx_nmfsc_dev (which wants V already divided by the GLOBAL max):
+ *   nmfx_minmax_dev   out_dev[0] = max(X(:)), out_dev[1] = -min(X(:)) as doubles -- both "larger is more extreme", so ONE MAX all-reduce of the two over
+ *                     the ranks gives the global pair; the caller raises "Negative values in data!" when the second is > 0 (nmfsc.m:57-59);
+ *   nmfx_scale_dev    out = (float)((double)X / divide_by), element-wise (nmfsc.m:62 with the global max); out may be X.
+ * Asynchronous on `stream`; fixed reduction order (run-to-run deterministic). */
+nmfx_status nmfx_minmax_dev(void *stream, const float *X_dev, int64_t count, double *out_dev);
+nmfx_status nmfx_scale_dev(void *stream, const float *X_dev, int64_t count, double divide_by, float *out_dev);
+
 /* Measurement hook for the blocking calls (bench.py --api blocking): wall seconds the last nmfx_nmf / nmfx_cnmf / nmfx_lnmf /
  * nmfx_constrainednmf on the calling thread spent moving the host arrays in (host-side fp64 -> fp32 conversion on threads + DMA through
  * two pinned buffers), iterating, and moving the results out; and the bytes of host arrays read / written.  Any pointer may be NULL. */

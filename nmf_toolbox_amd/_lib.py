@@ -25,6 +25,7 @@ EXPORTS = [
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
     "nmfx_engine_between_allreduces", "nmfx_engine_between_allreduces_cost", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing", "nmfx_sc_iteration_seconds", "nmfx_engine_cost_lag", "nmfx_engine_sumvv_local", "nmfx_engine_sumvv_set_global",
+    "nmfx_minmax_dev", "nmfx_scale_dev",
 ]
 
 
@@ -130,6 +131,8 @@ def load():
     lib.nmfx_engine_cost_lag.argtypes = [C.c_void_p]
     lib.nmfx_engine_sumvv_local.argtypes = [C.c_void_p, C.c_void_p]
     lib.nmfx_engine_sumvv_set_global.argtypes = [C.c_void_p, C.c_void_p]
+    lib.nmfx_minmax_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.nmfx_scale_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
     _lib = lib
     return lib
 

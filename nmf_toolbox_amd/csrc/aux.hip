@@ -365,6 +365,21 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     const int c = blockIdx.x;
     const int k = c % p.K;
     float *w = p.W + p.m * c;
+    if (p.fin_on && blockIdx.x == gridDim.x - 1) {   // the cost of the state this W step started from (gram_cost_finish_kernel, same arithmetic and order)
+        const bool exact = *p.fin_exact_flag != 0;
+        double s = 0.0, t = 0.0;
+        if (exact) { for (int i = threadIdx.x; i < p.fin_nparts; i += 256) s += p.fin_partials[i]; }
+        else if (p.fin_rank0) { for (int cc = threadIdx.x; cc < p.fin_nc; cc += 256) s += 0.5 * p.dndp[cc] - p.dndp[p.fin_nc + cc]; }
+        s = block_sum<4>(s, red);
+        if (p.fin_l1W) for (int cc = threadIdx.x; cc < p.fin_nW; cc += 256) t += (double)p.fin_lamW[cc % p.fin_K] * p.fin_l1W[cc];
+        if (p.fin_l1H) for (int kk = threadIdx.x; kk < p.fin_K; kk += 256) t += (double)p.fin_lamH[kk] * p.fin_l1H[kk];
+        t = block_sum<4>(t, red);
+        if (threadIdx.x == 0) {
+            const double cst = (exact ? 0.5 * s : 0.5 * p.fin_sumVV[0] + s) + t;
+            *p.fin_out = cst;
+            if (p.fin_out2) *p.fin_out2 = cst;
+        }
+    }
     if (p.fixW && p.fixW[k]) {
         if (p.dndp && !p.stats_in) {   // fixed column: untouched, but <W, N> and <W, P> of the Gram-form cost run over every column
             const float *pp = p.P ? p.P + p.m * c : nullptr;
@@ -619,6 +634,37 @@ __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, cons
     const float lam = lamH ? lamH[k] : 0.0f;
     if (inv_exp == -2.0f) { H[idx] = sqrtf(H[idx] * gsum); return; }   // lnmf.m:76  H = sqrt(H .* (W'*(V./V_hat)))
     H[idx] = H[idx] * (neg / fmaxf(pos + lam, NMFX_EPS_F));
+}
+__global__ void h_update_shift_kernel(float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
+                                      float *Hpad, long padcount, long rightcount) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, count = (long)K * n;
+    if (Hpad) {
+        if (idx < padcount) Hpad[idx] = 0.0f;
+        if (idx < rightcount) Hpad[padcount + count + idx] = 0.0f;
+    }
+    if (idx >= count) return;
+    const long j = idx / K;
+    const int k = (int)(idx - j * K);
+    float h = H[idx];
+    if (!(fixH && fixH[k])) {
+        const long KT = (long)K * T;
+        float neg = 0.0f;
+        for (int t = 0; t < T; ++t)
+            if (j + t < nvalid) neg += Q[(long)t * K + k + KT * (j + t)];   // (shift_sum_kernel's order)
+        const float lam = lamH ? lamH[k] : 0.0f;
+        h = h * (neg / fmaxf(Gp[idx] + lam, NMFX_EPS_F));                   // cnmf.m:231 (h_update_kernel with inv_exp == 1)
+        H[idx] = h;
+    }
+    if (Hpad) Hpad[padcount + idx] = h;
+}
+nmfx_status h_update_shift(hipStream_t st, float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
+                           float *Hpad, int padL, int padR) {
+    const long count = (long)K * n, padcount = (long)K * padL, rightcount = (long)K * padR;
+    const long tot = std::max(count, std::max(padcount, rightcount));
+    if (tot <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(h_update_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, H, Q, Gp, K, T, n, nvalid, lamH, fixH, Hpad, padcount, rightcount);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
 }
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
                      const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride) {
@@ -1266,4 +1312,64 @@ nmfx_status cvt_to_f64(hipStream_t st, const float *in, double *out, long count)
     return NMFX_OK;
 }
 
+// ---- nmfsc.m:57-62 on a device-resident shard: max / -min in two deterministic stages, and the rescale -----------------------------------
+constexpr int MM_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void minmax_stage1_kernel(const float *X, long count, float *part) {
+    __shared__ float smx[4], smn[4];
+    float mx = -INFINITY, mn = INFINITY;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) { const float v = X[i]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        part[2 * blockIdx.x + 1] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    }
+}
+__global__ __launch_bounds__(256) void minmax_stage2_kernel(const float *part, int nblk, double *out) {
+    __shared__ float smx[4], smn[4];
+    float mx = -INFINITY, mn = INFINITY;
+    for (int b = threadIdx.x; b < nblk; b += 256) { mx = fmaxf(mx, part[2 * b]); mn = fminf(mn, part[2 * b + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); mn = fminf(mn, __shfl_xor(mn, o)); }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (double)fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        out[1] = -(double)fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    }
+}
+__global__ void scale_div_kernel(const float *X, long count, double divide_by, float *out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (float)((double)X[i] / divide_by);   // the value the host-side ingest of the blocking call produces (host_io.hip::narrow)
+}
+
 }  // namespace nmfx
+
+extern "C" {
+
+nmfx_status nmfx_minmax_dev(void *stream, const float *X_dev, int64_t count, double *out_dev) {
+    using namespace nmfx;
+    if (!X_dev || !out_dev || count <= 0) { set_error("nmfx_minmax_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // stage-1 partials live in a per-call device buffer freed in stream order (a shard is preprocessed once per factorisation: not a hot path)
+    float *part = nullptr;
+    NMFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), sizeof(float) * 2 * MM_BLOCKS, st));
+    const int nblk = (int)std::min<long>(MM_BLOCKS, (count + 255) / 256);
+    hipLaunchKernelGGL(minmax_stage1_kernel, dim3(nblk), dim3(256), 0, st, X_dev, (long)count, part);
+    hipLaunchKernelGGL(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, part, nblk, out_dev);
+    hipError_t le = hipGetLastError();
+    hipError_t fe = hipFreeAsync(part, st);
+    if (le != hipSuccess || fe != hipSuccess) { set_error("nmfx_minmax_dev: %s", hipGetErrorString(le != hipSuccess ? le : fe)); return NMFX_ERR_HIP; }
+    return NMFX_OK;
+}
+nmfx_status nmfx_scale_dev(void *stream, const float *X_dev, int64_t count, double divide_by, float *out_dev) {
+    using namespace nmfx;
+    if (!X_dev || !out_dev || count <= 0 || !(divide_by != 0.0)) { set_error("nmfx_scale_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    hipLaunchKernelGGL(scale_div_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), X_dev, (long)count, divide_by, out_dev);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
+}  // extern "C"

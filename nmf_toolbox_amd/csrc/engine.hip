@@ -1130,8 +1130,10 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             e->chunk_parts = 0;
             TRY(fused_wpass_rows(e, false, 0, e->m, nullptr, false, e->exact_flag));   // returns at once while the flag is clear
             Scope s(e, TAG_SMALL);
-            TRY(gram_cost_finish(e->st, e->dndp, e->K, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->chunk_parts, useW ? e->l1W : nullptr, e->K, e->lamW,
-                                 useH ? e->l1H : nullptr, e->K, e->lamH, e->cost, e->cost_dst2));
+            // the cost finisher rides in the update launch (its last workgroup): statistics, flag and residual partials are complete by now
+            p.fin_on = 1; p.fin_nc = e->K; p.fin_sumVV = e->sumVV; p.fin_rank0 = e->rank0; p.fin_exact_flag = e->exact_flag; p.fin_partials = e->cost_partials;
+            p.fin_nparts = e->chunk_parts; p.fin_l1W = useW ? e->l1W : nullptr; p.fin_nW = e->K; p.fin_lamW = e->lamW; p.fin_l1H = useH ? e->l1H : nullptr; p.fin_K = e->K;
+            p.fin_lamH = e->lamH; p.fin_out = e->cost; p.fin_out2 = e->cost_dst2;
             if (e->cost_dst2) e->cost_dst2_done = true;
             p.stats_only = 0; p.stats_in = 1;
             TRY(w_update(e->st, p));
@@ -1169,8 +1171,10 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             e->decide_seq++;
             if (e->eucw) TRY(eucw_cost_pass(e, e->exact_flag));
             else TRY(fusedT_pass(e, FT_COST_EUC, nullptr, e->exact_flag));
-            TRY(gram_cost_finish(e->st, e->dndp, e->KT, e->sumVV, e->rank0, e->exact_flag, e->cost_partials, e->n_cost_used, useW ? e->l1W : nullptr, e->KT, e->lamW,
-                                 useH ? e->l1H : nullptr, e->K, e->lamH, e->cost, e->cost_dst2));
+            // the cost finisher rides in the update launch (its last workgroup)
+            p.fin_on = 1; p.fin_nc = e->KT; p.fin_sumVV = e->sumVV; p.fin_rank0 = e->rank0; p.fin_exact_flag = e->exact_flag; p.fin_partials = e->cost_partials;
+            p.fin_nparts = e->n_cost_used; p.fin_l1W = useW ? e->l1W : nullptr; p.fin_nW = e->KT; p.fin_lamW = e->lamW; p.fin_l1H = useH ? e->l1H : nullptr; p.fin_K = e->K;
+            p.fin_lamH = e->lamH; p.fin_out = e->cost; p.fin_out2 = e->cost_dst2;
             if (e->cost_dst2) e->cost_dst2_done = true;
             p.stats_only = 0; p.stats_in = 1;
         }
@@ -1299,6 +1303,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
     if (!e->all_fixH) {
         OpView a{}, b{};
         num_view(e, a);
+        bool fuse_hupd = false;
         if (e->lagram) TRY(ensure_hpad(e));   // the denominator below reads the padded copy of the CURRENT H
         if (e->fusedT_kl) {   // R = V./V_hat with the W just updated
             TRY(fusedT_pass(e, FT_S_KL, nullptr));
@@ -1348,8 +1353,13 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 g.C = e->Qbuf; g.ldc = e->KT; g.epi = EPI_STORE; g.splitk = 1;
                 TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
             }
-            Scope s(e, TAG_SMALL);
-            TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gn));
+            // euclidean Gram path, one GPU: the shift-sum over t rides in the H update below (h_update_shift), which also rewrites the padded copy of H
+            fuse_hupd = e->gram && e->algo == 1 && mdiv(e) == NMFX_DIV_EUCLIDEAN && outer_exp(e) == 1.0f && e->hL == 0 && e->hR == 0 && e->Hpad && !e->fusedT_kl &&
+                        getenv("NMFX_NO_HUPD_FUSE") == nullptr;
+            if (!fuse_hupd) {
+                Scope s(e, TAG_SMALL);
+                TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gn));
+            }
         } else TRY(wt_times_x(e, a, e->Gn, TAG_HNUM));
         if (e->gram) {
             // sum_t W_t' * lshift_t(V_hat) = sum_t D_t * lshift_t(Hs),  D = W_flat' * W_flat  (cnmf.m:217-226 without V_hat)
@@ -1398,7 +1408,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(sum_over_t(e->st, e->colsum, e->K, e->T, e->Gpvec));
         }
         if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
-        else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
+        else if (fuse_hupd) {
+            TRY(h_update_shift(e->st, e->H, e->Qbuf, e->Gp, e->K, e->T, e->n, e->nvalid, e->lamH, e->fixH, e->Hpad, e->T - 1, e->lagram ? e->T - 1 : 0));
+            e->hpad_valid = true;   // (the layout ensure_hpad would produce)
+        } else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
     }
     if (e->defer_hfinish) return NMFX_OK;   // the caller refreshes H's halos first, then calls nmfx_engine_hstep_finish
     return nmfx_engine_hstep_finish(e);

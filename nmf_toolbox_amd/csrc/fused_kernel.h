@@ -1,4 +1,4 @@
-// The fused two-stage MFMA kernel template (included by fused.hip and by the dev-only probe_fused.hip).
+// The fused two-stage MFMA kernel template (instantiated by the fused_*.hip translation units through fused_launch.h).
 #pragma once
 #include "nmfx_internal.h"
 

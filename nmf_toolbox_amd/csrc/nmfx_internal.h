@@ -183,6 +183,13 @@ struct WUpdateParams {
     double *dndp;        // [2*K*T] or nullptr: dn[c] = sum_i W.*P and dp[c] = sum_i W.*N of column c (fixed columns included).  stats_only: the kernel
     int stats_only;      // writes them and returns (w_stats); stats_in: it reads them instead of summing (the update half of a split W update)
     int stats_in;
+    // Gram-form cost (see gram_cost_finish): when fin_on, the LAST workgroup of the launch first finishes the cost of the state this W step started from --
+    // the statistics, the flag and the (conditional) residual partials are all complete by then -- and only then updates its own column: one launch less
+    int fin_on, fin_nc, fin_rank0, fin_nparts, fin_nW, fin_K;
+    const double *fin_sumVV, *fin_partials, *fin_l1W, *fin_l1H;
+    const int *fin_exact_flag;
+    const float *fin_lamW, *fin_lamH;
+    double *fin_out, *fin_out2;
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 // Euclidean cost in Gram form, from the column statistics of the W update:  0.5*||V - W*H||^2 = 0.5*sumVV - sum(dp) + 0.5*sum(dn).
@@ -207,6 +214,10 @@ nmfx_status gp_tail(hipStream_t st, const float *CC, const float *H, int K, int 
 nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
+// cnmf, euclidean Gram path: Gn(k, j) = sum_t Q((t,k), j + t) (cnmf.m:217-226, the shift-sum of the Q product), the update of cnmf.m:231 and the
+// zero-padded copy Hpad = [padL zero columns | H | padR zero columns] the next passes stream -- shift_sum + h_update + pad_left in ONE launch
+nmfx_status h_update_shift(hipStream_t st, float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
+                           float *Hpad, int padL, int padR);
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
                      const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs = 1, long slab_stride = 0);   // n_slabs > 1: Gn = sum of slabs
 nmfx_status z_update(hipStream_t st, float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long nz, const long *seg,

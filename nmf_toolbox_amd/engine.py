@@ -416,14 +416,18 @@ def nmfsc_sharded(V, W, H, n_total=None, W_sparsity=0.0, H_sparsity=0.0, W_fixed
     if resume is not None:
         Vs, vmax = resume["Vs"], resume["vmax"]
     else:
-        # nmfsc.m:57-62: data must be non-negative; V = V / max(V(:)) with the GLOBAL max
-        mm = torch.stack([V.max(), -V.min()]).double()
+        # nmfsc.m:57-62: data must be non-negative; V = V / max(V(:)) with the GLOBAL max -- both steps are libnmfx kernels (nmfx_minmax_dev /
+        # nmfx_scale_dev: what a C host driving nmfx_nmfsc_dev calls too); torch only allocates and carries the MAX all-reduce of [max, -min]
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        mm = torch.empty(2, dtype=torch.float64, device=dev)
+        _lib.check(lib.nmfx_minmax_dev(stream, V.data_ptr(), V.numel(), mm.data_ptr()))
         if allreduce is not None:
             allreduce(mm, _lib.REDUCE_MAX)
         vmax, vmin = float(mm[0]), -float(mm[1])
         if vmin < 0:
             raise ValueError("Negative values in data!")
-        Vs = V / vmax
+        Vs = torch.empty_like(V)
+        _lib.check(lib.nmfx_scale_dev(stream, V.data_ptr(), V.numel(), vmax, Vs.data_ptr()))
     nt = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
     if allreduce is not None:
         allreduce(nt, _lib.REDUCE_SUM)

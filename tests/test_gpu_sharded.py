@@ -192,7 +192,16 @@ def _free_port():
     return p
 
 
-def _dist_worker(rank, world, port, q, K=64, div="kl", n_chunks=2, kind=1, lag=1):
+def _switch_data(m, n, K, noise=0.33):
+    """a rank-K product plus enough noise that 0.5||V - W*H||^2 starts above 5 % of 0.5||V||^2 and sinks below it after a few iterations: the Gram-form cost of the
+    euclidean fused path switches to the explicit residual pass there"""
+    rs = np.random.RandomState
+    V = rs(1001).rand(m, K) @ rs(1002).rand(K, n) / K + noise * np.fmax(rs(1000).rand(m, n), EPS)
+    _, W0, H0 = synth(m, n, K)
+    return V, W0, H0
+
+
+def _dist_worker(rank, world, port, q, K=64, div="kl", n_chunks=2, kind=1, lag=1, planted=False, iters=10):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -200,15 +209,15 @@ def _dist_worker(rank, world, port, q, K=64, div="kl", n_chunks=2, kind=1, lag=1
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nmf_toolbox_amd.engine import Engine, colmajor_to_torch, shard_columns, torch_to_colmajor
     m, n = 256, 1024
-    V, W0, H0 = synth(m, n, K)
+    V, W0, H0 = _switch_data(m, n, K) if planted else synth(m, n, K)
     lo, hi = shard_columns(n, world, rank)
     dev = "cuda:0"
     e = Engine(colmajor_to_torch(V[:, lo:hi], dev), colmajor_to_torch(W0, dev), colmajor_to_torch(H0[:, lo:hi], dev), divergence=div,
                n_chunks=n_chunks)                   # (2: also exercises the row-chunked, async all-reduce form of the W step)
     assert e.dist is not None and e.rank == rank and e.n_chunks == n_chunks and e.path_kind == kind and e.cost_lag == lag
     e.init()
-    cost = torch.zeros(10, dtype=torch.float64, device=dev)
-    e.iterate(10, cost)
+    cost = torch.zeros(iters, dtype=torch.float64, device=dev)
+    e.iterate(iters, cost)
     torch.cuda.synchronize()
     q.put((rank, torch_to_colmajor(e.W).reshape(m, K), torch_to_colmajor(e.H), cost.cpu().numpy()))
     dist.barrier()
@@ -237,6 +246,35 @@ def test_torch_distributed_loop_two_processes(gpu_lib, K, div, n_chunks, kind, l
     assert np.array_equal(res[0][1], res[1][1])
     assert rel_fro(res[0][1], W) < 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) < 1e-5
     assert rel_fro(res[0][3], c0) < 1e-6 and rel_fro(res[1][3], c0) < 1e-6
+
+
+def test_torch_distributed_loop_through_the_gram_cost_switch(gpu_lib):
+    """Two processes, euclidean fused path (cost lag 2), PLANTED data: the residual falls below 5 % of ||V||^2 within a few iterations, the device-side flag turns the
+    explicit residual pass on and, two W updates later, both ranks go back to the one-pass kernel -- from where on the cost of an iteration turns up one phase
+    EARLIER.  The merged loop of round 3 read it after the next wstep_partial had already overwritten it (every entry from the switch on shifted by one; advisor,
+    r3): the cost vector must equal the unsharded oracle's entry for entry, on both ranks, through the switch."""
+    import torch.multiprocessing as mp
+    from oracle import nmf_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    K, iters = 64, 40
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q, K, "euclidean", 1, 1, 2, True, iters)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m, n = 256, 1024
+    V, W0, H0 = _switch_data(m, n, K)
+    W, H, c0 = O.nmf(V, K, dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300))
+    cross = int(np.argmax(c0 < 0.05 * 0.5 * np.sum(V * V)))
+    assert 3 <= cross <= iters - 6, cross                                               # the run really crosses the switch, with iterations to spare on both sides
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][3], res[1][3])   # W and the cost vector bit-identical on both ranks
+    assert rel_fro(res[0][1], W) < 1e-5 and rel_fro(np.concatenate([res[0][2], res[1][2]], axis=1), H) < 1e-5
+    worst = float(np.max(np.abs(res[0][3] - c0) / c0))
+    assert worst < 1e-6, (worst, res[0][3][:8], c0[:8])                                  # entry for entry: a shifted vector is off by the iteration-to-iteration decrease
 
 
 # ---- cnmf on column shards (SURVEY 8(f) row f2): halo columns of H / V, exchanged between neighbours --------------------
