@@ -239,8 +239,11 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_INVALID;
     }
     // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
-    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps and two accumulator sets per pass: K <= 192 (registers)
-    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 192;
+    // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps per pass: with two accumulator sets in ONE pass up to K = 192
+    // (registers), as two single-map passes above it (dual2, round 4)
+    static const bool no_dual2 = getenv("NMFX_NO_DUAL2") != nullptr;   // dev switch (A/B runs against the materialised path)
+    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && (e->K <= 192 || (e->K <= 256 && !no_dual2));
+    e->dual2 = e->dual && e->K > 192;
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
                           e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
     if (d->path == 2 && !eligible && e->algo != 1) {   // cnmf: see the fused shift-sum passes below
@@ -248,7 +251,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
-    if (!e->fused) e->dual = false;
+    if (!e->fused) e->dual = e->dual2 = false;
     static const bool exact_cost_env = getenv("NMFX_EXACT_COST") != nullptr;   // dev switch (A/B runs): always the explicit residual inside the W-step pass
     e->gram_cost = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !e->dual && !exact_cost_env;
     static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
@@ -534,7 +537,23 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
         f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = 1.0f;
         if (e->Valpha) f.D = e->Valpha + row0;
     }
-    {
+    if (e->dual2) {
+        // K > 192: numerators (+ the cost terms) and denominators in two passes of one element map each; the second one writes where the dual-map kernel's
+        // second accumulator set would have gone
+        func = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
+        f.out2 = nullptr;
+        {
+            Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
+            TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
+        }
+        if (do_g2) {
+            FusedParams g = f;
+            g.out = split == 1 ? out2 : e->slabs2;
+            g.cost_partials = nullptr;
+            Scope s(e, TAG_FUSED_W);
+            TRY(launch_fused(e->st, g, split, true, func + 1, true, 0));
+        }
+    } else {
         Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));   // (a conditional launch is a no-op most of the time: not worth an event pair)
         TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
     }
@@ -1260,15 +1279,23 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             if (hug) { TRY(h_update_gram(e->st, e->H, e->GW, e->Gn, 1, 0, e->K, e->n, e->lamH, e->fixH)); }
             else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
             else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
-        } else if (e->isplit_h == 1 && e->algo != 3 && !hug) {
+        } else if (e->isplit_h == 1 && e->algo != 3 && !hug && !e->dual2) {
             f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
             TRY(launch_fused(e->st, f, 1, false, func, true, 1));
-        } else if (e->dual) {   // split over the rows of W, or constrainednmf: numerator and denominator slabs, then the generic update
+        } else if (e->dual) {   // split over the rows of W, or constrainednmf, or K > 192: numerator and denominator slabs, then the generic update
             f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.out2 = e->isplit_h == 1 ? e->Gp : e->slabs2;
             f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
-            {
+            if (e->dual2) {   // one element map per pass: W'*A, then W'*B
+                const int fa = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
+                FusedParams g = f;
+                g.out = f.out2; g.out2 = nullptr;
+                f.out2 = nullptr;
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, f, e->isplit_h, false, fa, true, 0));
+                TRY(launch_fused(e->st, g, e->isplit_h, false, fa + 1, true, 0));
+            } else {
                 Scope s(e, TAG_FUSED_H);
                 TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));
             }
@@ -1533,11 +1560,12 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
         if (e->fusedT || e->fusedT_kl || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
+        if (e->dual2) { *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch (two per W step): S + one contraction
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
-    case TAG_FUSED_H: *flops = (e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_H: *flops = (e->dual2 ? 4.0 : e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
     case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
     }

@@ -34,6 +34,10 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         sum (V - S).^2 of the accumulated S (functor 1's terms), nothing stored
 //       9 (cost-only form, W-step form): R = max(D + S, 0) stored to p.Rout -- cnmfsc.m:262, V_hat = max(V_hat + dW_t * rshift_t(H), 0), in place (D = Rout = V_hat)
 //       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc keeps V_hat: its W branch updates it slice by slice)
+//       11 / 12 (IS) and 13 / 14 (alpha-beta, alpha ~= 0): the two element maps of functors 4 / 5 as TWO single-map passes, for 192 < K <= 256 where a second
+//         accumulator set no longer fits the register file (nmf.m:154-164,185-195 have no K limit).  11: A = V./S.^2 (+ the IS cost terms), 12: B = 1./S,
+//         13: A = V.^alpha .* S.^(beta-1) (+ the alpha-beta cost terms; D holds V.^alpha), 14: B = S.^(alpha+beta-1).  Each is the KL pass with another map:
+//         S is formed twice (8*m*n*K per half-iteration instead of 6) but V_hat never reaches HBM
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S && PROBE == 0;
-    constexpr int NU = DUAL ? 8 : 4;       // micro-ops per element of the element map
+    constexpr int NU = (DUAL || FUNC == 11 || FUNC == 13) ? 8 : 4;   // micro-ops per element of the element map
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
@@ -258,6 +262,27 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 5) sacc2[jb][reg] = live ? er[sl] : 0.0f;
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC == 11) {                          // IS, numerators only: A = V./S.^2, cost terms q - ln(q) (functor 4 without its B tile)
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
+                if (u == 1) eq[sl] = v * er[sl];
+                if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
+                if (u == 4) er[sl] = __builtin_amdgcn_logf(eq[sl]);                  // log2(q)
+                if (u == 5) tc = live ? tc + eq[sl] : tc;
+                if (u == 6) tc = live ? fmaf(-0.6931471805599453f, er[sl], tc) : tc;
+                if (u == 5 || u == 6) asm volatile("" : "+v"(tc));
+            } else if (FUNC == 12) {                          // IS, denominators only: B = 1./S
+                if (u == 0) sacc[jb][reg] = live ? __builtin_amdgcn_rcpf(sacc[jb][reg]) : 0.0f;
+            } else if (FUNC == 13) {                          // alpha-beta, numerators only: A = V.^a .* S.^(b-1), cost terms S.*(A - b/(a+b)*B) (functor 5 without its B tile)
+                if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(es[sl]), -3.0e38f, 3.0e38f); }   // log2(S), see functor 5
+                if (u == 1) eq[sl] = ab_e1 * er[sl];
+                if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
+                if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)
+                if (u == 4) { eq[sl] = v * eq[sl]; sacc[jb][reg] = live ? eq[sl] : 0.0f; }
+                if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
+                if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC == 14) {                          // alpha-beta, denominators only: B = S.^(a+b-1)
+                if (u == 0) er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(sacc[jb][reg]), -3.0e38f, 3.0e38f);
+                if (u == 1) sacc[jb][reg] = live ? __builtin_amdgcn_exp2f(ab_e2 * er[sl]) : 0.0f;
             } else if (FUNC == 9) {                           // V_hat <- max(V_hat + dW*Hs, 0)   (cnmfsc.m:262)
                 if (u == 0) sacc[jb][reg] = fmaxf(v + sacc[jb][reg], 0.0f);
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)

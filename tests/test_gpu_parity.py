@@ -824,7 +824,8 @@ def test_nmf_euclidean_K_above_256_in_column_blocks(gpu_lib, m, n, K, planted):
 # ---- IS and alpha-beta on the fused kernels (two element maps / two accumulator sets per pass, K <= 128): split and un-split epilogues,
 # ragged shapes, padded K, sources with sparsity / fixed flags; against the oracle and against the generic (materialised V_hat) path ----
 @pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5)), ("ab", (2.0, -0.5)), ("ab", (1.0, 0.5)), ("ab", (1.5, -1.5))])
-@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 15), (384, 640, 128, 10), (128, 8192, 32, 4), (513, 300, 40, 8), (129, 131, 96, 8), (2049, 257, 100, 4), (384, 1024, 192, 8), (300, 700, 150, 6)])   # the last two: K above 128 (two accumulator sets still fit up to 192)
+@pytest.mark.parametrize("m,n,K,iters", [(256, 1024, 64, 15), (384, 640, 128, 10), (128, 8192, 32, 4), (513, 300, 40, 8), (129, 131, 96, 8), (2049, 257, 100, 4), (384, 1024, 192, 8), (300, 700, 150, 6),
+                                         (384, 1024, 224, 6), (256, 768, 256, 6), (321, 515, 250, 5)])   # K above 128 (two accumulator sets still fit up to 192); above 192: two single-map passes
 def test_nmf_fused_is_and_alpha_beta(gpu_lib, div, ab, m, n, K, iters):
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K)
@@ -868,7 +869,39 @@ def test_nmf_fused_is_multi_source_fixed_and_shards(gpu_lib):
     _check(gpu_lib.nmf(V, Ks, cfg), ref, cost_tol=1e-5)
     _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_gpus=[0, 0, 0])), ref, cost_tol=1e-5)          # [N | P] through the peer exchange on three shards
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.nmf(V, 224, dict(divergence="is", maxiter=1, nmfx_path=2))                   # two accumulator sets: K <= 192 only (224 spills)
+        gpu_lib.nmf(V, 288, dict(divergence="is", maxiter=1, nmfx_path=2))                   # IS / alpha-beta on the fused kernels: K <= 256
+
+
+@pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5))])
+def test_nmf_is_ab_above_192_two_single_map_passes(gpu_lib, div, ab):
+    """IS / alpha-beta with 192 < K <= 256 (nmf.m:154-164,185-195 have no K limit): the dual-map kernel's second accumulator set no longer fits, so every pass runs
+    twice with one element map each (functors 11 + 12 / 13 + 14) -- V_hat still never formed.  The device-level engine says which path it took; sources with
+    sparsity and a fixed factor, three column shards ([N | P] through the peer exchange), the stop rule, and run to run."""
+    import torch
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
+    m, n, K = 384, 1280, 256
+    V, W0, H0 = synth(m, n, K)
+    kw = dict(alpha=ab[0], beta=ab[1]) if ab else {}
+    e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence=div, use_dist=False, **kw)
+    assert e.path_kind == 1 and e.cost_lag == 1           # the fused kernels (1), not the materialised path (0)
+    e.close()
+    Ks = [100, 156]
+    cfg = dict(divergence=div, W_init=[W0[:, :100], W0[:, 100:]], H_init=[H0[:100], H0[100:]], W_sparsity=[0.02, 0.0], H_sparsity=[0.0, 0.05],
+               W_fixed=[False, False], H_fixed=[True, False], maxiter=8, tolerance=1e-12, **kw)
+    ref = O.nmf(V, Ks, cfg)
+    got = gpu_lib.nmf(V, Ks, cfg)
+    _check(got, ref, cost_tol=1e-5)
+    _check(gpu_lib.nmf(V, Ks, dict(cfg, nmfx_gpus=[0, 0, 0])), ref, cost_tol=1e-5)
+    again = gpu_lib.nmf(V, Ks, cfg)
+    assert np.array_equal(np.hstack(again[0]), np.hstack(got[0])) and np.array_equal(np.vstack(again[1]), np.vstack(got[1])) and np.array_equal(again[2], got[2])   # run to run
+    probe = O.nmf(V, K, dict(divergence=div, W_init=W0, H_init=H0, maxiter=12, tolerance=1e-300, **kw))[2]
+    dec = -np.diff(probe)
+    if np.all(np.isfinite(probe)) and np.all(dec[:8] > 0) and dec[4] > dec[5]:
+        cfg2 = dict(divergence=div, W_init=W0, H_init=H0, maxiter=12, tolerance=float(0.5 * (dec[4] + dec[5])), **kw)
+        ref2, got2 = O.nmf(V, K, cfg2), gpu_lib.nmf(V, K, cfg2)
+        assert len(got2[2]) == len(ref2[2]) < 12
+        _check(got2, ref2, cost_tol=1e-5)
 
 
 # ---- cnmf on the register-stationary kernels (fused_kernel TT > 1): every instantiated (K, T) pair, aligned and ragged shapes, sparsity,
