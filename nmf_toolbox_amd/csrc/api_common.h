@@ -206,6 +206,7 @@ inline size_t dsize(int dtype) { return dtype == NMFX_F64 ? 8 : 4; }
 nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by);
 nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, size_t count);
 void host_minmax(const void *host, int dtype, size_t count, double *vmin, double *vmax);
+void staging_quiesce();   // the pinned staging buffers hold no reference to an event of a stream that is about to be handed back (host_io.hip)
 // per-thread account of the last blocking call (nmfx_last_call_timing)
 struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0; };
 IoStats &io_stats();

@@ -949,6 +949,22 @@ nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *po
     return NMFX_OK;
 }
 
+// cnmfsc.m:261 on one time slice, in one launch: Xnew = X0 .* (neg ./ max(pos, eps)) and dX = Xnew - X0 (the V_hat correction of cnmfsc.m:262 wants the difference);
+// the same arithmetic, in the same order, as copy + mu_plain + axpy_f32
+__global__ void mu_plain_diff_kernel(const float *X0, const float *neg, const float *pos, long count, float *Xnew, float *dX) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const float x0 = X0[idx], xn = x0 * (neg[idx] / fmaxf(pos[idx], NMFX_EPS_F));
+    Xnew[idx] = xn;
+    dX[idx] = xn + (-1.0f) * x0;
+}
+nmfx_status mu_plain_diff(hipStream_t st, const float *X0, const float *neg, const float *pos, long count, float *Xnew, float *dX) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(mu_plain_diff_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, X0, neg, pos, count, Xnew, dX);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // X <- X .* (neg ./ (pos + eps))     cnmfsc.m:202 (plus, not max)
 __global__ void mu_plus_eps_kernel(float *X, const float *neg, const float *pos, long count) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

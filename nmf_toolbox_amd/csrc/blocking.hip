@@ -230,6 +230,7 @@ struct MultiDev {
             (void)hipSetDevice(dev[g]);
             if (st[g]) (void)hipStreamSynchronize(st[g]);
         }
+        staging_quiesce();   // (the ingest left its DMA-done events recorded on these streams)
         for (int g = 0; g < ndev; ++g) {
             (void)hipSetDevice(dev[g]);
             if (eng[g]) nmfx_engine_destroy(eng[g]);

@@ -153,6 +153,15 @@ void unpool_event(int device, hipEvent_t ev) {
 
 IoStats &io_stats() { return g_io; }
 
+// The staging buffers remember the event of their last DMA (PinnedPool::pend_dev) and wait for it before they are refilled -- by then possibly in a LATER call.
+// A multi-device call records those events on ITS OWN streams, which go back to the pool (or, with NMFX_NO_POOL, are destroyed) when it ends: settle the
+// bookkeeping while the streams still exist, so that no later call ever synchronises an event whose stream is gone.  The callers have drained their streams.
+void staging_quiesce() {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (int b = 0; b < 2; ++b)
+        if (g_pool.wait(b) != NMFX_OK) { (void)hipGetLastError(); g_pool.pend_dev[b] = -1; }
+}
+
 // host (f32 / f64, pageable) -> device fp32, out = in / divide_by.  Returns once the last chunk is QUEUED on `st`; the caller's buffer is
 // no longer referenced at that point (the DMA reads the pinned copies), and work queued on `st` afterwards sees the data.
 nmfx_status upload(hipStream_t st, const void *host, int dtype, float *dev, size_t count, double divide_by) {

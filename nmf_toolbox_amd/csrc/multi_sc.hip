@@ -124,6 +124,7 @@ struct ScMulti {
             (void)hipSetDevice(C.dev[g]);
             if (C.st[g]) (void)hipStreamSynchronize(C.st[g]);
         }
+        staging_quiesce();   // (the ingest left its DMA-done events recorded on these streams)
         for (int g = 0; g < C.N; ++g) {
             (void)hipSetDevice(C.dev[g]);
             unpool_event(C.dev[g], C.evA[g]); unpool_event(C.dev[g], C.evB[g]); unpool_event(C.dev[g], C.evC[g]);

@@ -905,9 +905,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     const float *negt = fusedsc ? G1.as<float>() + (size_t)t * mK : G1.as<float>();
                     if (!fusedsc) TRY(xht(V.as<float>(), H, t, G1.as<float>()));                 // neg = V * Hs'
                     TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
-                    NMFX_HIP(hipMemcpyAsync(Wt, W0t, mK * 4, hipMemcpyDeviceToDevice, st));
-                    TRY(mu_plain(st, Wt, negt, G2.as<float>(), (long)mK));                           // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261
-                    TRY(axpy_f32(st, (long)mK, -1.0f, W0t, Wt, Wnew));                               // dW = W_t - W0_t
+                    TRY(mu_plain_diff(st, W0t, negt, G2.as<float>(), (long)mK, Wt, Wnew));           // W_t = W0_t .* (neg ./ max(pos, eps)), dW = W_t - W0_t   cnmfsc.m:261 (one launch)
                     if (fusedsc) { TRY(vhat_update_fused(Wnew, H, t)); continue; }                   // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     g.M = m; g.N = n; g.Kc = K;

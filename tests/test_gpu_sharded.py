@@ -852,3 +852,24 @@ def test_bench_self_launches_two_ranks(gpu_lib, workload):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["all_ranks_same_path"] and out["value"] > 0
     assert out["cost_monotone"] and len(out["per_rank_ms_per_step"]["all"]) == 2
+
+
+def test_engine_without_the_transposed_copy_of_V(gpu_lib):
+    """nmfx_engine_desc.flags bit 0 / Engine(no_vt=True): the euclidean fused path without V' (what every rank falls back to TOGETHER when one workspace does not
+    fit): smaller workspace, same kernels' results to rounding, cost vector within the contract of the run with the copy."""
+    import torch
+    from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
+    m, n, K = 512, 2048, 64
+    V, W0, H0 = synth(m, n, K)
+    out = []
+    for no_vt in (False, True):
+        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence="euclidean", use_dist=False, no_vt=no_vt)
+        assert e.path_kind == 1 and (int(e.desc.flags) & 1) == (1 if no_vt else 0)
+        e.init()
+        cost = torch.zeros(6, dtype=torch.float64, device="cuda:0")
+        e.iterate(6, cost)
+        torch.cuda.synchronize()
+        out.append((e.W.double().cpu().numpy(), e.H.double().cpu().numpy(), cost.cpu().numpy(), e.workspace.numel()))
+        e.close()
+    assert out[1][3] < out[0][3] - 4 * m * n + 4096                     # the copy (m*n floats) is what the flag gives back
+    assert rel_fro(out[1][0], out[0][0]) < 2e-6 and rel_fro(out[1][1], out[0][1]) < 2e-6 and rel_fro(out[1][2], out[0][2]) < 1e-7
