@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int MF = FUNC == 8 ? 3 : (FUNC == 10 ? 1 : FUNC);   // the element map
     static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
+    // element maps that never look at V (1./S, S.^(a+b-1)): no V loads are issued at all.  They must not merely be left unused: hipcc drops dead loads, and the
+    // tile-top wait below counts on exactly 32 V loads standing behind the DMA rows in the in-order counter -- with fewer, `vmcnt(32)` returns before the rows
+    // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
+    constexpr bool NO_V = FUNC == 12 || FUNC == 14;
     // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     };
     // piece i of 16: D_RC two dwords (columns c0 + 32*jb + {(reg&3) + 8*(reg>>2)}), else half of the 8 float4 (one per even i)
     auto load_d_piece = [&](const __amdgpu_buffer_rsrc_t srd, int t, int i) {
-        if ((PROBE & 4) || FUNC == 7) return;
+        if ((PROBE & 4) || FUNC == 7 || NO_V) return;
         if (D_RC) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
             // EARLY: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
             if (EARLY) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            else if (NEED_S && !(PROBE & 4)) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (NEED_S && !(PROBE & 4) && !NO_V) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
         }
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             const int sl = reg & 1;
             if (PROBE & 2) { if (u == 0) asm volatile("" : "+v"(sacc[jb][reg])); return; }
             if (FUNC == 7) return;                            // the raw partial S is what gets stored
-            const float v = d[jb * 16 + reg];
+            const float v = NO_V ? 0.0f : d[jb * 16 + reg];
             const bool live = !RAG || (32 * jb + (reg & 3) + 8 * (reg >> 2)) < cvh;   // streamed index inside the matrix
             if (FUNC == 4) {                                  // IS: B = 1./S, A = V./S.^2, cost terms q - ln(q) with q = V./S (the -1 per element: caller)
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
