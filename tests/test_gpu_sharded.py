@@ -873,3 +873,41 @@ def test_engine_without_the_transposed_copy_of_V(gpu_lib):
         e.close()
     assert out[1][3] < out[0][3] - 4 * m * n + 4096                     # the copy (m*n floats) is what the flag gives back
     assert rel_fro(out[1][0], out[0][0]) < 2e-6 and rel_fro(out[1][1], out[0][1]) < 2e-6 and rel_fro(out[1][2], out[0][2]) < 1e-7
+
+
+def _background_load(stop_after_s):
+    """a second process keeping the GPU busy with its own factorisations (different kernels, different timing) for a while"""
+    import time
+    import nmf_toolbox_amd as A
+    V, W0, H0 = synth(512, 2048, 96)
+    t0 = time.time()
+    while time.time() - t0 < stop_after_s:
+        A.nmf(V, 96, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=20, tolerance=1e-300))
+        A.nmf(V, 96, dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=20, tolerance=1e-300))
+
+
+def test_run_to_run_determinism_under_concurrent_load(gpu_lib):
+    """Same inputs => bit-identical outputs, also while ANOTHER process shares the GPU and shifts every timing: three shards on one device (ragged 427 / 427 / 426
+    columns) for the paths whose tiles are filled by LDS-DMA behind counted waits -- KL, euclidean (Gram-form cost), IS with the dual-map kernel (K = 96) and as two
+    single-map passes (K = 256), KL cnmf with halos.  This is the condition under which round 4 found the functor-12 / 14 race (a tile read before its DMA rows had
+    landed: right most of the time when nothing else ran)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    bg = ctx.Process(target=_background_load, args=(45.0,))
+    bg.start()
+    try:
+        m, n = 384, 1280
+        cases = [("nmf", "kl", 256, 1), ("nmf", "euclidean", 128, 1), ("nmf", "is", 96, 1), ("nmf", "is", 256, 1), ("cnmf", "kl", 64, 4)]
+        for alg, div, K, T in cases:
+            V, W0, H0 = synth(m, n, K, T=T if alg == "cnmf" else None)
+            cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-300, W_sparsity=0.01, nmfx_gpus=[0, 0, 0])
+            run = (lambda: gpu_lib.cnmf(V, K, T, cfg)) if alg == "cnmf" else (lambda: gpu_lib.nmf(V, K, cfg))
+            first = run()
+            for rep in range(7):
+                again = run()
+                assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1]) and np.array_equal(again[2], first[2]), (alg, div, K, rep)
+    finally:
+        bg.join(timeout=120)
+        if bg.is_alive():
+            bg.terminate()
+    assert bg.exitcode == 0
