@@ -361,6 +361,10 @@ def main():
                     help="engine: device-resident phase API (the metric).  blocking: ONE call of the host-buffer entry point a MATLAB user makes "
                          "(nmf.m:1 / cnmf.m:1) on float64 host arrays -- prints ingest_s / iterate_s / egress_s / GBps_h2d, not the metric")
     ap.add_argument("--host-dtype", default="f64", choices=["f64", "f32"], help="--api blocking: precision of the host arrays")
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="device spin-up before the W warm-up steps: the W-step partial of the engine (it changes neither W nor H) is launched untimed until this much "
+                         "wall time has passed, so that the warm-up and the timed region run at the sustained clock, not on the ramp from idle (rocm-smi: 1.36 -> 2.39 GHz over "
+                         "the first ~0.1 s; a 20-step run of a 1.2 ms iteration read 7 %% low without it).  0 = off")
     ap.add_argument("--h-sparsity", type=float, default=0.5, help="c5: Hoyer sparseness target of the rows of H (nmfsc.m:102-110)")
     args = ap.parse_args()
 
@@ -449,6 +453,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    spun_ms, spun_calls = 0.0, 0
+    if args.spinup_ms > 0:
+        t_sp = time.perf_counter()
+        while (time.perf_counter() - t_sp) * 1e3 < args.spinup_ms:
+            for _ in range(4):
+                eng.wstep_partial()          # reads V, W, H; writes only `packed` (and the engine's lagged-cost scratch): the factors do not move
+            torch.cuda.synchronize()
+            spun_calls += 4
+        spun_ms = (time.perf_counter() - t_sp) * 1e3
     eng.iterate(args.warmup, costs)
     sync()
     eng.profile(0 if args.no_profile else 2)   # event pairs around the MFMA launch groups only: bracketing the small kernels too costs 0.4 % at N = 1, 4 % on an 8-GPU shard
@@ -545,6 +558,7 @@ def main():
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,
         }
+        out["spinup"] = {"ms": round(spun_ms, 1), "wstep_partial_launches": spun_calls, "note": "untimed, before the warm-up steps; W and H untouched"}
         out["world_size_seen"] = int(dist.get_world_size()) if (world > 1 or force_dist) else 1
         if rank_info:
             ms = [1e3 * r[0] / args.steps for r in rank_info]
