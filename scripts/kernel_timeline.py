@@ -18,6 +18,6 @@ t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%9.1f  +%6.1f gap  %8.1f us  %s  grid %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r["Kernel_Name"][:90], r.get("Grid_Size", "")))
+    print("%9.1f  +%6.1f gap  %8.1f us  %s  grid %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r["Kernel_Name"][:90], "x".join(str(r[k]) for k in r if k.lower().startswith("grid"))))
     prev_end = e
 print("period %.1f us" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
