@@ -197,6 +197,7 @@ def bench_nmfsc(args, torch, dist, dev, world, rank, force_dist):
             "effective_tflops": round((5.0 + float(np.mean(tries))) * f_mnk * world * its / 1e12, 3),
             "cost_first_last": [float(c1[0]), float(c1[-1])], "cost_monotone": bool(np.all(np.diff(c1) <= 0)),
             "roofline": roof, "projfunc": pj,
+            "world_size_seen": int(dist.get_world_size()) if (world > 1 or force_dist) else 1,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
