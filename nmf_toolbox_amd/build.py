@@ -99,10 +99,13 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
             # the same driver against the NORMAL library (glibc's MALLOC_CHECK_ instead of ASan), and the microscope tests/host_asan/probe.cpp against both
             rp = "-Wl,-rpath," + HERE + ":" + ":".join(([_torch_lib_dir()] if _torch_lib_dir() else []) + ["/opt/rocm/lib"])
             d = os.path.dirname(drv_src)
+            have_plain = os.path.exists(OUT)   # (the normal library is built by build() without --sanitize)
             for c in (["g++", "-std=c++17", "-O1", "-g", "-I", INC, drv_src, "-o", drv + "_plain", "-L" + HERE, "-lnmfx", rp, "-lpthread"],
                       ["g++", "-std=c++17", "-O1", "-I", INC, os.path.join(d, "probe.cpp"), "-o", os.path.join(d, "probe_plain"), "-L" + HERE, "-lnmfx", rp],
                       ["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=function", "-I", INC,
                        os.path.join(d, "probe.cpp"), "-o", os.path.join(d, "probe_asan"), "-L" + HERE, "-lnmfx_asan", rp]):
+                if "-lnmfx" in c and not have_plain:
+                    continue
                 if verbose:
                     print(" ".join(c), flush=True)
                 subprocess.check_call(c)
