@@ -76,6 +76,26 @@ while time.time() - t0 < budget:
         if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.05), float(rs.rand() * 0.05)
         ref = O.nmf(V, K, cfg); got = A.nmf(V, K, cfg)
         tag = (kind, m, n, K, div, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
+    elif kind == "dual2":      # round 4: IS / alpha-beta with 192 < K <= 256 as two single-map passes per half-iteration (any K in between through the padding),
+        K = int(rs.choice([193, 200, 224, 225, 240, 250, 256]))   # one GPU or ragged column shards, sources / sparsity / fixed factors
+        m, n = int(rs.randint(64, 500)), int(rs.randint(200, 1500))
+        div = str(rs.choice(["is", "ab"]))
+        V, W0, H0 = synth(m, n, K)
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=int(rs.randint(1, 7)), tolerance=1e-300)
+        if div == "ab": cfg["alpha"], cfg["beta"] = [(0.5, 1.5), (2.0, -0.5), (1.0, 0.5), (1.5, 0.2)][rs.randint(4)]
+        if rs.rand() < 0.5: cfg["W_sparsity"], cfg["H_sparsity"] = float(rs.rand() * 0.05), float(rs.rand() * 0.05)
+        r = rs.rand()
+        if r < 0.15: cfg["W_fixed"] = True
+        elif r < 0.3: cfg["H_fixed"] = True
+        Ks = K
+        if rs.rand() < 0.25:
+            k1 = int(rs.randint(1, K)); Ks = [k1, K - k1]
+            cfg["W_init"] = [W0[:, :k1], W0[:, k1:]]; cfg["H_init"] = [H0[:k1], H0[k1:]]
+            cfg["W_fixed"] = [bool(rs.rand() < 0.5), False]; cfg["H_sparsity"] = [0.0, 0.03]; cfg["W_sparsity"] = 0.0; cfg.pop("H_fixed", None)
+        extra = {}
+        if rs.rand() < 0.4 and n >= 400: extra["nmfx_gpus"] = [0] * int(rs.randint(2, 5))
+        ref = O.nmf(V, Ks, cfg); got = A.nmf(V, Ks, dict(cfg, **extra))
+        tag = (kind, m, n, K, div, extra, {k: v for k, v in cfg.items() if k not in ("W_init", "H_init")})
     elif kind == "multi_edge":   # the blocking multi-GPU call on awkward geometry: tiny and uneven shards, ragged m, any K, nmf / cnmf / lnmf
         N = int(rs.randint(2, 9))
         alg = str(rs.choice(["nmf", "cnmf", "lnmf"]))
@@ -165,7 +185,7 @@ while time.time() - t0 < budget:
     fin = same_len and np.all(np.isfinite(ref[2])) and np.linalg.norm(ref[2]) > 0
     e = dict(W=rel_fro(cat(got[0]), cat(ref[0])), H=rel_fro(cat(got[1]), cat(ref[1])), cost=(rel_fro(got[2], ref[2]) if fin else (0.0 if same_len else 1.0)))
     for k in worst: worst[k] = max(worst[k], e[k])
-    lim_c = 1e-5 if ((kind == "multi_nmf" and tag[4] == "is") or kind == "is_wide" or (kind == "multi_edge" and tag[6] == "is")) else 1e-6
+    lim_c = 1e-5 if ((kind == "multi_nmf" and tag[4] == "is") or kind in ("is_wide", "dual2") or (kind == "multi_edge" and tag[6] == "is")) else 1e-6
     if not (e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= lim_c and tries_ok):
         bad.append((tag, e, tries_ok)); print("BAD", tag, e, "tries_ok", tries_ok, flush=True)
 print("seed", seed, "cases", counts, "worst", worst, "bad", len(bad))
