@@ -117,3 +117,16 @@ def test_bench_self_launch_starts_ranks_without_a_launcher():
     assert r.returncode != 0
     # torchrun SIGTERMs the other rank as soon as one has failed, so the message is there once or twice; its report names a rank > 0
     assert "bench.py needs an MI355X" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-1500:]
+
+
+def test_pmc_traffic_stamp_matches_kernel_sources():
+    """profiles/pmc_traffic.json feeds `roofline.traffic` of the bench line and is measured in separate rocprofv3 --pmc passes: it is stamped with the hash of
+    the kernel sources it was measured on, bench.py withholds the figure when the tree's hash differs -- and this test keeps a tree from being committed in that
+    state (re-run scripts/pmc_passes.sh, update the numbers, python profiles/pmc_stamp.py)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert pm.get("_kernel_sources_sha16") == bench.kernel_sources_sha16(), "profiles/pmc_traffic.json is stale: the kernel sources changed since the PMC passes"
+    got, note = bench.pmc_traffic_for("c3")
+    assert got and all(v > 4.4e9 for v in got.values()) and "not measured in this run" in note      # c3: at least the algorithmic 4.45e9 B per launch
