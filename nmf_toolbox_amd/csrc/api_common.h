@@ -160,6 +160,8 @@ struct nmfx_engine {
     int chunk_parts;          // cost partials written by the chunks so far
     float *WT, *slabs, *Pbuf, *GW;
     float *VT;                // euclidean fused path: V' (n x m), built once at init -- the H-step numerator W'*V runs as (V'*W)' on the W-step-form kernel
+                              // (also IS / alpha-beta above K = 192, whose H step runs on it as 4 + 2 m*n*K: engine.hip, dual2)
+    float *VTa;               // ... the transposed copy of V.^alpha next to it (alpha-beta with alpha ~= 1)
     bool use_vt;
     float *WTf;               // cnmf on the fused passes, euclidean: W_flat' (row i = its K*T floats), rebuilt before each Q product
     bool use_vtq;             // ... whose Q = W_flat'*V runs as (V'*W_flat)' on the W-step-form kernel, K-wide column blocks in grid.z

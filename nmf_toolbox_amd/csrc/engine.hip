@@ -4,6 +4,7 @@
 
 namespace nmfx {
 
+inline bool dual2_store() { static const bool on = getenv("NMFX_DUAL2_NO_STORE") == nullptr; return on; }   // dev switch (A/B runs): IS / alpha-beta above K = 192, W step as 4 + 2 instead of 4 + 4 m*n*K
 static thread_local char g_err[1024] = "";
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -90,11 +91,13 @@ Layout layout(nmfx_engine *e, void *ws) {
         Carver f(ws);
         e->Vhat = nullptr;
         e->WT = f.take<float>(mKT);
+        if (e->dual2 && dual2_store()) e->Vhat = f.take<float>(mn);   // the second element map's values of the W step (1./S, S.^(a+b-1)): written by the first pass, contracted by the second
         // row-chunked W steps use more splits on fewer rows: rows*split per launch never exceeds max(nsplit_w, 2) * m / 2
         e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
         e->slabs2 = e->dual ? f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn)) : nullptr;
         e->Valpha = (e->dual && e->div == NMFX_DIV_AB && e->alpha != 1.0) ? f.take<float>((size_t)e->m * e->n) : nullptr;
         e->VT = e->use_vt ? f.take<float>((size_t)e->m * e->n) : nullptr;
+        e->VTa = (e->use_vt && e->dual2 && e->div == NMFX_DIV_AB && e->alpha != 1.0) ? f.take<float>((size_t)e->m * e->n) : nullptr;   // (by the rule that gives Valpha, not by its pointer: the size query carves from a null base)
         e->Gn = f.take<float>(Kn);
         const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
         e->Gp = (euc || e->dual) ? f.take<float>(Kn) : nullptr;
@@ -259,7 +262,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // kernel -- and with it the summation order -- must not depend on how much memory happens to be free (run-to-run and rank-to-rank reproducibility).
     // A caller that cannot allocate the workspace with the copy retries with the flag set (the blocking API does).
     const bool room_vt = (d->flags & 1) == 0;
-    e->use_vt = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !no_vt && room_vt;
+    e->use_vt = e->fused && (e->div == NMFX_DIV_EUCLIDEAN || (e->dual2 && dual2_store())) && !no_vt && room_vt;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
@@ -538,20 +541,24 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
         if (e->Valpha) f.D = e->Valpha + row0;
     }
     if (e->dual2) {
-        // K > 192: numerators (+ the cost terms) and denominators in two passes of one element map each; the second one writes where the dual-map kernel's
-        // second accumulator set would have gone
+        // K > 192: numerators (+ the cost terms) and denominators in two passes; the second one writes where the dual-map kernel's second accumulator set
+        // would have gone.  With the m x n scratch (e->Vhat) the first pass also leaves the second map's values there -- by-products of the first map -- and the
+        // second pass contracts them WITHOUT forming S again (functor 0 on that buffer): 4 + 2 = 6*m*n*K instead of 8
         func = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
+        const bool stb = do_g2 && e->Vhat != nullptr && rows == e->m;
         f.out2 = nullptr;
+        if (stb) f.Rout = e->Vhat;
         {
             Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
-            TRY(launch_fused(e->st, f, split, true, func, do_g2, 0));
+            TRY(launch_fused(e->st, f, split, true, stb ? (func == 11 ? 15 : 16) : func, do_g2, 0));
         }
         if (do_g2) {
             FusedParams g = f;
             g.out = split == 1 ? out2 : e->slabs2;
-            g.cost_partials = nullptr;
+            g.cost_partials = nullptr; g.Rout = nullptr;
+            if (stb) g.D = e->Vhat;
             Scope s(e, TAG_FUSED_W);
-            TRY(launch_fused(e->st, g, split, true, func + 1, true, 0));
+            TRY(launch_fused(e->st, g, split, true, stb ? 0 : func + 1, true, 0));
         }
     } else {
         Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));   // (a conditional launch is a no-op most of the time: not worth an event pair)
@@ -833,7 +840,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     if ((e->use_vt || e->use_vtq || e->klw_vt) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = e->klw_vt = false;
     else if (!e->use_vt && !e->use_vtq && !e->klw_vt) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
         nmfx_engine probe = *e;
-        probe.use_vt = probe.fused && probe.div == NMFX_DIV_EUCLIDEAN && getenv("NMFX_NO_VT") == nullptr;
+        probe.use_vt = probe.fused && (probe.div == NMFX_DIV_EUCLIDEAN || (probe.dual2 && dual2_store())) && getenv("NMFX_NO_VT") == nullptr;
         probe.use_vtq = probe.fusedT && probe.qgemm && probe.hL == 0 && probe.hR == 0 && getenv("NMFX_NO_VT") == nullptr && probe.KT % probe.vtq_block == 0 && fused_supported(probe.vtq_block);
         probe.klw_vt = probe.klw && getenv("NMFX_NO_VT") == nullptr;
         if ((probe.use_vt || probe.use_vtq || probe.klw_vt) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; e->klw_vt = probe.klw_vt; }
@@ -957,6 +964,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
                 TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
                 if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+                if (e->VTa) TRY(transpose_f32(e->st, e->Valpha, e->m, e->n, e->VTa));
             }
             return refresh_w_derived(e);
         }
@@ -1287,7 +1295,22 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         } else if (e->dual) {   // split over the rows of W, or constrainednmf, or K > 192: numerator and denominator slabs, then the generic update
             f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.out2 = e->isplit_h == 1 ? e->Gp : e->slabs2;
             f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
-            if (e->dual2) {   // one element map per pass: W'*A, then W'*B
+            if (e->dual2 && e->Vhat && e->VT && (!e->Valpha || e->VTa)) {
+                // ... as 4 + 2 m*n*K on the transposed copy of V, the W step's scheme with the roles swapped: rows of V' (columns j) stationary, rows of W (the W' copy)
+                // streamed, B' = (1./S)' left in the m x n scratch as n x m, then (B'*W)' without forming S again.  out(k, j) straight into the K x n arrays
+                FusedParams a;
+                memset(&a, 0, sizeof(a));
+                a.X = e->H; a.xs_r = e->K; a.xs_k = 1;
+                a.Y = e->WT; a.D = e->VTa ? e->VTa : e->VT; a.ldd = e->n; a.R = e->n; a.Cn = e->m; a.K = e->K; a.c_per_split = e->cps_h;
+                a.out = f.out; a.slab_stride = f.slab_stride; a.os_r = e->K; a.os_k = 1;
+                a.ab_alpha = (float)e->alpha; a.ab_beta = (float)e->beta; a.inv_exp = 1.0f;
+                a.Rout = e->Vhat;
+                FusedParams b = a;
+                b.D = e->Vhat; b.Rout = nullptr; b.out = f.out2;
+                Scope s(e, TAG_FUSED_H);
+                TRY(launch_fused(e->st, a, e->isplit_h, true, mdiv(e) == NMFX_DIV_IS ? 15 : 16, true, 0));
+                TRY(launch_fused(e->st, b, e->isplit_h, true, 0, true, 0));
+            } else if (e->dual2) {   // one element map per pass: W'*A, then W'*B
                 const int fa = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
                 FusedParams g = f;
                 g.out = f.out2; g.out2 = nullptr;
@@ -1560,12 +1583,13 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
         if (e->fusedT || e->fusedT_kl || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
+        if (e->dual2 && e->Vhat) { *flops = 1.5 * f; *bytes = 4.0 * (2.0 * m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch, averaged over the two of a W step: S + one contraction (+ the m x n store), then one contraction
         if (e->dual2) { *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch (two per W step): S + one contraction
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
-    case TAG_FUSED_H: *flops = (e->dual2 ? 4.0 : e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_H: *flops = ((e->dual2 && e->Vhat && e->VT) ? 3.0 : e->dual2 ? 4.0 : e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
     case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
     }

@@ -38,6 +38,10 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         accumulator set no longer fits the register file (nmf.m:154-164,185-195 have no K limit).  11: A = V./S.^2 (+ the IS cost terms), 12: B = 1./S,
 //         13: A = V.^alpha .* S.^(beta-1) (+ the alpha-beta cost terms; D holds V.^alpha), 14: B = S.^(alpha+beta-1).  Each is the KL pass with another map:
 //         S is formed twice (8*m*n*K per half-iteration instead of 6) but V_hat never reaches HBM
+//       15 / 16 (W-step form, second product on): 11 / 13 that ALSO leave the second map's values B in HBM (p.Rout, m x n) -- 1./S and S.^(alpha+beta-1) are
+//         by-products of the first map, so storing them costs one buffer_store per element -- for a no-first-product pass (functor 0 with D = that buffer) to
+//         contract: 4 + 2 = 6*m*n*K per W step instead of 8.  The stores ride behind the MFMAs of the second product; the LDS-DMA rows of the next tile are
+//         waited for right behind P2, while nothing but loads is in flight (stores and loads do not retire in order relative to each other)
 // PROBE (dev only, timing experiments; results invalid): bit0 no barrier/DMA after tile 0, bit1 no element map, bit2 no V loads
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
@@ -66,11 +70,14 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // tile-top wait below counts on exactly 32 V loads standing behind the DMA rows in the in-order counter -- with fewer, `vmcnt(32)` returns before the rows
     // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
     constexpr bool NO_V = FUNC == 12 || FUNC == 14;
+    constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
+    constexpr int EF = FUNC == 15 ? 11 : (FUNC == 16 ? 13 : FUNC);                   // the element map to run
+    static_assert(!STB || (DO_G2 && D_RC && EPI == 0 && TT == 1), "functors 15 / 16: W-step form with the second product");
     // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S && PROBE == 0;
-    constexpr int NU = (DUAL || FUNC == 11 || FUNC == 13) ? 8 : 4;   // micro-ops per element of the element map
+    constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : 4;   // micro-ops per element of the element map
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // flight instead of draining to vmcnt(0), which exposed one HBM round trip (~2 us of a 13.6 us tile at K = 256) per tile.
             // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
             // EARLY: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
-            if (EARLY) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (EARLY || STB) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             else if (NEED_S && !(PROBE & 4) && !NO_V) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
@@ -237,6 +244,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
         f32x16 sacc2[DUAL ? 2 : 1];                           // the second map's tile (B)
+        float bq[STB ? 2 : 1][STB ? 16 : 1];                  // STB: the second map's values of this tile, on their way to p.Rout
+        const __amdgpu_buffer_rsrc_t rs_b = STB ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000)
+                                                : d_srd_fixed;
         float tc = 0.0f;
         const int cvh = RAG ? tile_rows(t) - 4 * h : 0;       // streamed index 32*jb + (reg&3) + 8*(reg>>2) + 4*h of this tile is real iff its h-free part < cvh
         float es[2], er[2], eq[2];                            // element-map pipeline state: S value, reciprocal / quotient, third temporary
@@ -266,9 +276,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 5) sacc2[jb][reg] = live ? er[sl] : 0.0f;
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
-            } else if (FUNC == 11) {                          // IS, numerators only: A = V./S.^2, cost terms q - ln(q) (functor 4 without its B tile)
+            } else if (EF == 11) {                            // IS, numerators only: A = V./S.^2, cost terms q - ln(q) (functor 4 without its B tile)
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) eq[sl] = v * er[sl];
+                if (STB && u == 2) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = 1./S
                 if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
                 if (u == 4) er[sl] = __builtin_amdgcn_logf(eq[sl]);                  // log2(q)
                 if (u == 5) tc = live ? tc + eq[sl] : tc;
@@ -276,12 +287,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 5 || u == 6) asm volatile("" : "+v"(tc));
             } else if (FUNC == 12) {                          // IS, denominators only: B = 1./S
                 if (u == 0) sacc[jb][reg] = live ? __builtin_amdgcn_rcpf(sacc[jb][reg]) : 0.0f;
-            } else if (FUNC == 13) {                          // alpha-beta, numerators only: A = V.^a .* S.^(b-1), cost terms S.*(A - b/(a+b)*B) (functor 5 without its B tile)
+            } else if (EF == 13) {                            // alpha-beta, numerators only: A = V.^a .* S.^(b-1), cost terms S.*(A - b/(a+b)*B) (functor 5 without its B tile)
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(es[sl]), -3.0e38f, 3.0e38f); }   // log2(S), see functor 5
                 if (u == 1) eq[sl] = ab_e1 * er[sl];
                 if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
                 if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)
                 if (u == 4) { eq[sl] = v * eq[sl]; sacc[jb][reg] = live ? eq[sl] : 0.0f; }
+                if (STB && u == 5) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = S.^(a+b-1)
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
             } else if (FUNC == 14) {                          // alpha-beta, denominators only: B = S.^(a+b-1)
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg) emap_u(1, reg, 0);
         }
         if (DO_G2) {
+            if (STB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA rows (issued under P1) have landed; from here on stores are in flight too
             auto g2_read = [&](int jb, int reg, float (&y)[NKB]) {
                 const float *yrow = Yt + (32 * jb + rowmap(reg, h)) * LDY + l31;
 #pragma unroll
@@ -367,6 +380,14 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     if (jb == 0 && NEED_S) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
                     if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 24 < ROWS_PER_WAVE ? (st + 1) * ROWS_PER_WAVE / 24 : ROWS_PER_WAVE);   // no first product: the DMA rides here, done by step 24
                     if (kb == NKB / 2 && jb == (NEED_S ? 1 : 0)) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4 (no first product: under P3 already)
+                    if (STB && kb == 1 && (jb == 1 || reg >= 8)) {   // the B values: half 0's (mapped under P2) two per step in the second half of P3, half 1's (mapped under P3) one per step of P4
+                        auto put = [&](int j2, int r2) {
+                            const float bv = bq[STB ? j2 : 0][STB ? r2 : 0];
+                            if (row_ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bv), rs_b, d_voff, (int)(p.ldd * (32 * j2 + (r2 & 3) + 8 * (r2 >> 2)) * 4), 0);
+                        };
+                        if (jb == 0) { put(0, 2 * (reg - 8)); put(0, 2 * (reg - 8) + 1); }
+                        else put(1, reg);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (DUAL) {
                         acc2[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr2, acc2[kb], 0, 0, 0);
