@@ -854,16 +854,18 @@ def test_bench_self_launches_two_ranks(gpu_lib, workload):
     assert out["cost_monotone"] and len(out["per_rank_ms_per_step"]["all"]) == 2
 
 
-def test_engine_without_the_transposed_copy_of_V(gpu_lib):
-    """nmfx_engine_desc.flags bit 0 / Engine(no_vt=True): the euclidean fused path without V' (what every rank falls back to TOGETHER when one workspace does not
-    fit): smaller workspace, same kernels' results to rounding, cost vector within the contract of the run with the copy."""
+@pytest.mark.parametrize("div,K", [("euclidean", 64), ("is", 256)])
+def test_engine_without_the_transposed_copy_of_V(gpu_lib, div, K):
+    """nmfx_engine_desc.flags bit 0 / Engine(no_vt=True): the euclidean fused path -- and IS above K = 192, whose H step otherwise runs as 4 + 2 m*n*K on that copy --
+    without V' (what every rank falls back to TOGETHER when one workspace does not fit): smaller workspace, same results to rounding, cost vector within the contract
+    of the run with the copy."""
     import torch
     from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
-    m, n, K = 512, 2048, 64
+    m, n = 512, 2048
     V, W0, H0 = synth(m, n, K)
     out = []
     for no_vt in (False, True):
-        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence="euclidean", use_dist=False, no_vt=no_vt)
+        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence=div, use_dist=False, no_vt=no_vt)
         assert e.path_kind == 1 and (int(e.desc.flags) & 1) == (1 if no_vt else 0)
         e.init()
         cost = torch.zeros(6, dtype=torch.float64, device="cuda:0")
