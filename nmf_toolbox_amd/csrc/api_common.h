@@ -121,6 +121,8 @@ struct nmfx_engine {
     double *cost_dst2;        // fused paths: the finisher of the next lagged cost also writes it here (the caller's cost vector), or nullptr
     bool tail_with_cost;      // fused KL: the finisher also converts rowsum(H) into the fp32 tail of `packed` (W-step partial passes only)
     bool dual;                // fused IS / alpha-beta: packed = [N | P], both contractions of a pass come out of one kernel (func 4 / 5)
+    bool dualz;               // alpha-beta with alpha == 0 (the reference's dual update equations): a `dual2` engine whose passes are functor 17 (S -> S.^beta ./ V ->
+                              // contraction) and functor 0 on V.^(beta-1) (kept in the Valpha slot); any K <= 256; the cost is the reference's +-Inf
     bool dual2;               // ... above K = 192 (a sub-mode of `dual`): the second accumulator set no longer fits, so every pass runs twice with ONE element map
                               // each (func 11 + 12 / 13 + 14): S = W*H is formed twice, V_hat still never reaches HBM
     float *slabs2, *Valpha;   // dual: slabs of the second contraction; alpha-beta with alpha ~= 1: V.^alpha (the kernels' data operand)

@@ -42,7 +42,7 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
-    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 256;   // fused IS / alpha-beta (above K = 192 as two single-map passes)
+    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256;   // fused IS / alpha-beta (above K = 192, and the dual form alpha == 0, in two passes)
     int Kup = (Kt + 31) / 32 * 32;
     // cnmf: the same zero padding opens the fused shift-sum passes to any K below an instantiated (K, T) pair (K = 20, T = 8 runs as (32, 8); K = 20, T = 2 as
     // (64, 2), the smallest pair with that context length)
@@ -330,7 +330,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
     long nmin = n;
     for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
-    const bool dual_ok = (dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && Kt <= 256;
+    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256;
     const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && m >= 64 && nmin >= 64)) && ((m >= 64 && nmin >= 64) || p->path == 2) &&
                      p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;

@@ -91,7 +91,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         Carver f(ws);
         e->Vhat = nullptr;
         e->WT = f.take<float>(mKT);
-        if (e->dual2 && dual2_store()) e->Vhat = f.take<float>(mn);   // the second element map's values of the W step (1./S, S.^(a+b-1)): written by the first pass, contracted by the second
+        if (e->dual2 && !e->dualz && dual2_store()) e->Vhat = f.take<float>(mn);   // the second element map's values of the W step (1./S, S.^(a+b-1)): written by the first pass, contracted by the second
         // row-chunked W steps use more splits on fewer rows: rows*split per launch never exceeds max(nsplit_w, 2) * m / 2
         e->slabs = f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn));
         e->slabs2 = e->dual ? f.take<float>(std::max((size_t)std::max(e->nsplit_w, 2) * mKT, (size_t)e->isplit_h * Kn)) : nullptr;
@@ -247,6 +247,9 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     static const bool no_dual2 = getenv("NMFX_NO_DUAL2") != nullptr;   // dev switch (A/B runs against the materialised path)
     e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && (e->K <= 192 || (e->K <= 256 && !no_dual2));
     e->dual2 = e->dual && e->K > 192;
+    // alpha == 0: the dual update equations (nmf.m:124-128).  Two passes per half-iteration at any K: numerators through S (functor 17), denominators without it
+    e->dualz = e->div == NMFX_DIV_AB && e->alpha == 0 && e->K <= 256 && !no_dual2 && e->algo != 3;
+    if (e->dualz) e->dual = e->dual2 = true;
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
                           e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
     if (d->path == 2 && !eligible && e->algo != 1) {   // cnmf: see the fused shift-sum passes below
@@ -254,7 +257,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         return NMFX_ERR_UNSUPPORTED;
     }
     e->fused = eligible && d->path != 1;
-    if (!e->fused) e->dual = e->dual2 = false;
+    if (!e->fused) e->dual = e->dual2 = e->dualz = false;
     static const bool exact_cost_env = getenv("NMFX_EXACT_COST") != nullptr;   // dev switch (A/B runs): always the explicit residual inside the W-step pass
     e->gram_cost = e->fused && e->div == NMFX_DIV_EUCLIDEAN && !e->dual && !exact_cost_env;
     static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;   // dev switch (A/B runs): H-step numerator on the pipelined GEMM, no transposed copy of V
@@ -262,7 +265,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // kernel -- and with it the summation order -- must not depend on how much memory happens to be free (run-to-run and rank-to-rank reproducibility).
     // A caller that cannot allocate the workspace with the copy retries with the flag set (the blocking API does).
     const bool room_vt = (d->flags & 1) == 0;
-    e->use_vt = e->fused && (e->div == NMFX_DIV_EUCLIDEAN || (e->dual2 && dual2_store())) && !no_vt && room_vt;
+    e->use_vt = e->fused && (e->div == NMFX_DIV_EUCLIDEAN || (e->dual2 && !e->dualz && dual2_store())) && !no_vt && room_vt;
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
@@ -544,11 +547,15 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
         // K > 192: numerators (+ the cost terms) and denominators in two passes; the second one writes where the dual-map kernel's second accumulator set
         // would have gone.  With the m x n scratch (e->Vhat) the first pass also leaves the second map's values there -- by-products of the first map -- and the
         // second pass contracts them WITHOUT forming S again (functor 0 on that buffer): 4 + 2 = 6*m*n*K instead of 8
-        func = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
-        const bool stb = do_g2 && e->Vhat != nullptr && rows == e->m;
+        func = e->dualz ? 17 : (mdiv(e) == NMFX_DIV_IS ? 11 : 13);
+        const bool stb = do_g2 && !e->dualz && e->Vhat != nullptr && rows == e->m;
         f.out2 = nullptr;
         if (stb) f.Rout = e->Vhat;
-        {
+        if (e->dualz) f.D = e->V + row0;   // (the Valpha slot holds V.^(beta-1), the operand of the SECOND pass)
+        if (e->dualz && !do_g2) {
+            // the dual form has no cost to reduce (the reference divides by alpha*beta = 0: the finisher reproduces its +-Inf from the element count alone)
+            NMFX_HIP(hipMemsetAsync(e->cost_partials + e->chunk_parts, 0, sizeof(double) * (size_t)(blocks * split), e->st));
+        } else {
             Scope s(e, do_g2 ? TAG_FUSED_W : TAG_FUSED_COST);
             TRY(launch_fused(e->st, f, split, true, stb ? (func == 11 ? 15 : 16) : func, do_g2, 0));
         }
@@ -557,8 +564,9 @@ nmfx_status fused_wpass_rows(nmfx_engine *e, bool do_g2, long row0, long rows, f
             g.out = split == 1 ? out2 : e->slabs2;
             g.cost_partials = nullptr; g.Rout = nullptr;
             if (stb) g.D = e->Vhat;
+            if (e->dualz) g.D = e->Valpha + row0;
             Scope s(e, TAG_FUSED_W);
-            TRY(launch_fused(e->st, g, split, true, stb ? 0 : func + 1, true, 0));
+            TRY(launch_fused(e->st, g, split, true, (stb || e->dualz) ? 0 : func + 1, true, 0));
         }
     } else {
         Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));   // (a conditional launch is a no-op most of the time: not worth an event pair)
@@ -840,7 +848,7 @@ nmfx_status nmfx_engine_create(const nmfx_engine_desc *d, const float *V, float 
     if ((e->use_vt || e->use_vtq || e->klw_vt) && layout(e, nullptr).total > workspace_bytes) e->use_vt = e->use_vtq = e->klw_vt = false;
     else if (!e->use_vt && !e->use_vtq && !e->klw_vt) {   // ... and the other way round: memory looked tight now, but the workspace was sized with the copy
         nmfx_engine probe = *e;
-        probe.use_vt = probe.fused && (probe.div == NMFX_DIV_EUCLIDEAN || (probe.dual2 && dual2_store())) && getenv("NMFX_NO_VT") == nullptr;
+        probe.use_vt = probe.fused && (probe.div == NMFX_DIV_EUCLIDEAN || (probe.dual2 && !probe.dualz && dual2_store())) && getenv("NMFX_NO_VT") == nullptr;
         probe.use_vtq = probe.fusedT && probe.qgemm && probe.hL == 0 && probe.hR == 0 && getenv("NMFX_NO_VT") == nullptr && probe.KT % probe.vtq_block == 0 && fused_supported(probe.vtq_block);
         probe.klw_vt = probe.klw && getenv("NMFX_NO_VT") == nullptr;
         if ((probe.use_vt || probe.use_vtq || probe.klw_vt) && layout(&probe, nullptr).total <= workspace_bytes) { e->use_vt = probe.use_vt; e->use_vtq = probe.use_vtq; e->klw_vt = probe.klw_vt; }
@@ -963,7 +971,7 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
             if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
                 TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
-                if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+                if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, e->dualz ? (float)(e->beta - 1.0) : (float)e->alpha));   // (dual form: the denominator operand V.^(alpha+beta-1))
                 if (e->VTa) TRY(transpose_f32(e->st, e->Valpha, e->m, e->n, e->VTa));
             }
             return refresh_w_derived(e);
@@ -1311,13 +1319,14 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(launch_fused(e->st, a, e->isplit_h, true, mdiv(e) == NMFX_DIV_IS ? 15 : 16, true, 0));
                 TRY(launch_fused(e->st, b, e->isplit_h, true, 0, true, 0));
             } else if (e->dual2) {   // one element map per pass: W'*A, then W'*B
-                const int fa = mdiv(e) == NMFX_DIV_IS ? 11 : 13;
+                const int fa = e->dualz ? 17 : (mdiv(e) == NMFX_DIV_IS ? 11 : 13);
                 FusedParams g = f;
                 g.out = f.out2; g.out2 = nullptr;
                 f.out2 = nullptr;
+                if (e->dualz) { f.D = e->V; g.D = e->Valpha; }   // numerators from V through S, denominators from V.^(beta-1) without it
                 Scope s(e, TAG_FUSED_H);
                 TRY(launch_fused(e->st, f, e->isplit_h, false, fa, true, 0));
-                TRY(launch_fused(e->st, g, e->isplit_h, false, fa + 1, true, 0));
+                TRY(launch_fused(e->st, g, e->isplit_h, false, e->dualz ? 0 : fa + 1, true, 0));
             } else {
                 Scope s(e, TAG_FUSED_H);
                 TRY(launch_fused(e->st, f, e->isplit_h, false, func, true, 0));

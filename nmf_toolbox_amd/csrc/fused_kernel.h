@@ -38,6 +38,8 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         accumulator set no longer fits the register file (nmf.m:154-164,185-195 have no K limit).  11: A = V./S.^2 (+ the IS cost terms), 12: B = 1./S,
 //         13: A = V.^alpha .* S.^(beta-1) (+ the alpha-beta cost terms; D holds V.^alpha), 14: B = S.^(alpha+beta-1).  Each is the KL pass with another map:
 //         S is formed twice (8*m*n*K per half-iteration instead of 6) but V_hat never reaches HBM
+//       17: the DUAL form of the alpha-beta divergence (alpha == 0; nmf.m:124-128,159-160,190-191): numerators A = V.^(-1) .* S.^beta.  (Its denominators
+//         V.^(beta-1) * H' do not involve S: functor 0 on a precomputed V.^(beta-1).)  No cost terms: the reference's cost divides by alpha*beta = 0
 //       15 / 16 (W-step form, second product on): 11 / 13 that ALSO leave the second map's values B in HBM (p.Rout, m x n) -- 1./S and S.^(alpha+beta-1) are
 //         by-products of the first map, so storing them costs one buffer_store per element -- for a no-first-product pass (functor 0 with D = that buffer) to
 //         contract: 4 + 2 = 6*m*n*K per W step instead of 8.  The stores ride behind the MFMAs of the second product; the LDS-DMA rows of the next tile are
@@ -296,6 +298,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (STB && u == 5) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = S.^(a+b-1)
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+            } else if (FUNC == 17) {                          // alpha-beta, dual form (alpha == 0): A = S.^beta ./ V
+                if (u == 0) er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(sacc[jb][reg]), -3.0e38f, 3.0e38f);   // log2(S), clamped as in functor 5
+                if (u == 1) eq[sl] = __builtin_amdgcn_exp2f(p.ab_beta * er[sl]);                                         // S.^beta
+                if (u == 2) er[sl] = __builtin_amdgcn_rcpf(v);
+                if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
             } else if (FUNC == 14) {                          // alpha-beta, denominators only: B = S.^(a+b-1)
                 if (u == 0) er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(sacc[jb][reg]), -3.0e38f, 3.0e38f);
                 if (u == 1) sacc[jb][reg] = live ? __builtin_amdgcn_exp2f(ab_e2 * er[sl]) : 0.0f;

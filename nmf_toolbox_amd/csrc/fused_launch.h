@@ -62,6 +62,7 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 13: if constexpr (K >= 224 && EPI == 0) return launch_one<K, D_RC, 13, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 12: if constexpr (K >= 224 && EPI == 0 && DO_G2) return launch_one<K, D_RC, 12, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 14: if constexpr (K >= 224 && EPI == 0 && DO_G2) return launch_one<K, D_RC, 14, DO_G2, EPI, RAG>(st, p, nsplit); break;
+    case 17: if constexpr (EPI == 0 && DO_G2) return launch_one<K, D_RC, 17, DO_G2, EPI, RAG>(st, p, nsplit); break;   // alpha-beta dual form (alpha == 0): numerators; any K
     case 15: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 15, DO_G2, EPI, RAG>(st, p, nsplit); break;   // 11 / 13 + the second map's values to p.Rout
     case 16: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 16, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 9: if constexpr (!DO_G2 && D_RC && K <= 128) return launch_one<K, D_RC, 9, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:262 (K = components of one time slice)

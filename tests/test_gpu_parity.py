@@ -262,6 +262,29 @@ def test_nmf_ab_divergence(gpu_lib, alpha, beta):
     _check(gpu_lib.nmf(V, 12, cfg), O.nmf(V, 12, cfg))
 
 
+@pytest.mark.parametrize("beta", [1.0, 2.0, 0.5])
+@pytest.mark.parametrize("m,n,K", [(256, 768, 64), (384, 1024, 256), (321, 515, 100), (128, 640, 12)])
+def test_nmf_ab_dual_form_on_the_fused_kernels(gpu_lib, beta, m, n, K):
+    """alpha == 0 selects the reference's DUAL update equations (nmf.m:124-128,159-160,190-191): numerators (V.^(-1) .* V_hat.^beta) * H' through S = W*H (functor 17),
+    denominators V.^(beta-1) * H' without it, outer exponent 1/beta, and a cost that divides by alpha*beta = 0.  The equations diverge double-exponentially even in
+    float64, so -- as in test_nmf_ab_divergence -- two iterations are what float32 can be held to; the fused path (default), the materialised path and three column
+    shards against the oracle, +-Inf cost pattern included."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    if K % 32 == 0 and m % 128 == 0:
+        import torch
+        from nmf_toolbox_amd.engine import Engine, colmajor_to_torch
+        e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence="ab", alpha=0.0, beta=beta, use_dist=False)
+        assert e.path_kind == 1           # the fused kernels, not the materialised path
+        e.close()
+    cfg = dict(divergence="ab", alpha=0.0, beta=beta, W_init=W0, H_init=H0, maxiter=2, tolerance=1e-12, W_sparsity=0.01)
+    with np.errstate(all="ignore"):
+        ref = O.nmf(V, K, cfg)
+    _check(gpu_lib.nmf(V, K, cfg), ref)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1)), ref)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0, 0, 0])), ref)
+
+
 @pytest.mark.parametrize("alpha,beta", [(0.5, 1.5), (0.0, 1.0)])
 def test_cnmf_ab_divergence(gpu_lib, alpha, beta):
     from oracle import nmf_oracle as O
