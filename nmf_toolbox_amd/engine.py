@@ -156,6 +156,29 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None, tole
     return ran
 
 
+def agree_on_workspace(flags, size_of, alloc, any_rank, release=lambda: None):
+    """Allocate the engine workspace so that EVERY rank ends with the same descriptor flags.  size_of(flags) -> bytes, alloc(bytes) -> buffer (raises an
+    out-of-memory error when it does not fit), any_rank(failed) -> True when the allocation failed on at least one rank (a MAX all-reduce; identity without a
+    process group).  First try with the flags as given; if any rank fails, all ranks drop theirs and retry without the transposed copy of V (flags bit 0).  A second
+    failure anywhere, or a first one with bit 0 already set, is NMFX_ERR_NOMEM on all ranks.  Errors other than out-of-memory propagate.  -> (buffer, flags)"""
+    for attempt in range(2):
+        nbytes = size_of(flags)
+        buf, failed = None, False
+        try:
+            buf = alloc(nbytes)
+        except (MemoryError, RuntimeError) as ex:            # torch.OutOfMemoryError is a RuntimeError
+            if not isinstance(ex, MemoryError) and "out of memory" not in str(ex).lower():
+                raise
+            failed = True
+        if not any_rank(failed):
+            return buf, flags
+        buf = None
+        if attempt == 1 or flags & 1:
+            raise _lib.NmfxError(_lib.NMFX_ERR_NOMEM, "Engine: the workspace (%d bytes) does not fit on a rank, even without the transposed copy of V" % nbytes)
+        release()
+        flags |= 1
+
+
 class Engine:
     """One rank's multiplicative-update engine on HBM-resident V (local column shard), W, H."""
 
@@ -210,26 +233,21 @@ class Engine:
         self.packed = torch.zeros(count.value, dtype=torch.float32, device=self.V.device)
         # the workspace may hold a transposed copy of V (euclidean paths; nmfx_engine_desc.flags bit 0 = without).  If it does not fit HERE, every rank gives it
         # up together: the kernel path -- and the summation order of the replicated W update -- follows from the descriptor, which must be the same everywhere
-        for attempt in range(2):
+        def size_of(flags):
+            d.flags = flags
             _lib.check(self.lib.nmfx_engine_workspace_bytes(C.byref(d), C.byref(nbytes)))
-            failed = 0.0
-            try:
-                self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=self.V.device)
-            except (torch.OutOfMemoryError, RuntimeError) as ex:
-                if "out of memory" not in str(ex).lower():
-                    raise
-                self.workspace, failed = None, 1.0
-            if self.dist is not None:
-                ft = torch.tensor([failed], dtype=torch.float64, device=self.V.device)
-                self.dist.all_reduce(ft, op=self.dist.ReduceOp.MAX, group=group)
-                failed = float(ft.item())
-            if not failed:
-                break
-            self.workspace = None
-            if attempt == 1 or d.flags & 1:
-                raise _lib.NmfxError(_lib.NMFX_ERR_NOMEM, "Engine: the workspace (%d bytes) does not fit on a rank, even without the transposed copy of V" % nbytes.value)
-            torch.cuda.empty_cache()
-            d.flags |= 1
+            return nbytes.value
+
+        def any_rank(failed):
+            if self.dist is None:
+                return failed
+            ft = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=self.V.device)
+            self.dist.all_reduce(ft, op=self.dist.ReduceOp.MAX, group=group)
+            return bool(ft.item())
+
+        self.workspace, d.flags = agree_on_workspace(d.flags, size_of, lambda nb: torch.empty(nb, dtype=torch.uint8, device=self.V.device), any_rank,
+                                                     torch.cuda.empty_cache)
+        size_of(d.flags)
         self.cost_buf = None
         h = C.c_void_p()
         _lib.check(self.lib.nmfx_engine_create(C.byref(d), self.V.data_ptr(), self.W.data_ptr(), self.H.data_ptr(), self.workspace.data_ptr(),

@@ -329,3 +329,93 @@ def test_distributed_projfunc_protocol_matches_projfunc_m():
         its.append(it)
         assert np.allclose(V[k], v, rtol=1e-12, atol=1e-14) and res[0][2][k] == it
     assert len(set(its)) > 1                                              # rows really finished at different rounds
+
+
+def _ws_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nmf_toolbox_amd import _lib
+    from nmf_toolbox_amd.engine import agree_on_workspace
+
+    def any_rank(failed):
+        t = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
+    def run(capacity, flags0=0, err=None):
+        asked, released = [], []
+
+        def alloc(nb):
+            asked.append(nb)
+            if err is not None and rank == 1:
+                raise err
+            if nb > capacity[rank]:
+                raise RuntimeError("HIP out of memory. Tried to allocate %d bytes" % nb)
+            return bytearray(8)
+
+        try:
+            buf, flags = agree_on_workspace(flags0, lambda f: 600 if f & 1 else 1000, alloc, any_rank, lambda: released.append(1))
+            return ("ok", flags, asked, len(released), buf is not None)
+        except _lib.NmfxError as ex:
+            return ("nomem", ex.status, asked, len(released), False)
+        except RuntimeError as ex:
+            return ("raised", str(ex), asked, len(released), False)
+
+    out = [run([2000, 2000]),                 # fits everywhere: flags untouched, one attempt
+           run([2000, 700]),                  # rank 1 is short: BOTH ranks drop the transposed copy and retry
+           run([2000, 500]),                  # rank 1 cannot hold it either way: NOMEM on both ranks
+           run([2000, 700], flags0=1),        # already without the copy and it fits
+           run([2000, 500], flags0=1)]        # already without the copy: no second attempt, NOMEM on both
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_workspace_retry_is_collective():
+    """a rank that cannot hold the transposed copy of V must take every other rank with it -- the kernel path and the summation order of the
+    replicated W update follow from the descriptor flags.  Engine's allocation loop (engine.py::agree_on_workspace) with a fake allocator on two gloo ranks."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ws_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from nmf_toolbox_amd import _lib
+    for rank in (0, 1):
+        fits, short, never, pre, pre_never = res[rank]
+        assert fits == ("ok", 0, [1000], 0, True)
+        assert short == ("ok", 1, [1000, 600], 1, True)                 # same flags, same two attempts on the rank that had room as on the one that had not
+        assert never[:2] == ("nomem", _lib.NMFX_ERR_NOMEM) and never[2] == [1000, 600]
+        assert pre == ("ok", 1, [600], 0, True)
+        assert pre_never[:2] == ("nomem", _lib.NMFX_ERR_NOMEM) and pre_never[2] == [600]
+
+
+def test_workspace_retry_single_process_and_foreign_errors():
+    from nmf_toolbox_amd import _lib
+    from nmf_toolbox_amd.engine import agree_on_workspace
+
+    def alloc_limit(limit):
+        def alloc(nb):
+            if nb > limit:
+                raise MemoryError()
+            return nb
+        return alloc
+
+    same = lambda failed: failed
+    assert agree_on_workspace(0, lambda f: 600 if f & 1 else 1000, alloc_limit(2000), same) == (1000, 0)
+    assert agree_on_workspace(0, lambda f: 600 if f & 1 else 1000, alloc_limit(700), same) == (600, 1)
+    with pytest.raises(_lib.NmfxError) as ei:
+        agree_on_workspace(0, lambda f: 600 if f & 1 else 1000, alloc_limit(100), same)
+    assert ei.value.status == _lib.NMFX_ERR_NOMEM
+
+    def broken(nb):
+        raise RuntimeError("invalid device ordinal")
+
+    with pytest.raises(RuntimeError, match="invalid device ordinal"):      # not an out-of-memory condition: never swallowed, never retried
+        agree_on_workspace(0, lambda f: 1000, broken, same)
