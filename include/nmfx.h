@@ -89,6 +89,11 @@ typedef struct {
                                  (SURVEY 8(e)); cnmf adds T-1 halo columns of H copied between neighbouring devices per iteration, nmfsc
                                  runs one host thread per shard with the sums of its line searches / projfunc reduced over the peers */
     const int32_t *device_ids;/* [n_gpus] HIP ordinals, or NULL = 0 .. n_gpus-1 */
+    int32_t multi_backend;    /* the per-iteration exchange of the packed W-step sums behind nmfx_nmf / nmfx_cnmf / nmfx_lnmf with n_gpus >= 1:
+                                 0 = auto (RCCL -- ncclCommInitAll over device_ids, ONE ncclAllReduce per device and iteration on its stream -- when the
+                                 devices are distinct and librccl can be dlopen'ed, else the peer exchange; NMFX_MULTI_BACKEND=peer|rccl overrides auto),
+                                 1 = peer reduce-scatter + all-gather over xGMI peer mappings (no library; the only one that takes one device named twice),
+                                 2 = RCCL (an error when it cannot run).  With a value != 0, n_gpus == 1 also takes the sharded driver (one shard) */
 } nmfx_problem;
 
 typedef struct {
@@ -179,6 +184,11 @@ nmfx_status nmfx_scale_dev(void *stream, const float *X_dev, int64_t count, doub
  * two pinned buffers), iterating, and moving the results out; and the bytes of host arrays read / written.  Any pointer may be NULL. */
 nmfx_status nmfx_last_call_timing(double *ingest_s, double *iterate_s, double *egress_s, double *host_bytes_in, double *host_bytes_out);
 
+/* the packed exchange of the last blocking multi-GPU call on this thread: mean milliseconds device 0's stream spent in it (hipEvent pairs around the first <= 32
+ * exchanges), how many were timed, and the backend that ran (1 peer, 2 RCCL; 0: no such call) */
+nmfx_status nmfx_last_call_exchange(double *ms_per_exchange, int32_t *exchanges_timed, int32_t *backend);
+/* the RCCL library the backend loads ("" when none can be loaded) and its version code */
+const char *nmfx_rccl_library(int32_t *version);
 const char *nmfx_last_error(void);
 int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */
 int32_t nmfx_version(void);
@@ -283,6 +293,17 @@ nmfx_status nmfx_engine_between_allreduces(nmfx_engine *e, int32_t last);
 /* the same with the read point of a lag-2 engine inside: right after its wstep_finish the cost of the previous iteration is copied (8 bytes, device to
  * device, on the engine's stream) to lag2_cost_dst_dev when that is not NULL -- the wstep_partial that follows may overwrite the engine's cost */
 nmfx_status nmfx_engine_between_allreduces_cost(nmfx_engine *e, int32_t last, double *lag2_cost_dst_dev);
+/* The engine keeps float64 MASTER copies of W and H in its workspace (nmf.m:168-169,199 run in double: the reference's state between iterations is
+ * float64).  Every update reads the master, computes in double and writes both the master and the fp32 array the MFMA passes contract; the fp32 arrays the
+ * caller handed over stay the results.  nmfx_engine_init derives the masters from W / H; a caller that rewrites W or H itself afterwards (a restore after
+ * a stop, a halo refresh is NOT one: halos are read-only operands) calls nmfx_engine_sync_master.  The pointers (W64: m x K*T, H64: K x n_local, both
+ * column-major, device) are NULL for constrainednmf's H, which is a gather of Z. */
+nmfx_status nmfx_engine_sync_master(nmfx_engine *e);
+/* nmfx_engine_init with the caller's float64 initial factors (DEVICE arrays: W_init64 m x K*T, H_init64 K x n_local -- the shard's own columns; either may be
+ * NULL = take the fp32 array).  The masters start from them exactly and the fp32 arrays are rewritten as their images: what the blocking calls do with
+ * float64 host buffers, so that MATLAB's doubles are not rounded on the way in (nmf.m:130-139 normalises in double). */
+nmfx_status nmfx_engine_init_f64(nmfx_engine *e, const double *W_init64_dev, const double *H_init64_dev);
+nmfx_status nmfx_engine_master_ptrs(nmfx_engine *e, double **W64_dev, double **H64_dev);
 /* convenience for one GPU: `iters` full iterations, costs written to the DEVICE array dev_cost_out[iters] (may be NULL) */
 nmfx_status nmfx_engine_iterate(nmfx_engine *e, int32_t iters, double *dev_cost_out);
 
@@ -315,6 +336,11 @@ nmfx_status nmfx_gemm_f32(void *stream, int32_t opA, int32_t opB, int64_t M, int
                           const float *A, const float *A2, int64_t lda, int32_t proA, const float *B,
                           const float *B2, int64_t ldb, int32_t proB, float *C, int64_t ldc, int32_t accumulate,
                           void *workspace, size_t workspace_bytes);
+/* C (M x N) = A (M x Kc) * B (Kc x N) accumulated in float64 on the fp64 matrix core: A(i, k) = A[i + lda*k] given as float64 (A64) or fp32 (A32),
+ * B(k, j) = B[k + ldb*j] likewise, C[i + ldc*j] written as float64 and / or fp32 (either may be NULL).  What the engine runs nmf.m:150's V_hat*H' with, in
+ * the Gram form W*(H*H'), from the float64 master copy of W. */
+nmfx_status nmfx_gemm64(void *stream, int64_t M, int64_t N, int64_t Kc, const double *A64, const float *A32, int64_t lda, const double *B64,
+                        const float *B32, int64_t ldb, double *C64, float *C32, int64_t ldc);
 
 #ifdef __cplusplus
 }

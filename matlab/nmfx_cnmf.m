@@ -50,6 +50,7 @@ if ~isfield(config, 'tolerance') || config.tolerance <= 0, config.tolerance = 1e
 opts.divergence = dv; opts.alpha = config.alpha; opts.beta = config.beta;
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
 if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end   % extension: column shards over several GPUs
+if isfield(config, 'nmfx_multi_backend'), opts.multi_backend = double(config.nmfx_multi_backend); end   % extension: 0 auto | 1 peer exchange | 2 RCCL all-reduce
 K_s = int32(cell2mat(num_basis_elems(:)'));
 W_all = cat(2, config.W_init{:});            % cell2mat(1 x S) of m x K_s x T tensors: along dimension 2
 [Wa, Ha, cost] = nmfx_mex('cnmf', double(V), double(W_all), double(cell2mat(config.H_init)), K_s, T, opts);

@@ -20,5 +20,6 @@ opts.divergence = 1;                                   % KL: the only cost lnmf 
 opts.W_fixed = uint8(logical(config.W_fixed)); opts.H_fixed = uint8(logical(config.H_fixed));
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
 if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end   % extension: column shards over several GPUs
+if isfield(config, 'nmfx_multi_backend'), opts.multi_backend = double(config.nmfx_multi_backend); end   % extension: 0 auto | 1 peer exchange | 2 RCCL all-reduce
 [W, H, cost] = nmfx_mex('lnmf', double(V), double(config.W_init), double(config.H_init), int32(K), 1, opts);
 end

@@ -93,6 +93,7 @@ static void factorise(const char *algo, int nlhs, mxArray *plhs[], int nrhs, con
     p.tolerance = opt_d(o, "tolerance", 1e-3);
     p.device = (int32_t)opt_d(o, "device", 0);
     p.path = (int32_t)opt_d(o, "path", 0);
+    p.multi_backend = (int32_t)opt_d(o, "multi_backend", 0);   /* 0 auto | 1 peer exchange | 2 RCCL (device_ids) */
     p.sc_W_sparsity = opt_d(o, "sc_W_sparsity", 0.0);
     p.sc_H_sparsity = opt_d(o, "sc_H_sparsity", 0.0);
     if (p.maxiter < 1) FAIL("value", "maxiter must be positive (the .m wrapper applies the reference default)");

@@ -46,6 +46,7 @@ if ~isfield(config, 'tolerance') || config.tolerance <= 0, config.tolerance = 1e
 opts.divergence = dv; opts.alpha = config.alpha; opts.beta = config.beta;
 opts.maxiter = config.maxiter; opts.tolerance = config.tolerance;
 if isfield(config, 'nmfx_device_ids'), opts.device_ids = int32(config.nmfx_device_ids); end
+if isfield(config, 'nmfx_multi_backend'), opts.multi_backend = double(config.nmfx_multi_backend); end   % extension: 0 auto | 1 peer exchange | 2 RCCL all-reduce
 K_s = int32(cell2mat(num_basis_elems(:)'));
 [Wa, Ha, cost] = nmfx_mex('nmf', double(V), cell2mat(config.W_init), cell2mat(config.H_init), K_s, 1, opts);
 edges = [0, cumsum(double(K_s))];

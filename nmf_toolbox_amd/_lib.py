@@ -25,7 +25,7 @@ EXPORTS = [
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
     "nmfx_engine_between_allreduces", "nmfx_engine_between_allreduces_cost", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing", "nmfx_sc_iteration_seconds", "nmfx_engine_cost_lag", "nmfx_engine_sumvv_local", "nmfx_engine_sumvv_set_global",
-    "nmfx_minmax_dev", "nmfx_scale_dev",
+    "nmfx_minmax_dev", "nmfx_scale_dev", "nmfx_gemm64", "nmfx_engine_sync_master", "nmfx_engine_master_ptrs", "nmfx_engine_init_f64", "nmfx_last_call_exchange", "nmfx_rccl_library",
 ]
 
 
@@ -45,6 +45,7 @@ class Problem(C.Structure):
         ("maxiter", C.c_int32), ("tolerance", C.c_double), ("device", C.c_int32),
         ("sc_W_sparsity", C.c_double), ("sc_H_sparsity", C.c_double), ("path", C.c_int32),
         ("sc_stepsize_H0", C.c_double), ("sc_stepsize_W0", C.c_double), ("sc_resume", C.c_int32), ("n_gpus", C.c_int32), ("device_ids", C.c_void_p),
+        ("multi_backend", C.c_int32),
     ]
 
 
@@ -133,6 +134,13 @@ def load():
     lib.nmfx_engine_sumvv_set_global.argtypes = [C.c_void_p, C.c_void_p]
     lib.nmfx_minmax_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.nmfx_scale_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
+    lib.nmfx_gemm64.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.nmfx_engine_sync_master.argtypes = [C.c_void_p]
+    lib.nmfx_last_call_exchange.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.nmfx_rccl_library.restype = C.c_char_p
+    lib.nmfx_rccl_library.argtypes = [C.POINTER(C.c_int32)]
+    lib.nmfx_engine_init_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.nmfx_engine_master_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = lib
     return lib
 

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libnmfx.so")
-SOURCES = ["fused_cnmf_a.hip", "fused_cnmf_b.hip", "fused_cnmf_c.hip", "fused_cnmf_e.hip", "fused_cnmf_d.hip", "fused_cnmf_g.hip", "fused_cnmf_f.hip", "gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "small_mm.hip", "engine.hip", "host_io.hip", "blocking.hip", "sc.hip", "multi_sc.hip"]
+SOURCES = ["fused_cnmf_a.hip", "fused_cnmf_b.hip", "fused_cnmf_c.hip", "fused_cnmf_e.hip", "fused_cnmf_d.hip", "fused_cnmf_g.hip", "fused_cnmf_f.hip", "gemm_pipe_edge.hip", "gemm_pipe.hip", "gemm.hip", "fused_k224_256.hip", "fused_rag_k224_256.hip", "fused_k128_192.hip", "fused_rag_k128_192.hip", "fused_k32_96.hip", "fused_rag_k32_96.hip", "fused.hip", "aux.hip", "projfunc.hip", "small_mm.hip", "gemm64.hip", "engine.hip", "host_io.hip", "blocking.hip", "sc.hip", "sc64.hip", "multi_sc.hip", "rccl_backend.hip"]
 ARCH = "gfx950"
 
 
@@ -35,6 +35,23 @@ def _torch_lib_dir():
     return None
 
 
+def _deps(src, incdirs, seen=None):
+    """the file and every header it reaches through #include "..." (so that touching api_common.h does not recompile the 20 kernel-only translation units)"""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    with open(src) as f:
+        for name in re.findall(r'^\s*#\s*include\s*"([^"]+)"', f.read(), re.M):
+            for d in [os.path.dirname(src)] + incdirs:
+                cand = os.path.join(d, name)
+                if os.path.exists(cand):
+                    _deps(cand, incdirs, seen)
+                    break
+    return seen
+
+
 def _newer(src_list, target):
     if not os.path.exists(target):
         return True
@@ -46,7 +63,6 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
     """sanitize: the HOST pass of every translation unit with -fsanitize=address,undefined (device code objects unchanged: GPU ASan is not available on
     this pool) into libnmfx_asan.so + the campaign driver tests/host_asan/fuzz_multi -- test infrastructure, never loaded by the package"""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(INC, "nmfx.h"), os.path.abspath(__file__)]   # + this file: the flags live here
     objdir = os.path.join(CSRC, "_obj_asan" if sanitize else "_obj")
     out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else OUT
     # (-g / -fno-omit-frame-pointer for the HOST pass only: handed to the device pass as well they change the gfx950 code objects -- frame pointer, CFI spills --
@@ -59,7 +75,7 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if force or _newer([src] + hdrs, obj):
+        if force or _newer(sorted(_deps(src, [CSRC, INC])) + [os.path.abspath(__file__)], obj):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed"] + san + [
                    "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if os.path.basename(src).startswith("fused_"):

@@ -104,6 +104,10 @@ struct nmfx_engine {
     hipStream_t st;
     const float *V;
     float *W, *H, *packed;
+    // float64 master copies (workspace): the state between iterations is double, as in the reference (nmf.m:168-169,199); W / H are their fp32 images, the
+    // operands of the MFMA passes and the caller's results.  H64 covers the shard's own columns (halos are read-only operands); nullptr for constrainednmf's
+    // H (a gather of Z).  P64: W*(H*H') of the euclidean Gram paths in float64 (gemm64.hip)
+    double *W64, *H64, *P64;
     int rank0;
     bool any_lamW, any_lamH;
     // workspace
@@ -160,7 +164,7 @@ struct nmfx_engine {
     long cps_w, cps_h;        // streamed extent per split (multiples of 64; the last split may be shorter)
     int w_chunks;             // row chunks of the last W-step partial: packed = [chunk 0 (m/c x K) | chunk 1 | ... | tail]
     int chunk_parts;          // cost partials written by the chunks so far
-    float *WT, *slabs, *Pbuf, *GW;
+    float *WT, *slabs, *GW;
     float *VT;                // euclidean fused path: V' (n x m), built once at init -- the H-step numerator W'*V runs as (V'*W)' on the W-step-form kernel
                               // (also IS / alpha-beta above K = 192, whose H step runs on it as 4 + 2 m*n*K: engine.hip, dual2)
     float *VTa;               // ... the transposed copy of V.^alpha next to it (alpha-beta with alpha ~= 1)
@@ -212,7 +216,8 @@ nmfx_status download(hipStream_t st, const float *dev, int dtype, void *host, si
 void host_minmax(const void *host, int dtype, size_t count, double *vmin, double *vmax);
 void staging_quiesce();   // the pinned staging buffers hold no reference to an event of a stream that is about to be handed back (host_io.hip)
 // per-thread account of the last blocking call (nmfx_last_call_timing)
-struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0; };
+struct IoStats { double ingest_s = 0, iterate_s = 0, egress_s = 0, h2d_bytes_host = 0, h2d_bytes_pcie = 0, d2h_bytes_host = 0;
+                 double exchange_ms = 0; int exchanges_timed = 0, exchange_backend = 0; };   // multi-GPU calls: the packed exchange (nmfx_last_call_exchange)
 IoStats &io_stats();
 nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool nmfsc, bool need_H_init = true);
 // Streams and events of the single-process multi-GPU drivers come out of a process-wide pool and go back to it, never destroyed: a MATLAB session calls
@@ -222,7 +227,15 @@ nmfx_status pool_stream(int device, hipStream_t *st);
 nmfx_status pool_event(int device, hipEvent_t *ev);
 void unpool_stream(int device, hipStream_t st);
 void unpool_event(int device, hipEvent_t ev);
+nmfx_status pool_event_timed(int device, hipEvent_t *ev);   // the same with timing enabled (hipEventElapsedTime)
+void unpool_event_timed(int device, hipEvent_t ev);
 nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r);   // multi_sc.hip
+// RCCL behind the blocking multi-GPU calls, dlopen'ed (rccl_backend.hip)
+bool rccl_usable(const int *devs, int n, std::string *why);
+nmfx_status rccl_comms(const int *devs, int n, void **comms_out);
+nmfx_status rccl_allreduce_f32(void *const *comms, const int *devs, hipStream_t const *streams, float *const *bufs, int n, size_t count);
+bool nmfsc_f64_eligible(const nmfx_problem *p);                       // sc64.hip: small problems run nmfsc.m in float64 end to end
+nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r);
 void sc_thread_cleanup();                                              // sc.hip
 
 }  // namespace nmfx

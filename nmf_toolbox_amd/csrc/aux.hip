@@ -30,22 +30,23 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 __global__ void reduce_slabs_kernel(const float *slabs, int nslab, long stride, long count, float *out, int accumulate) {
     long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (idx + 3 < count && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0 && (stride & 3) == 0) {
-        float4 s = *reinterpret_cast<const float4 *>(slabs + idx);
+        const float4 s0 = *reinterpret_cast<const float4 *>(slabs + idx);
+        double sx = s0.x, sy = s0.y, sz = s0.z, sw = s0.w;   // the slabs are summed in double, in slab order (deterministic)
         for (int z = 1; z < nslab; ++z) {
             float4 t = *reinterpret_cast<const float4 *>(slabs + z * stride + idx);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            sx += t.x; sy += t.y; sz += t.z; sw += t.w;
         }
         if (accumulate) {
             float4 o = *reinterpret_cast<float4 *>(out + idx);
-            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            sx += o.x; sy += o.y; sz += o.z; sw += o.w;
         }
-        *reinterpret_cast<float4 *>(out + idx) = s;
+        *reinterpret_cast<float4 *>(out + idx) = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
     } else {
         for (long e = idx; e < idx + 4 && e < count; ++e) {
-            float s = slabs[e];
+            double s = slabs[e];
             for (int z = 1; z < nslab; ++z) s += slabs[z * stride + e];
             if (accumulate) s += out[e];
-            out[e] = s;
+            out[e] = (float)s;
         }
     }
 }
@@ -257,6 +258,22 @@ nmfx_status col_reduce(hipStream_t st, const float *X, long rows, long ld, int n
     return NMFX_OK;
 }
 
+// the same over float64 columns (the master copy of W): mode 0 sum, 1 sum of squares, 2 sum of |x|
+__global__ __launch_bounds__(256) void col_reduce64_kernel(const double *X, long rows, long ld, int mode, double *out) {
+    __shared__ double red[4];
+    const double *x = X + ld * blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < rows; i += 256) { const double v = x[i]; s += mode == 0 ? v : (mode == 1 ? v * v : fabs(v)); }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+nmfx_status col_reduce64(hipStream_t st, const double *X, long rows, long ld, int ncols, int mode, double *out) {
+    if (ncols <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(col_reduce64_kernel, dim3(ncols), dim3(256), 0, st, X, rows, ld, mode, out);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // out[c] = sum_i X[i + ld*c].^e in fp64 (alpha-beta cost constant sum(V.^(alpha+beta)), nmf.m:214); MATLAB power semantics for e in {0, 1}
 __global__ __launch_bounds__(256) void col_reduce_pow_kernel(const float *X, long rows, long ld, float e, double *out) {
     __shared__ double red[4];
@@ -360,6 +377,66 @@ size_t row_reduce_scratch_bytes(int rows) { return sizeof(double) * (size_t)RR_B
 // ---- W update: one workgroup per column c = k + K*t -------------------------------------------
 //   dn = sum_i W.*P  (= diag(H*B'*W)),  dp = sum_i W.*N
 //   W <- W .* ((N + W*dn).^e ./ max((P + W*dp).^e + lambda, eps))          nmf.m:168 / cnmf.m:193
+// the same update on the float64 master copy of W: every sweep in double, both arrays written (the fp32 one is what the MFMA passes contract)
+__device__ void w_update64_body(const WUpdateParams &p, double *red) {
+    const int c = blockIdx.x, k = c % p.K;
+    double *w = p.W64 + p.m * c;
+    float *w32 = p.W + p.m * c;
+    const int nch = p.n_chunks > 1 ? p.n_chunks : 1;
+    const long cr = p.m / nch, KT = (long)p.K * p.T;
+    const float *pp = p.P ? p.P + p.m * c : nullptr;
+    const double *pp64 = p.P64 ? p.P64 + p.m * c : nullptr;
+    const double pv = p.Pvec ? p.Pvec[c] : (p.Pvecf ? (double)p.Pvecf[c] : 0.0);
+    auto nat = [&](long i) { const long ch = i / cr; return (double)p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
+    auto pat = [&](long i) { return pp64 ? pp64[i] : (pp ? (double)pp[i] : pv); };
+    const bool fixed = p.fixW && p.fixW[k];
+    const bool plain = p.rule == 1;   // lnmf.m:69
+    double dn = 0.0, dp = 0.0;
+    if (p.stats_in) { dn = p.dndp[c]; dp = p.dndp[KT + c]; }
+    else if (p.dndp || (!fixed && !plain)) {
+        for (long i = threadIdx.x; i < p.m; i += 256) {
+            const double wi = w[i];
+            dn = fma(wi, pat(i), dn);
+            dp = fma(wi, nat(i), dp);
+        }
+        dn = block_sum<4>(dn, red);
+        dp = block_sum<4>(dp, red);
+        if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
+    }
+    if (p.stats_only) return;
+    if (fixed) {
+        if (p.fuse_norm != 0 && p.colsum_out) {   // fixed column: untouched, but its sum is still part of the H-step denominator
+            double cs = 0.0;
+            for (long i = threadIdx.x; i < p.m; i += 256) cs += w[i];
+            cs = block_sum<4>(cs, red);
+            if (threadIdx.x == 0) p.colsum_out[c] = cs;
+        }
+        return;
+    }
+    const double lam = p.lamW ? (double)p.lamW[k] : 0.0, eps = 2.220446049250313e-16, ie = (double)p.inv_exp;
+    double ss = 0.0;
+    for (long i = threadIdx.x; i < p.m; i += 256) {
+        const double wi = w[i], ni = nat(i), pi = pat(i);
+        double neg = plain ? ni : fma(wi, dn, ni);
+        double pos = plain ? pi : fma(wi, dp, pi);
+        if (p.inv_exp != 1.0f) { neg = pow(neg, ie); pos = pow(pos, ie); }
+        const double wn = wi * (neg / fmax(pos + lam, eps));   // nmf.m:168 / cnmf.m:193
+        w[i] = wn;
+        if (p.fuse_norm == 0) w32[i] = (float)wn;
+        ss += plain ? wn : wn * wn;
+    }
+    ss = block_sum<4>(ss, red);
+    if (threadIdx.x == 0) p.sumsq[c] = ss;
+    if (p.fuse_norm == 0) return;
+    const double f = p.fuse_norm == 2 ? 1.0 / ss : 1.0 / sqrt(ss);   // nmf.m:169 / lnmf.m:70
+    double cs = 0.0;
+    for (long i = threadIdx.x; i < p.m; i += 256) { const double v = w[i] * f; w[i] = v; w32[i] = (float)v; cs += v; }
+    if (p.colsum_out) {
+        cs = block_sum<4>(cs, red);
+        if (threadIdx.x == 0) p.colsum_out[c] = cs;
+    }
+}
+
 __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     __shared__ double red[4];
     const int c = blockIdx.x;
@@ -380,6 +457,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
             if (p.fin_out2) *p.fin_out2 = cst;
         }
     }
+    if (p.W64) { w_update64_body(p, red); return; }
     if (p.fixW && p.fixW[k]) {
         if (p.dndp && !p.stats_in) {   // fixed column: untouched, but <W, N> and <W, P> of the Gram-form cost run over every column
             const float *pp = p.P ? p.P + p.m * c : nullptr;
@@ -559,7 +637,7 @@ nmfx_status gram_cost_finish(hipStream_t st, const double *dndp, int nc, const d
 // nmf.m:169   W(:,k) <- W(:,k) * (1/sqrt(sum W(:,k).^2))
 // cnmf.m:196-199  W(:,k,:) <- W(:,k,:) / (norm(squeeze(W(:,k,:)),'fro') / T)
 __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix,
-                                                          int cnmf_rule, double *f_out, int kvalid) {
+                                                          int cnmf_rule, double *f_out, int kvalid, double *W64) {
     const int c = blockIdx.x, k = c % K, t = c / K;
     if (fix && fix[k]) return;
     if (kvalid > 0 && k >= kvalid) {         // zero padding components (nmfx_engine_desc.K_valid): 0 * (1/0) must not turn into NaN
@@ -567,6 +645,18 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
         return;
     }
     float *w = W + m * c;
+    if (W64) {   // float64 master: scaled in double, both arrays written
+        double *w64 = W64 + m * c;
+        double nrm;
+        if (cnmf_rule == 1) {
+            double s = 0.0;
+            for (int tt = 0; tt < T; ++tt) s += sumsq[k + K * tt];
+            nrm = sqrt(s) / (double)T;
+            if (f_out && t == 0 && threadIdx.x == 0) f_out[k] = nrm;
+        } else nrm = cnmf_rule == 2 ? sumsq[c] : sqrt(sumsq[c]);
+        for (long i = threadIdx.x; i < m; i += 256) { const double v = w64[i] / nrm; w64[i] = v; w[i] = (float)v; }
+        return;
+    }
     if (cnmf_rule == 1) {
         double s = 0.0;
         for (int tt = 0; tt < T; ++tt) s += sumsq[k + K * tt];
@@ -585,8 +675,8 @@ __global__ __launch_bounds__(256) void w_normalize_kernel(float *W, long m, int 
     }
 }
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
-                        double *f_out, int kvalid) {
-    hipLaunchKernelGGL(w_normalize_kernel, dim3(K * T), dim3(256), 0, st, W, m, K, T, sumsq, fix, cnmf_rule, f_out, kvalid);
+                        double *f_out, int kvalid, double *W64) {
+    hipLaunchKernelGGL(w_normalize_kernel, dim3(K * T), dim3(256), 0, st, W, m, K, T, sumsq, fix, cnmf_rule, f_out, kvalid, W64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
@@ -607,10 +697,49 @@ nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, in
     return NMFX_OK;
 }
 
+// the float64 master of H: H64(k,:) *= s[k] and H = (float)H64   (cnmf.m:165)
+__global__ void scale_rows64_kernel(double *H64, float *H, int K, long count, const double *s) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) { const double v = s[idx % K] * H64[idx]; H64[idx] = v; H[idx] = (float)v; }
+}
+nmfx_status scale_rows64(hipStream_t st, double *H64, float *H, int K, long n, const double *s) {
+    const long count = (long)K * n;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(scale_rows64_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H64, H, K, count, s);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// dst (rd x cols, float64) <- src (rs x cols, float64): rows beyond rs are zero (padding K)
+__global__ void repack_rows64_kernel(const double *src, int rs, double *dst, int rd, long count) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const int k = (int)(idx % rd);
+    const long j = idx / rd;
+    dst[idx] = k < rs ? src[k + (long)rs * j] : 0.0;
+}
+nmfx_status repack_rows64(hipStream_t st, const double *src, int rs, double *dst, int rd, long cols) {
+    const long count = (long)rd * cols;
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(repack_rows64_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, src, rs, dst, rd, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+// out = (float)in
+__global__ void cvt_d2f_long_kernel(const double *in, float *out, long count) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < count) out[idx] = (float)in[idx];
+}
+nmfx_status cvt_f64_to_f32(hipStream_t st, const double *in, float *out, long count) {
+    if (count <= 0) return NMFX_OK;
+    hipLaunchKernelGGL(cvt_d2f_long_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, out, count);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // H(k,:) *= s[k]   (cnmf.m:165)
 __global__ void scale_rows_kernel(float *H, int K, long count, const double *s) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < count) H[idx] = (float)s[idx % K] * H[idx];
+    if (idx < count) H[idx] = (float)(s[idx % K] * (double)H[idx]);   // (in double, as scale_rows64 forms the owner's copy of the same column)
 }
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s) {
     long count = (long)K * n;
@@ -621,7 +750,7 @@ nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s)
 
 // H <- H .* (Gn.^e ./ max(Gp.^e + lambda, eps))     nmf.m:199 / cnmf.m:231
 __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long count,
-                                const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride) {
+                                const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride, double *H64) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     const int k = (int)(idx % K);
@@ -629,6 +758,19 @@ __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, cons
     float neg = Gn[idx];
     for (int sl = 1; sl < n_slabs; ++sl) neg += Gn[idx + sl * slab_stride];   // split partial sums, fixed order (deterministic)
     const float gsum = neg;
+    if (H64) {   // float64 master: nmf.m:199 in double, both arrays written
+        double dneg = (double)neg, dpos = Gp ? (double)Gp[idx] : Gpvec[k];
+        const double h = H64[idx];
+        double hn;
+        if (inv_exp == -2.0f) hn = sqrt(h * dneg);   // lnmf.m:76
+        else {
+            if (inv_exp != 1.0f) { dneg = pow(dneg, (double)inv_exp); dpos = pow(dpos, (double)inv_exp); }
+            hn = h * (dneg / fmax(dpos + (lamH ? (double)lamH[k] : 0.0), 2.220446049250313e-16));
+        }
+        H64[idx] = hn;
+        H[idx] = (float)hn;
+        return;
+    }
     float pos = Gp ? Gp[idx] : (float)Gpvec[k];
     if (inv_exp != 1.0f) { neg = powf(neg, inv_exp); pos = powf(pos, inv_exp); }
     const float lam = lamH ? lamH[k] : 0.0f;
@@ -636,7 +778,7 @@ __global__ void h_update_kernel(float *H, const float *Gn, const float *Gp, cons
     H[idx] = H[idx] * (neg / fmaxf(pos + lam, NMFX_EPS_F));
 }
 __global__ void h_update_shift_kernel(float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
-                                      float *Hpad, long padcount, long rightcount) {
+                                      float *Hpad, long padcount, long rightcount, double *H64) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, count = (long)K * n;
     if (Hpad) {
         if (idx < padcount) Hpad[idx] = 0.0f;
@@ -652,26 +794,31 @@ __global__ void h_update_shift_kernel(float *H, const float *Q, const float *Gp,
         for (int t = 0; t < T; ++t)
             if (j + t < nvalid) neg += Q[(long)t * K + k + KT * (j + t)];   // (shift_sum_kernel's order)
         const float lam = lamH ? lamH[k] : 0.0f;
+        if (H64) {   // float64 master: cnmf.m:231 in double
+            const double hn = H64[idx] * ((double)neg / fmax((double)Gp[idx] + (double)lam, 2.220446049250313e-16));
+            H64[idx] = hn;
+            h = (float)hn;
+        } else
         h = h * (neg / fmaxf(Gp[idx] + lam, NMFX_EPS_F));                   // cnmf.m:231 (h_update_kernel with inv_exp == 1)
         H[idx] = h;
     }
     if (Hpad) Hpad[padcount + idx] = h;
 }
 nmfx_status h_update_shift(hipStream_t st, float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
-                           float *Hpad, int padL, int padR) {
+                           float *Hpad, int padL, int padR, double *H64) {
     const long count = (long)K * n, padcount = (long)K * padL, rightcount = (long)K * padR;
     const long tot = std::max(count, std::max(padcount, rightcount));
     if (tot <= 0) return NMFX_OK;
-    hipLaunchKernelGGL(h_update_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, H, Q, Gp, K, T, n, nvalid, lamH, fixH, Hpad, padcount, rightcount);
+    hipLaunchKernelGGL(h_update_shift_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, H, Q, Gp, K, T, n, nvalid, lamH, fixH, Hpad, padcount, rightcount, H64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
-                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride) {
+                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs, long slab_stride, double *H64) {
     long count = (long)K * n;
     if (count <= 0) return NMFX_OK;
     hipLaunchKernelGGL(h_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, H, Gn, Gp, Gpvec, K, count, lamH, fixH, inv_exp,
-                       n_slabs, slab_stride);
+                       n_slabs, slab_stride, H64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -26,6 +26,30 @@ void expand_sources(const nmfx_problem *p, int K, std::vector<float> &lw, std::v
     }
 }
 
+// float64 host factors -> DEVICE doubles in the engine's (K-padded) layout, for nmfx_engine_init_f64: MATLAB's doubles reach the master copies unrounded.
+// W: m x Kt x T -> m x K x T (zero columns appended to every time slice); H: columns [col0, col0 + ncols) of the Kt x n array -> K x ncols (zero rows appended)
+nmfx_status stage_init64(hipStream_t st, const nmfx_problem *p, int K, long col0, long ncols, bool want_H, DevBuf &W0d, DevBuf &H0d) {
+    const int Kt = p->K_total, T = p->T;
+    const size_t sl = (size_t)p->m * Kt, slp = (size_t)p->m * K;
+    TRY(W0d.alloc(slp * T * 8));
+    if (K != Kt) NMFX_HIP(hipMemsetAsync(W0d.p, 0, slp * T * 8, st));
+    for (int t = 0; t < T; ++t)
+        NMFX_HIP(hipMemcpyAsync(W0d.as<double>() + t * slp, static_cast<const double *>(p->W_init) + t * sl, sl * 8, hipMemcpyHostToDevice, st));
+    if (want_H) {
+        const double *Hh = static_cast<const double *>(p->H_init) + (size_t)Kt * col0;
+        TRY(H0d.alloc((size_t)K * ncols * 8));
+        if (K != Kt) {
+            DevBuf tmp;
+            TRY(tmp.alloc((size_t)Kt * ncols * 8));
+            NMFX_HIP(hipMemcpyAsync(tmp.p, Hh, (size_t)Kt * ncols * 8, hipMemcpyHostToDevice, st));
+            TRY(repack_rows64(st, tmp.as<double>(), Kt, H0d.as<double>(), K, ncols));
+            NMFX_HIP(hipStreamSynchronize(st));   // tmp goes out of scope
+        } else NMFX_HIP(hipMemcpyAsync(H0d.p, Hh, (size_t)K * ncols * 8, hipMemcpyHostToDevice, st));
+    }
+    NMFX_HIP(hipStreamSynchronize(st));   // the host arrays are the caller's (pageable): the copies have left them
+    return NMFX_OK;
+}
+
 nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const int64_t *seg = nullptr, int64_t nz = 0, const void *Z_init = nullptr,
                    void *Z_out = nullptr) {
     TRY(validate_problem(p, r, false, algorithm != 3));
@@ -117,7 +141,12 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     nmfx_status s = algorithm == 3 ? nmfx_engine_set_constraint(e, seg, nz, Z.as<float>()) : NMFX_OK;
     NMFX_HIP(hipStreamSynchronize(st));   // (nmfx_engine_create has drained the stream already: this only closes the ingest clock)
     const auto t1 = std::chrono::steady_clock::now();
-    if (s == NMFX_OK) s = nmfx_engine_init(e);
+    if (s == NMFX_OK && p->dtype == NMFX_F64) {   // float64 host buffers: the masters start from the caller's doubles
+        DevBuf W0d, H0d;
+        s = stage_init64(st, p, K, 0, p->n, algorithm != 3, W0d, H0d);
+        if (s == NMFX_OK) s = nmfx_engine_init_f64(e, W0d.as<double>(), algorithm != 3 ? H0d.as<double>() : nullptr);
+        if (hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();   // W0d / H0d go out of scope
+    } else if (s == NMFX_OK) s = nmfx_engine_init(e);
     int it = 0;
     r->iters_run = 0;
     auto read_cost = [&](int idx) -> nmfx_status {
@@ -221,6 +250,10 @@ struct MultiDev {
     // stack; a rare host-heap corruption ("free(): invalid pointer", scripts/fuzz_campaign_r3.py multi_edge, only with the NumPy oracle's threads alive in
     // the same process) went away with them -- asynchronous copies into a few bytes of pageable heap are staged by the runtime
     double *hpin = nullptr;
+    bool use_rccl = false;                 // the packed exchange: RCCL (rccl_backend.hip) or the peer reduce-scatter + all-gather below
+    void *comms[NMFX_MAX_GPUS] = {};
+    std::vector<hipEvent_t> evX;           // pairs around the first exchanges on device 0's stream (nmfx_last_call_exchange)
+    int nx = 0;
     nmfx_status init_host() {
         if (!hpin) NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&hpin), sizeof(double) * (NMFX_MAX_GPUS + 2), hipHostMallocPortable));
         return NMFX_OK;
@@ -237,11 +270,36 @@ struct MultiDev {
             unpool_event(dev[g], evP[g]); unpool_event(dev[g], evR[g]); unpool_event(dev[g], evG[g]); unpool_event(dev[g], evH[g]);
             unpool_stream(dev[g], st[g]);   // (drained above)
         }
+        if (ndev > 0) (void)hipSetDevice(dev[0]);
+        for (hipEvent_t ev : evX) unpool_event_timed(dev[0], ev);
         if (hpin) (void)hipHostFree(hpin);
     }
 };
 
+nmfx_status multi_allreduce_peer(MultiDev &M, size_t count);
+// the ONE exchange of an iteration: packed[g] <- sum over the devices, in place, on every device's own stream
 nmfx_status multi_allreduce(MultiDev &M, size_t count) {
+    const bool timed = M.nx < 32;
+    if (timed) {
+        NMFX_HIP(hipSetDevice(M.dev[0]));
+        hipEvent_t a = nullptr, b = nullptr;
+        TRY(pool_event_timed(M.dev[0], &a)); TRY(pool_event_timed(M.dev[0], &b));
+        M.evX.push_back(a); M.evX.push_back(b);
+        NMFX_HIP(hipEventRecord(a, M.st[0]));
+    }
+    if (M.use_rccl) {
+        float *bufs[NMFX_MAX_GPUS];
+        for (int g = 0; g < M.ndev; ++g) bufs[g] = M.packed[g].as<float>();
+        TRY(rccl_allreduce_f32(M.comms, M.dev, M.st, bufs, M.ndev, count));
+    } else TRY(multi_allreduce_peer(M, count));
+    if (timed) {
+        NMFX_HIP(hipSetDevice(M.dev[0]));
+        NMFX_HIP(hipEventRecord(M.evX[2 * M.nx + 1], M.st[0]));
+        ++M.nx;
+    }
+    return NMFX_OK;
+}
+nmfx_status multi_allreduce_peer(MultiDev &M, size_t count) {
     const int N = M.ndev;
     PeerPtrs ptrs{};
     for (int g = 0; g < N; ++g) ptrs.p[g] = M.packed[g].as<float>();
@@ -313,7 +371,17 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         M.dev[g] = p->device_ids ? p->device_ids[g] : g;
         TRY(check_device(M.dev[g]));
     }
-    for (int g = 0; g < N; ++g)      // peer mappings: the reduce kernel reads the other devices' `packed` in place
+    {   // which exchange: nmfx_problem.multi_backend, NMFX_MULTI_BACKEND for "auto"
+        int want = p->multi_backend;
+        if (want == 0) { const char *env = getenv("NMFX_MULTI_BACKEND"); if (env) want = !strcmp(env, "rccl") ? 2 : (!strcmp(env, "peer") ? 1 : 0); }
+        std::string why;
+        if (want == 2) {
+            if (!rccl_usable(M.dev, N, &why)) { set_error("multi_backend = rccl: %s", why.c_str()); return NMFX_ERR_UNSUPPORTED; }
+            M.use_rccl = true;
+        } else M.use_rccl = want == 0 && rccl_usable(M.dev, N, &why);
+        if (M.use_rccl) TRY(rccl_comms(M.dev, N, M.comms));
+    }
+    for (int g = 0; g < N; ++g)      // peer mappings: the reduce kernel reads the other devices' `packed` in place (and cnmf's halo copies go direct)
         for (int h = 0; h < N; ++h) {
             if (M.dev[g] == M.dev[h]) continue;
             int can = 0;
@@ -405,7 +473,18 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         const int kd = nmfx_engine_is_fused(M.eng[g]);
         if (kind < 0) kind = kd;
         else if (kd != kind) { set_error("n_gpus: shards picked different kernel paths; pass path = 1"); return NMFX_ERR_UNSUPPORTED; }
-        TRY(nmfx_engine_init(M.eng[g]));
+        if (p->dtype == NMFX_F64) {   // float64 host buffers: the masters start from the caller's doubles (this shard's own columns of H)
+            DevBuf W0d, H0d;
+            TRY(stage_init64(M.st[g], p, K, M.lo[g], nl, true, W0d, H0d));
+            nmfx_status si = nmfx_engine_init_f64(M.eng[g], W0d.as<double>(), H0d.as<double>());
+            NMFX_HIP(hipStreamSynchronize(M.st[g]));   // W0d / H0d go out of scope
+            TRY(si);
+        } else TRY(nmfx_engine_init(M.eng[g]));
+    }
+    if (hh > 0) {   // the halo columns were scaled as fp32 copies (cnmf.m:165): fetch the owners' images instead, so that every shard sees the same H
+        TRY(multi_halo_exchange(M, K, hh));
+        for (int g = 0; g < N; ++g) TRY(nmfx_engine_hstep_finish(M.eng[g]));   // (paths that keep V_hat: refreshed with the final halos)
+        for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); }
     }
     const int lagk = nmfx_engine_cost_lag(M.eng[0]);   // 1: cost(it-1) after wstep_partial(it); 2: after wstep_finish(it) (Gram-form cost); 0: cost(it) after hstep(it)
     const bool lag = lagk != 0;
@@ -484,6 +563,16 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
         r->cost_len = p->maxiter;
     }
+    {   // the exchange as device 0's stream saw it
+        IoStats &io = io_stats();
+        io.exchange_backend = M.use_rccl ? 2 : 1; io.exchange_ms = 0; io.exchanges_timed = 0;
+        NMFX_HIP(hipSetDevice(M.dev[0]));
+        NMFX_HIP(hipStreamSynchronize(M.st[0]));
+        for (int i = 0; i < M.nx; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, M.evX[2 * i], M.evX[2 * i + 1]) == hipSuccess) { io.exchange_ms += ms; io.exchanges_timed++; } else (void)hipGetLastError();
+        }
+    }
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         const long nl = M.lo[g + 1] - M.lo[g];
@@ -504,7 +593,7 @@ extern "C" {
 // n_gpus / device_ids: a one-entry list names THE device (it overrides p->device); more entries shard the columns
 static nmfx_status dispatch_mu(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     if (!p) return run_mu(p, r, algorithm);
-    if (p->n_gpus > 1) return run_mu_multi(p, r, algorithm);
+    if (p->n_gpus > 1 || (p->n_gpus == 1 && p->multi_backend != 0)) return run_mu_multi(p, r, algorithm);   // (one shard through the sharded driver: how a 1-GPU box runs the RCCL branch)
     if (p->n_gpus == 1 && p->device_ids) { nmfx_problem q = *p; q.device = p->device_ids[0]; return run_mu(&q, r, algorithm); }
     return run_mu(p, r, algorithm);
 }

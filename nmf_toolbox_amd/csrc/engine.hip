@@ -85,6 +85,9 @@ Layout layout(nmfx_engine *e, void *ws) {
     e->n_cost_partials = (int)gemm_grid_blocks(e->m, e->n + e->hR);
     e->cost_partials = c.take<double>(e->n_cost_partials);
     e->rr_scratch = c.take<char>(row_reduce_scratch_bytes(e->K));
+    e->W64 = c.take<double>(mKT);
+    e->H64 = e->algo == 3 ? nullptr : c.take<double>(Kn);
+    e->P64 = nullptr;
     Layout L;
     if (e->fused) {
         // V_hat, Gn/Gp of the generic path are not needed: rewind and carve the fused buffers instead
@@ -101,7 +104,9 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->Gn = f.take<float>(Kn);
         const bool euc = e->div == NMFX_DIV_EUCLIDEAN;
         e->Gp = (euc || e->dual) ? f.take<float>(Kn) : nullptr;
-        e->Pbuf = euc ? f.take<float>(mKT) : nullptr;
+        e->P64 = euc ? f.take<double>(mKT) : nullptr;
+        e->W64 = f.take<double>(mKT);
+        e->H64 = e->algo == 3 ? nullptr : f.take<double>(Kn);
         e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
         size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
         e->gemm_scratch_bytes = euc ? std::max(std::max(std::max(g1, g2), g3), std::max(gram_rc_scratch_bytes(e->K, e->K, e->n), gram_rc_scratch_bytes(e->K, e->K, e->m))) : 0;
@@ -125,7 +130,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         return L;
     }
     if (e->gram) {
-        e->Pbuf = c.take<float>(mKT);
+        e->P64 = c.take<double>(mKT);
         e->CC = c.take<float>((size_t)e->KT * e->KT);
         size_t g4 = gemm_scratch_bytes(e->KT, e->KT, e->n), g5 = gemm_scratch_bytes(e->KT, e->KT, e->m);
         size_t gg = std::max(std::max(g4, g5), sizeof(float) * Kn * e->T);   // + T slabs of the z-batched H-step denominator
@@ -476,6 +481,10 @@ int fused_split(long blocks, long extent, int K, long *c_per_split) {
     const long tiles = (extent + 63) / 64;
     long s = 1;
     while (blocks * s < target && s * 2 <= tiles) s *= 2;   // every split keeps at least one 64-wide tile
+    // ... and no fp32 accumulation chain of the second product runs over more than chain_max streamed indices: a workgroup's accumulators are a sequential
+    // fmaf chain over its slice of the streamed dimension, whose rounding error grows with the square root of its length; the slabs are summed in double
+    static const long chain_max = getenv("NMFX_CHAIN_MAX") ? atol(getenv("NMFX_CHAIN_MAX")) : 0;
+    if (chain_max >= 64) { const long need = (tiles * 64 + chain_max - 1) / chain_max; if (need > s) s = need < tiles ? need : tiles; }
     const long per = (tiles + s - 1) / s;                   // tiles per split; trailing splits that would be empty are dropped
     *c_per_split = per * 64;
     return (int)((tiles + per - 1) / per);
@@ -935,12 +944,28 @@ nmfx_status nmfx_engine_sumvv_set_global(nmfx_engine *e, const double *src_dev) 
     e->sumvv_global_set = true;
     return NMFX_OK;
 }
+// W64 <- W, H64 <- H (own columns): the masters follow the fp32 arrays (init; a caller that rewrote W / H itself)
+nmfx_status nmfx_engine_sync_master(nmfx_engine *e) {
+    DeviceGuard dg_;
+    NMFX_HIP(hipSetDevice(e->device));
+    TRY(cvt_to_f64(e->st, e->W, e->W64, (long)e->m * e->KT));
+    if (e->H64) TRY(cvt_to_f64(e->st, e->H, e->H64, (long)e->K * e->n));
+    return NMFX_OK;
+}
+nmfx_status nmfx_engine_master_ptrs(nmfx_engine *e, double **W64_dev, double **H64_dev) {
+    if (W64_dev) *W64_dev = e->W64;
+    if (H64_dev) *H64_dev = e->H64;
+    return NMFX_OK;
+}
 // 0: the cost of iteration i is ready after hstep(i); 1: after wstep_partial(i+1); 2: after wstep_finish(i+1) (read it there; engines of kind 2
 // may also deliver it at point 1 -- reading at point 2 is always right for them)
 int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->klw) ? 1 : 0); }
 
-// nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat
-nmfx_status nmfx_engine_init(nmfx_engine *e) {
+// nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat.
+// The normalisation runs on the float64 masters: one fp32 rounding of the INITIAL state is a perturbation the iteration carries to the end, and problems that
+// amplify it (one factor fixed, planted data: x300) left the contract through exactly that door (scripts/diag_wstep.py: 1.7e-5 from an fp32-normalised W0,
+// 5e-6 from fl32(W0) normalised in double, 1.5e-6 from the caller's float64 W0) -- hence also nmfx_engine_init_f64
+static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const double *H0) {
     DeviceGuard dg_;
     NMFX_HIP(hipSetDevice(e->device));
     e->hpad_valid = false;
@@ -950,9 +975,20 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
     }
     {
         Scope s(e, TAG_SMALL);
-        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out, e->K_valid));
-        if (e->algo == 1) TRY(scale_rows(e->st, e->Hext, e->K, e->hL + e->n + e->hR, e->f_out));   // halos too: every rank applies the same factors
+        const size_t mKT = (size_t)e->m * e->KT, Kn = (size_t)e->K * e->n;
+        if (W0) NMFX_HIP(hipMemcpyAsync(e->W64, W0, sizeof(double) * mKT, hipMemcpyDeviceToDevice, e->st));
+        else TRY(cvt_to_f64(e->st, e->W, e->W64, (long)mKT));
+        if (e->H64) {
+            if (H0) { NMFX_HIP(hipMemcpyAsync(e->H64, H0, sizeof(double) * Kn, hipMemcpyDeviceToDevice, e->st)); TRY(cvt_f64_to_f32(e->st, e->H64, e->H, (long)Kn)); }
+            else TRY(cvt_to_f64(e->st, e->H, e->H64, (long)Kn));
+        }
+        TRY(col_reduce64(e->st, e->W64, e->m, e->m, e->KT, e->algo == 2 ? 0 : 1, e->sumsq));   // lnmf.m:59: L1 sums
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, nullptr, norm_mode(e), e->f_out, e->K_valid, e->W64));
+        if (e->algo == 1) {   // cnmf.m:165; the halos too (fp32 copies of the neighbours' columns: every rank applies the same factors)
+            TRY(scale_rows64(e->st, e->H64, e->H, e->K, e->n, e->f_out));
+            if (e->hL) TRY(scale_rows(e->st, e->Hext, e->K, e->hL, e->f_out));
+            if (e->hR) TRY(scale_rows(e->st, e->H + (size_t)e->K * e->n, e->K, e->hR, e->f_out));
+        }
         if (e->fused) {
             e->cost_valid = false;
             if (e->VT) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
@@ -1006,6 +1042,8 @@ nmfx_status nmfx_engine_init(nmfx_engine *e) {
     }
     return recon(e, false);
 }
+nmfx_status nmfx_engine_init(nmfx_engine *e) { return engine_init_impl(e, nullptr, nullptr); }
+nmfx_status nmfx_engine_init_f64(nmfx_engine *e, const double *W_init64_dev, const double *H_init64_dev) { return engine_init_impl(e, W_init64_dev, H_init64_dev); }
 
 // local sums of the W step: packed = [N | P]  or  [N | Pvec]        nmf.m:149-164 / cnmf.m:187-192
 static nmfx_status fused_wstep_tail(nmfx_engine *e);
@@ -1137,11 +1175,11 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             Scope s(e, TAG_SMALL);
             p.Pvecf = e->packed + mK;   // the all-reduced rowsum(H), still fp32 as it travelled
         } else {
-            Scope s(e, TAG_GRAM);   // P = W * (H*H')
-            TRY(small_gemm(e, e->m, e->K, e->K, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                           OpView{e->packed + mK, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
-            p.P = e->Pbuf;
+            Scope s(e, TAG_GRAM);   // P = W * (H*H'), float64 accumulation from the master copy of W (gemm64.hip)
+            TRY(gemm64(e->st, e->m, e->K, e->K, e->W64, nullptr, e->m, nullptr, e->packed + mK, e->K, e->P64, nullptr, e->m));
+            p.P64 = e->P64;
         }
+        p.W64 = e->W64;
         p.rule = e->algo == 2 ? 1 : 0;
         // update, column normalisation (nmf.m:169 / lnmf.m:70) and, for KL, the column sums of the final W (H-step denominator) in ONE launch
         p.fuse_norm = norm_mode(e) == 2 ? 2 : 1;
@@ -1186,10 +1224,10 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         WUpdateParams p{};
         p.W = e->W; p.N = e->packed; p.m = e->m; p.K = e->K; p.T = e->T;
         p.lamW = e->lamW; p.fixW = e->fixW; p.sumsq = e->sumsq; p.inv_exp = outer_exp(e);
-        if (e->gram) {   // P_all = W_flat * (Hs*Hs')
-            TRY(small_gemm(e, e->m, e->KT, e->KT, OpView{e->W, nullptr, e->m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                           OpView{e->packed + mKT, nullptr, (long)e->KT, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Pbuf, e->m));
-            p.P = e->Pbuf;
+        p.W64 = e->W64;
+        if (e->gram) {   // P_all = W_flat * (Hs*Hs'), float64 accumulation from the master copy of W (gemm64.hip)
+            TRY(gemm64(e->st, e->m, e->KT, e->KT, e->W64, nullptr, e->m, nullptr, e->packed + mKT, e->KT, e->P64, nullptr, e->m));
+            p.P64 = e->P64;
         } else if (div_has_matrix_den(e->div)) p.P = e->packed + mKT;
         else {
             TRY(f2d(e->st, e->packed + mKT, e->Pvec, e->KT));
@@ -1214,7 +1252,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
             p.stats_only = 0; p.stats_in = 1;
         }
         TRY(w_update(e->st, p));
-        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr));
+        TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr, 0, e->W64));
         e->cost_valid = false;
     }
     if (e->gram || e->fusedT_kl || e->klw) return NMFX_OK;
@@ -1271,12 +1309,12 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             Scope s(e, TAG_SMALL);
             const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
             if (hug) {
-                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, g.slab_stride, e->K, e->n, e->lamH, e->fixH));
+                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, g.slab_stride, e->K, e->n, e->lamH, e->fixH, e->H64));
             } else {
             if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, g.slab_stride, g.slab_stride, e->Gn, 0));
-            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, e->isplit_h, g.slab_stride));
+            if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, e->isplit_h, g.slab_stride, e->H64));
             else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
-            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, 1, 0, e->H64));
             }
         } else if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
@@ -1292,11 +1330,11 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
             }
             Scope s(e, TAG_SMALL);
-            if (hug) { TRY(h_update_gram(e->st, e->H, e->GW, e->Gn, 1, 0, e->K, e->n, e->lamH, e->fixH)); }
+            if (hug) { TRY(h_update_gram(e->st, e->H, e->GW, e->Gn, 1, 0, e->K, e->n, e->lamH, e->fixH, e->H64)); }
             else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
-            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, 1, 0, e->H64));
         } else if (e->isplit_h == 1 && e->algo != 3 && !hug && !e->dual2) {
-            f.Hio = e->H; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
+            f.Hio = e->H; f.H64 = e->H64; f.den = kl ? nullptr : e->Gp; f.denvec = kl ? e->Gpvec : nullptr; f.lam = e->lamH; f.fix = e->fixH;
             f.sqrt_rule = e->algo == 2;
             Scope s(e, TAG_FUSED_H);
             TRY(launch_fused(e->st, f, 1, false, func, true, 1));
@@ -1337,7 +1375,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(reduce_slabs(e->st, e->slabs2, e->isplit_h, f.slab_stride, f.slab_stride, e->Gp, 0));
             }
             if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
-            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, outer_exp(e)));
+            else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, outer_exp(e), 1, 0, e->H64));
         } else {
             f.out = e->isplit_h == 1 ? e->Gn : e->slabs; f.slab_stride = (long)e->K * e->n; f.os_r = e->K; f.os_k = 1;
             {
@@ -1347,13 +1385,13 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             Scope s(e, TAG_SMALL);
             const bool fuse_sum = e->isplit_h > 1 && e->algo != 3;   // h_update sums the slabs on the fly
             if (hug) {
-                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, f.slab_stride, e->K, e->n, e->lamH, e->fixH));
+                TRY(h_update_gram(e->st, e->H, e->GW, e->isplit_h == 1 ? e->Gn : e->slabs, e->isplit_h, f.slab_stride, e->K, e->n, e->lamH, e->fixH, e->H64));
             } else {
                 if (e->isplit_h > 1 && !fuse_sum) TRY(reduce_slabs(e->st, e->slabs, e->isplit_h, f.slab_stride, f.slab_stride, e->Gn, 0));
                 if (fuse_sum) TRY(h_update(e->st, e->H, e->slabs, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f,
-                                           e->isplit_h, f.slab_stride));
+                                           e->isplit_h, f.slab_stride, e->H64));
                 else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, kl ? nullptr : e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
-                else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f));
+                else TRY(h_update(e->st, e->H, e->Gn, kl ? nullptr : e->Gp, kl ? e->Gpvec : nullptr, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : 1.0f, 1, 0, e->H64));
             }
         }
         e->cost_valid = false;
@@ -1468,9 +1506,9 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         }
         if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, outer_exp(e), 0));
         else if (fuse_hupd) {
-            TRY(h_update_shift(e->st, e->H, e->Qbuf, e->Gp, e->K, e->T, e->n, e->nvalid, e->lamH, e->fixH, e->Hpad, e->T - 1, e->lagram ? e->T - 1 : 0));
+            TRY(h_update_shift(e->st, e->H, e->Qbuf, e->Gp, e->K, e->T, e->n, e->nvalid, e->lamH, e->fixH, e->Hpad, e->T - 1, e->lagram ? e->T - 1 : 0, e->H64));
             e->hpad_valid = true;   // (the layout ensure_hpad would produce)
-        } else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e)));
+        } else TRY(h_update(e->st, e->H, e->Gn, e->Gp, div_has_matrix_den(e->div) ? nullptr : e->Gpvec, e->K, e->n, e->lamH, e->fixH, e->algo == 2 ? -2.0f : outer_exp(e), 1, 0, e->H64));
     }
     if (e->defer_hfinish) return NMFX_OK;   // the caller refreshes H's halos first, then calls nmfx_engine_hstep_finish
     return nmfx_engine_hstep_finish(e);

@@ -454,8 +454,21 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     const int k = 32 * kb + rowmap(reg, h);
                     if (!row_ok || (p.fix && p.fix[k])) continue;
                     const long idx = (long)k + (long)K * r;
-                    if (p.sqrt_rule) { p.Hio[idx] = sqrtf(p.Hio[idx] * acc[kb][reg]); continue; }   // lnmf.m:76
                     const float lam = p.lam ? p.lam[k] : 0.0f;
+                    if (p.H64) {   // float64 master copy of H: the update in double, both arrays written
+                        const double hv = p.H64[idx];
+                        double hn;
+                        if (p.sqrt_rule) hn = sqrt(hv * (double)acc[kb][reg]);   // lnmf.m:76
+                        else if (DUAL) {
+                            double gn = (double)acc[kb][reg], gp = (double)acc2[kb][reg];
+                            if (p.inv_exp != 1.0f) { gn = pow(gn, (double)p.inv_exp); gp = pow(gp, (double)p.inv_exp); }
+                            hn = hv * (gn / fmax(gp + (double)lam, 2.220446049250313e-16));
+                        } else hn = hv * ((double)acc[kb][reg] / fmax((p.den ? (double)p.den[idx] : p.denvec[k]) + (double)lam, 2.220446049250313e-16));
+                        p.H64[idx] = hn;
+                        p.Hio[idx] = (float)hn;
+                        continue;
+                    }
+                    if (p.sqrt_rule) { p.Hio[idx] = sqrtf(p.Hio[idx] * acc[kb][reg]); continue; }   // lnmf.m:76
                     if (DUAL) {   // nmf.m:186-187,193-194 + 199: numerator and denominator both come out of this pass; outer .^(1/alpha) for alpha-beta
                         float gn = acc[kb][reg], gp = acc2[kb][reg];
                         if (p.inv_exp != 1.0f) { gn = powf(gn, p.inv_exp); gp = powf(gp, p.inv_exp); }

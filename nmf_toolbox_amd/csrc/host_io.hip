@@ -105,7 +105,7 @@ thread_local IoStats g_io;
 struct ResPool {
     std::mutex mu;
     std::vector<hipStream_t> st[NMFX_MAX_GPUS];
-    std::vector<hipEvent_t> ev[NMFX_MAX_GPUS];
+    std::vector<hipEvent_t> ev[NMFX_MAX_GPUS], evt[NMFX_MAX_GPUS];   // evt: events WITH timing (the exchange brackets of the multi-GPU calls)
 };
 ResPool g_res;
 
@@ -137,6 +137,22 @@ nmfx_status pool_event(int device, hipEvent_t *ev) {
     NMFX_HIP(hipSetDevice(device));
     NMFX_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return NMFX_OK;
+}
+nmfx_status pool_event_timed(int device, hipEvent_t *ev) {
+    if (device < 0 || device >= NMFX_MAX_GPUS) { set_error("pool_event_timed: device %d out of range", device); return NMFX_ERR_INVALID; }
+    if (!pool_off()) {
+        std::lock_guard<std::mutex> lk(g_res.mu);
+        if (!g_res.evt[device].empty()) { *ev = g_res.evt[device].back(); g_res.evt[device].pop_back(); return NMFX_OK; }
+    }
+    NMFX_HIP(hipSetDevice(device));
+    NMFX_HIP(hipEventCreate(ev));
+    return NMFX_OK;
+}
+void unpool_event_timed(int device, hipEvent_t ev) {
+    if (!ev || device < 0 || device >= NMFX_MAX_GPUS) return;
+    if (pool_off()) { (void)hipEventDestroy(ev); return; }
+    std::lock_guard<std::mutex> lk(g_res.mu);
+    g_res.evt[device].push_back(ev);
 }
 void unpool_stream(int device, hipStream_t st) {
     if (!st || device < 0 || device >= NMFX_MAX_GPUS) return;
@@ -247,6 +263,13 @@ extern "C" {
 
 // Measurement hook (bench.py --api blocking): seconds the last blocking factorisation on this thread spent moving data in, iterating, and
 // moving results out, and the bytes it took from / returned to host arrays.
+nmfx_status nmfx_last_call_exchange(double *ms_per_exchange, int32_t *exchanges_timed, int32_t *backend) {
+    const nmfx::IoStats &s = nmfx::io_stats();
+    if (ms_per_exchange) *ms_per_exchange = s.exchanges_timed > 0 ? s.exchange_ms / s.exchanges_timed : 0.0;
+    if (exchanges_timed) *exchanges_timed = s.exchanges_timed;
+    if (backend) *backend = s.exchange_backend;
+    return NMFX_OK;
+}
 nmfx_status nmfx_last_call_timing(double *ingest_s, double *iterate_s, double *egress_s, double *host_bytes_in, double *host_bytes_out) {
     const nmfx::IoStats &s = nmfx::io_stats();
     if (ingest_s) *ingest_s = s.ingest_s;

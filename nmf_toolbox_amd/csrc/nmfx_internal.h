@@ -138,6 +138,7 @@ struct FusedParams {
     const float *lam;     // [K] or nullptr
     const uint8_t *fix;   // [K] or nullptr
     int sqrt_rule;        // EPI 1: H <- sqrt(H .* G)   (lnmf.m:76) instead of the ratio update
+    double *H64;          // EPI 1: float64 master copy of H (K x n) or nullptr: the epilogue reads it, updates in double and writes both arrays
     const int *run_if;    // when set: every workgroup returns at once unless *run_if != 0 (a device-side decision, no host round trip)
 };
 bool fused_supported(int K);
@@ -152,7 +153,7 @@ nmfx_status gram_rc(hipStream_t st, const float *A, long lda, int K1, const floa
                     long b_tshift = 0, int b_tblk = 0);
 bool h_update_gram_supported(int K);
 nmfx_status h_update_gram(hipStream_t st, float *H, const float *G, const float *Gn, int n_slabs, long slab_stride, int K, long n, const float *lam,
-                          const uint8_t *fix);
+                          const uint8_t *fix, double *H64 = nullptr);   // H64: the float64 master of H (K x n), see h_update
 
 // ---- small kernels (aux.hip) ----------------------------------------------------------------
 nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out,
@@ -190,6 +191,10 @@ struct WUpdateParams {
     const int *fin_exact_flag;
     const float *fin_lamW, *fin_lamH;
     double *fin_out, *fin_out2;
+    // float64 master copy of W (m x K*T, or nullptr): the column is read from it, updated in double and written to BOTH arrays (nmf.m:168-169 run in
+    // double; W is what the MFMA passes contract).  P64: the denominator product in float64 (gemm64), instead of P
+    double *W64;
+    const double *P64;
 };
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p);
 // Euclidean cost in Gram form, from the column statistics of the W update:  0.5*||V - W*H||^2 = 0.5*sumVV - sum(dp) + 0.5*sum(dn).
@@ -201,7 +206,10 @@ nmfx_status gram_decide(hipStream_t st, const double *dndp, int nc, const double
 nmfx_status gram_cost_finish(hipStream_t st, const double *dndp, int nc, const double *sumVV, int rank0, const int *exact_flag, const double *partials, int nparts,
                              const double *l1W, int nW, const float *lamW, const double *l1H, int K, const float *lamH, double *out, double *out2);
 nmfx_status w_normalize(hipStream_t st, float *W, long m, int K, int T, const double *sumsq, const uint8_t *fix, int cnmf_rule,
-                        double *f_out, int kvalid = 0);
+                        double *f_out, int kvalid = 0, double *W64 = nullptr);   // W64: the float64 master (read, scaled in double, both arrays written)
+// C (M x N) = A * B accumulated in float64 on the fp64 matrix core (gemm64.hip); A(i, k) = A[i + lda*k], B(k, j) = B[k + ldb*j], each fp32 or float64
+nmfx_status gemm64(hipStream_t st, long M, long N, long Kc, const double *A64, const float *A32, long lda, const double *B64, const float *B32, long ldb,
+                   double *C64, float *C32, long ldc);
 constexpr int NMFX_MAX_GPUS = 16;
 struct PeerPtrs { float *p[NMFX_MAX_GPUS]; };
 nmfx_status peer_reduce(hipStream_t st, const PeerPtrs &bufs, int ndev, int self, long off, long count);
@@ -213,13 +221,18 @@ nmfx_status lag_sum(hipStream_t st, const float *CC, int K, int T, float *E);
 nmfx_status gp_tail(hipStream_t st, const float *CC, const float *H, int K, int T, long n, float *Gp);
 nmfx_status repack_rows(hipStream_t st, const float *src, int rs, float *dst, int rd, long cols);
 nmfx_status scale_rows(hipStream_t st, float *H, int K, long n, const double *s);
+nmfx_status scale_rows64(hipStream_t st, double *H64, float *H, int K, long n, const double *s);   // the float64 master and its fp32 image
+nmfx_status repack_rows64(hipStream_t st, const double *src, int rs, double *dst, int rd, long cols);
+nmfx_status col_reduce64(hipStream_t st, const double *X, long rows, long ld, int ncols, int mode, double *out);
+nmfx_status cvt_f64_to_f32(hipStream_t st, const double *in, float *out, long count);
 nmfx_status scale_cols(hipStream_t st, float *X, long rows, int ncols, const double *s, int use_sqrt, int divide);
 // cnmf, euclidean Gram path: Gn(k, j) = sum_t Q((t,k), j + t) (cnmf.m:217-226, the shift-sum of the Q product), the update of cnmf.m:231 and the
 // zero-padded copy Hpad = [padL zero columns | H | padR zero columns] the next passes stream -- shift_sum + h_update + pad_left in ONE launch
 nmfx_status h_update_shift(hipStream_t st, float *H, const float *Q, const float *Gp, int K, int T, long n, long nvalid, const float *lamH, const uint8_t *fixH,
-                           float *Hpad, int padL, int padR);
+                           float *Hpad, int padL, int padR, double *H64 = nullptr);
+// H64 (or nullptr): the float64 master copy of H -- the update reads it, runs nmf.m:199 in double and writes both arrays
 nmfx_status h_update(hipStream_t st, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long n,
-                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs = 1, long slab_stride = 0);   // n_slabs > 1: Gn = sum of slabs
+                     const float *lamH, const uint8_t *fixH, float inv_exp, int n_slabs = 1, long slab_stride = 0, double *H64 = nullptr);   // n_slabs > 1: Gn = sum of slabs
 nmfx_status z_update(hipStream_t st, float *Z, float *H, const float *Gn, const float *Gp, const double *Gpvec, int K, long nz, const long *seg,
                      const float *lamZ, const uint8_t *fixZ, float inv_exp, int gather_only);
 nmfx_status center_of_gravity(hipStream_t st, const void *W, int is_f64, long m, int K, int *cog);

@@ -959,6 +959,7 @@ nmfx_status nmfx_nmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (p->n_gpus > 1) return run_nmfsc_multi(p, r);   // csrc/multi_sc.hip: one host thread per column shard over nmfx_nmfsc_dev
     nmfx_problem q;
     TRY(sc_devices(p, &q, "nmfsc"));
+    if (nmfsc_f64_eligible(&q)) return run_nmfsc_f64(&q, r);   // small problems: float64 end to end (sc64.hip)
     return run_nmfsc(&q, r);
 }
 nmfx_status nmfx_nmfsc_dev(const nmfx_problem *p, const float *V_dev, float *W_dev, float *H_dev, int64_t n_total, void *stream,

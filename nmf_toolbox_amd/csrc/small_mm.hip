@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void gram_rc_kernel(const float *__restrict__ 
 // chain of L2-latency loads (G) and the occupancy is what hides it.
 template <int KB>
 __global__ __launch_bounds__(64 * (KB < 4 ? KB : 4)) void h_update_gram_kernel(float *__restrict__ H, const float *__restrict__ G, const float *__restrict__ Gn, int n_slabs,
-                                                                                  long slab_stride, long n, const float *__restrict__ lam, const uint8_t *__restrict__ fix) {
+                                                                                  long slab_stride, long n, const float *__restrict__ lam, const uint8_t *__restrict__ fix,
+                                                                                  double *__restrict__ H64) {
     constexpr int K = 32 * KB, NW = KB < 4 ? KB : 4, NB = (KB + NW - 1) / NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const long j0 = (long)blockIdx.x * 32;
@@ -151,7 +152,12 @@ __global__ __launch_bounds__(64 * (KB < 4 ? KB : 4)) void h_update_gram_kernel(f
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long j = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (j < n) H[k + (long)K * j] = hv[e] * (neg[e] / fmaxf(acc[b][e] + lm, NMFX_EPS_F));   // nmf.m:199
+            if (j >= n) continue;
+            if (H64) {   // float64 master: the update in double, both arrays written
+                const double hn = H64[k + (long)K * j] * ((double)neg[e] / fmax((double)acc[b][e] + (double)lm, 2.220446049250313e-16));
+                H64[k + (long)K * j] = hn;
+                H[k + (long)K * j] = (float)hn;
+            } else H[k + (long)K * j] = hv[e] * (neg[e] / fmaxf(acc[b][e] + lm, NMFX_EPS_F));   // nmf.m:199
         }
     }
 }
@@ -273,11 +279,11 @@ bool h_update_gram_supported(int K) { return K % 32 == 0 && K >= 32 && K <= 256;
 
 // H (K x n, in place) <- H .* (sum of n_slabs numerator slabs) ./ max(G*H + lambda, eps), G (K x K) symmetric    (nmf.m:181,199 in Gram form)
 nmfx_status h_update_gram(hipStream_t st, float *H, const float *G, const float *Gn, int n_slabs, long slab_stride, int K, long n, const float *lam,
-                          const uint8_t *fix) {
+                          const uint8_t *fix, double *H64) {
     if (!h_update_gram_supported(K)) { set_error("h_update_gram: K = %d", K); return NMFX_ERR_INVALID; }
     if (n <= 0) return NMFX_OK;
     dim3 grid((unsigned)((n + 31) / 32));
-#define NMFX_HUG(KB) hipLaunchKernelGGL((h_update_gram_kernel<KB>), grid, dim3(64 * (KB < 4 ? KB : 4)), 0, st, H, G, Gn, n_slabs, slab_stride, n, lam, fix)
+#define NMFX_HUG(KB) hipLaunchKernelGGL((h_update_gram_kernel<KB>), grid, dim3(64 * (KB < 4 ? KB : 4)), 0, st, H, G, Gn, n_slabs, slab_stride, n, lam, fix, H64)
     switch (K / 32) {
     case 1: NMFX_HUG(1); break;
     case 2: NMFX_HUG(2); break;

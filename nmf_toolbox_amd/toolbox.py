@@ -184,6 +184,8 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     ids = _gpu_ids(cfg)
     if ids is not None:
         p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
+    # extension: the exchange of the packed W-step sums between those GPUs -- "rccl" (ncclAllReduce), "peer" (reduce-scatter + all-gather over peer mappings), default auto
+    p.multi_backend = {None: 0, "auto": 0, "peer": 1, "rccl": 2}.get(cfg.get("nmfx_multi_backend", None), 0)
     r = _lib.Result()
     r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
     _lib.check(fn(C.byref(p), C.byref(r)))

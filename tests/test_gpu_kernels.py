@@ -109,3 +109,46 @@ def test_projfunc_signed(gpu_lib):
     v, it = gpu_lib.projfunc(s, 6.0, 1.0, False)
     v0, it0 = O.projfunc(s, 6.0, 1.0, False)
     assert it == it0 and rel_fro(v, v0) < 1e-12
+
+
+@pytest.mark.parametrize("M,N,Kc", [(64, 64, 16), (128, 192, 64), (358, 640, 640), (8192, 128, 128), (1000, 37, 53), (1, 1, 1), (65, 129, 17), (4096, 512, 512)])
+@pytest.mark.parametrize("a64,b64", [(True, False), (False, False), (True, True), (False, True)])
+def test_gemm64(gpu_lib, M, N, Kc, a64, b64):
+    """the float64 matrix-core product behind P = W*(H*H') (gemm64.hip): every operand-type combination against NumPy float64, float64 and fp32 results;
+    an asymmetric B with A = I would expose a transposed write, the relative error the accumulation type"""
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(M + 3 * N + 7 * Kc)
+    A = rs.rand(M, Kc) - 0.3
+    B = rs.rand(Kc, N) - 0.3
+    if not a64:
+        A = A.astype(np.float32).astype(np.float64)
+    if not b64:
+        B = B.astype(np.float32).astype(np.float64)
+    dev = "cuda:0"
+    cm = lambda X, dt: torch.from_numpy(np.ascontiguousarray(X.T)).to(dt).to(dev)   # column-major image
+    tA, tB = cm(A, torch.float64 if a64 else torch.float32), cm(B, torch.float64 if b64 else torch.float32)
+    C64 = torch.zeros(N, M, dtype=torch.float64, device=dev)
+    C32 = torch.zeros(N, M, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.nmfx_gemm64(st, M, N, Kc, tA.data_ptr() if a64 else None, None if a64 else tA.data_ptr(), M, tB.data_ptr() if b64 else None,
+                               None if b64 else tB.data_ptr(), Kc, C64.data_ptr(), C32.data_ptr(), M))
+    torch.cuda.synchronize()
+    ref = A @ B
+    assert rel_fro(C64.cpu().numpy().T, ref) < 1e-14
+    assert rel_fro(C32.cpu().numpy().T, ref) < 1e-7
+
+
+def test_gemm64_is_transpose_safe(gpu_lib):
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    n = 96
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) / 7.0
+    tA = torch.eye(n, dtype=torch.float64, device="cuda:0")
+    tB = torch.from_numpy(np.ascontiguousarray(B.T)).to("cuda:0")
+    C64 = torch.zeros(n, n, dtype=torch.float64, device="cuda:0")
+    _lib.check(lib.nmfx_gemm64(torch.cuda.current_stream().cuda_stream, n, n, n, tA.data_ptr(), None, n, tB.data_ptr(), None, n, C64.data_ptr(), None, n))
+    torch.cuda.synchronize()
+    assert np.array_equal(C64.cpu().numpy().T, B)

@@ -708,7 +708,10 @@ def test_engine_loop_stop_rule_equals_blocking_call(gpu_lib, div, path):
     assert np.all(dec[:14] > 0) and dec[11] > dec[12]
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=30, tolerance=tol)
     Wr, Hr, cr = O.nmf(V, K, cfg)
-    Wb, Hb, cb = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=path))
+    # float32 host arrays: the blocking call then starts its float64 master copies from the same fp32 values the device-level Engine is handed (with float64
+    # host arrays it starts them from the doubles themselves, nmfx_engine_init_f64 -- closer to the oracle, but no longer the same run bit for bit)
+    f32 = np.float32
+    Wb, Hb, cb = gpu_lib.nmf(V.astype(f32), K, dict(cfg, W_init=W0.astype(f32), H_init=H0.astype(f32), nmfx_path=path))
     e = Engine(colmajor_to_torch(V, "cuda:0"), colmajor_to_torch(W0, "cuda:0"), colmajor_to_torch(H0, "cuda:0"), divergence=div, path=path, use_dist=False)
     e.init()
     cost = torch.zeros(30, dtype=torch.float64, device="cuda:0")
@@ -913,3 +916,60 @@ def test_run_to_run_determinism_under_concurrent_load(gpu_lib):
         if bg.is_alive():
             bg.terminate()
     assert bg.exitcode == 0
+
+
+# ---- the RCCL backend of the blocking multi-GPU call (rccl_backend.hip; north_star: ONE RCCL all-reduce of the packed W-step sums per iteration) ----------------
+def test_rccl_library_loads(gpu_lib):
+    import ctypes as C
+    from nmf_toolbox_amd import _lib
+    v = C.c_int32(0)
+    path = _lib.load().nmfx_rccl_library(C.byref(v))
+    assert path and b"rccl" in path and v.value > 0, (path, v.value)
+
+
+@pytest.mark.parametrize("alg,div,m,n,K,T", [("nmf", "kl", 256, 1024, 64, 1), ("nmf", "euclidean", 256, 1024, 64, 1), ("nmf", "is", 200, 600, 40, 1), ("nmf", "euclidean", 130, 700, 300, 1),
+                                             ("cnmf", "euclidean", 128, 512, 32, 4), ("cnmf", "kl", 128, 512, 32, 4), ("lnmf", "kl", 256, 1024, 64, 1)])
+def test_blocking_api_rccl_backend_one_shard(gpu_lib, alg, div, m, n, K, T):
+    """the 1-GPU box runs the RCCL branch of the sharded driver with ONE shard (nmfx_gpus = [0], nmfx_multi_backend = "rccl": ncclCommInitAll over one device,
+    one ncclAllReduce per iteration on the engine's stream): bit-identical to the peer branch and to the unsharded call, the exchange timed and named"""
+    import ctypes as C
+    from oracle import nmf_oracle as O
+    from nmf_toolbox_amd import _lib
+    V, W0, H0 = synth(m, n, K, T=(T if alg == "cnmf" else None))
+    if alg == "lnmf":
+        cfg = dict(W_init=W0 / W0.sum(0), H_init=H0, maxiter=6, tolerance=1e-300)
+        run = lambda c: gpu_lib.lnmf(V, K, c)
+        ref = O.lnmf(V, K, cfg)
+    elif alg == "cnmf":
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-300)
+        run = lambda c: gpu_lib.cnmf(V, K, T, c)
+        ref = O.cnmf(V, K, T, cfg)
+    else:
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-300, W_sparsity=0.01)
+        run = lambda c: gpu_lib.nmf(V, K, c)
+        ref = O.nmf(V, K, cfg)
+    out = {}
+    for be in ("rccl", "peer"):
+        out[be] = run(dict(cfg, nmfx_gpus=[0], nmfx_multi_backend=be))
+        ms, cnt, used = C.c_double(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.load().nmfx_last_call_exchange(C.byref(ms), C.byref(cnt), C.byref(used)))
+        assert used.value == (2 if be == "rccl" else 1) and cnt.value == 6 and ms.value > 0
+    plain = run(cfg)
+    for a, b, c in zip(out["rccl"], out["peer"], plain):
+        assert np.array_equal(np.asarray(a), np.asarray(b)) and np.array_equal(np.asarray(a), np.asarray(c))
+    assert rel_fro(out["rccl"][0], ref[0]) <= 1e-5 and rel_fro(out["rccl"][1], ref[1]) <= 1e-5 and rel_fro(out["rccl"][2], ref[2]) <= (1e-5 if div == "is" else 1e-6)
+
+
+def test_blocking_api_rccl_backend_refuses_duplicate_devices(gpu_lib):
+    """RCCL takes distinct GPUs: asked for by name on [0, 0] it is an error with the reason; "auto" falls back to the peer exchange"""
+    import ctypes as C
+    from nmf_toolbox_amd import _lib
+    V, W0, H0 = synth(128, 512, 32)
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300, nmfx_gpus=[0, 0])
+    with pytest.raises(_lib.NmfxError) as ei:
+        gpu_lib.nmf(V, 32, dict(cfg, nmfx_multi_backend="rccl"))
+    assert ei.value.status == _lib.NMFX_ERR_UNSUPPORTED and "more than once" in str(ei.value)
+    gpu_lib.nmf(V, 32, cfg)
+    used = C.c_int32(0)
+    _lib.check(_lib.load().nmfx_last_call_exchange(None, None, C.byref(used)))
+    assert used.value == 1
