@@ -260,16 +260,21 @@ def bench_cnmfsc(args):
     f = 2.0 * m * n * K * T
     label = {names[0]: "objective passes: S = sum_t W_t*rshift_t(H) in registers -> 0.5||V - S||^2 (fused_kernel<K*T, ..., TT=T>, cost-only form; S stored as V_hat only where cnmfsc.m:215,269 keep it)",
              names[2]: "dH = sum_t W_t'*lshift_t(V_hat - V) as Q = W_flat'*(V_hat - V) (two-operand GEMM) + shift-sum",
-             names[3]: "W-step terms: V*H_stack' for all t in one fused pass; per slice V_hat*rshift_t(H)' and V_hat = max(V_hat + dW*rshift_t(H), 0) (functor 9, in place)"}
-    work = {names[0]: (f, 4.0 * (2 * m * n + m * K * T + K * n)), names[2]: (f, 4.0 * (2 * m * n + m * K * T + K * n)), names[3]: (f / T, 4.0 * (m * n + m * K + K * n))}
-    tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in work}
+             names[3]: "W-step terms (cnmfsc.m:257-263): V*H_stack' for all t in one fused pass; slice 0: V_hat*rshift_0(H)'; slice t >= 1 in ONE launch (functor 18): "
+                       "V_hat <- max(V_hat + dW_(t-1)*rshift_(t-1)(H), 0) stored in place and contracted with rshift_t(H) from the same registers"}
+    # flops / algorithmic bytes of a tag PER OUTER ITERATION (its launches differ: the W-step tag holds one K*T-wide pass, one K-wide pass and T-1 two-stage launches)
+    f18 = not os.environ.get("NMFX_SC_NO_F18")
+    per_it = {names[0]: (f * cnt[0] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[0] / total), names[2]: (f * cnt[2] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[2] / total),
+              names[3]: ((f * (3.0 - 1.0 / T), 4.0 * m * n * (2 + 2 * (T - 1))) if f18 else (3.0 * f, 4.0 * m * n * (1 + 3 * T)))}   # V once, V_hat once (slice 0) + read and written once per later slice
+    tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in per_it}
     roof = None
     if tags:
         name = max(tags, key=lambda k: tags[k][0])
-        avg_ms = tags[name][0] / tags[name][1]
-        ach = work[name][0] / (avg_ms * 1e-3) / 1e12
+        ms_it = tags[name][0] / total
+        ach = per_it[name][0] / (ms_it * 1e-3) / 1e12
         roof = dict(bound="mfma", kernel=label[name], achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                    avg_launch_ms=round(avg_ms, 4), launches=int(tags[name][1]), flops_per_launch=work[name][0], algorithmic_bytes_per_launch=work[name][1],
+                    ms_per_outer_iteration=round(ms_it, 4), launch_groups=int(tags[name][1]), flops_per_outer_iteration=per_it[name][0], algorithmic_bytes_per_outer_iteration=per_it[name][1],
+                    tag_frac_of_peak={k: round(per_it[k][0] / (tags[k][0] / total * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) for k in tags},
                     phases_ms_per_iteration_whole_call={names[t]: round(ms[t] / total, 4) for t in range(nt) if cnt[t] > 0})
     out = {"metric": "NMF multiplicative-update iterations/s", "value": round(its, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -312,20 +317,41 @@ def bench_blocking(args):
     W0 = np.fmax(rs(1).rand(m, K) if T == 1 else rs(1).rand(m, K, T), EPS)
     H0 = np.fmax(rs(2).rand(K, n), EPS)
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=args.steps, nmfx_disable_stop=True)
-    run = (lambda: A.nmf(V, K, cfg)) if alg == "nmf" else (lambda: A.cnmf(V, K, T, cfg))
     A.nmf(np.asfortranarray(V[:256, :512]), 16, dict(divergence=div, maxiter=1))     # first-call costs (context, code objects, the pinned buffers) are not ingest
-    t0 = time.perf_counter()
-    W, H, c = run()
-    wall = time.perf_counter() - t0
-    tm = _lib.last_call_timing()
-    out = {"metric": "blocking host-buffer call, end to end (NOT the BASELINE metric)", "workload": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div,
-           "host_dtype": args.host_dtype, "iterations": args.steps, "call_wall_s": round(wall, 4), "ingest_s": round(tm["ingest_s"], 4),
-           "iterate_s": round(tm["iterate_s"], 4), "egress_s": round(tm["egress_s"], 4), "python_wrapper_s": round(wall - tm["ingest_s"] - tm["iterate_s"] - tm["egress_s"], 4),
-           "host_bytes_in": tm["host_bytes_in"], "GBps_h2d": round(tm["host_bytes_in"] / max(tm["ingest_s"], 1e-9) / 1e9, 2),
-           "host_bytes_out": tm["host_bytes_out"], "GBps_d2h": round(tm["host_bytes_out"] / max(tm["egress_s"], 1e-9) / 1e9, 2),
-           "ms_per_iteration_inside": round(1e3 * tm["iterate_s"] / args.steps, 4), "host_cores": os.cpu_count(),
-           "cost_first_last": [float(c[0]), float(c[-1])]}
-    print(json.dumps(out), flush=True)
+    # --gpus N: the single-process sharded driver behind the same call (nmfx_problem.n_gpus), ONE LINE PER EXCHANGE BACKEND -- RCCL (ncclAllReduce on every
+    # device's stream) and the peer reduce-scatter + all-gather -- so that the first multi-GPU lease is an A/B.  N = 1 runs both with one shard.
+    import ctypes as C
+    lib = _lib.load()
+    backends = [None] if args.gpus <= 1 and not args.backends else [b for b in (args.backends or "rccl,peer").split(",") if b]
+    for be in backends:
+        c2 = dict(cfg) if be is None else dict(cfg, nmfx_gpus=list(range(max(args.gpus, 1))), nmfx_multi_backend=be)
+        run = (lambda: A.nmf(V, K, c2)) if alg == "nmf" else (lambda: A.cnmf(V, K, T, c2))
+        t0 = time.perf_counter()
+        try:
+            W, H, c = run()
+        except _lib.NmfxError as ex:
+            print(json.dumps({"metric": "blocking host-buffer call, end to end (NOT the BASELINE metric)", "workload": args.workload, "n_gpus": args.gpus, "backend": be, "error": str(ex)}), flush=True)
+            continue
+        wall = time.perf_counter() - t0
+        tm = _lib.last_call_timing()
+        out = {"metric": "blocking host-buffer call, end to end (NOT the BASELINE metric)", "workload": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div,
+               "host_dtype": args.host_dtype, "iterations": args.steps, "call_wall_s": round(wall, 4), "ingest_s": round(tm["ingest_s"], 4),
+               "iterate_s": round(tm["iterate_s"], 4), "egress_s": round(tm["egress_s"], 4), "python_wrapper_s": round(wall - tm["ingest_s"] - tm["iterate_s"] - tm["egress_s"], 4),
+               "host_bytes_in": tm["host_bytes_in"], "GBps_h2d": round(tm["host_bytes_in"] / max(tm["ingest_s"], 1e-9) / 1e9, 2),
+               "host_bytes_out": tm["host_bytes_out"], "GBps_d2h": round(tm["host_bytes_out"] / max(tm["egress_s"], 1e-9) / 1e9, 2),
+               "ms_per_iteration_inside": round(1e3 * tm["iterate_s"] / args.steps, 4), "host_cores": os.cpu_count(),
+               "cost_first_last": [float(c[0]), float(c[-1])]}
+        if be is not None:
+            ms, cnt, used, ver = C.c_double(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.nmfx_last_call_exchange(C.byref(ms), C.byref(cnt), C.byref(used)))
+            mK = m * K * T
+            payload = 4 * (mK + (K * T if div == "kl" else (K * T) ** 2))
+            p_ = max(args.gpus, 1)
+            out.update(n_gpus=p_, backend=be, backend_used={1: "peer", 2: "rccl"}.get(used.value, "?"), allreduce_ms_per_step=round(ms.value, 4), allreduces_timed=cnt.value,
+                       allreduce_bytes=payload, allreduce_busbw_GBps=round(2.0 * (p_ - 1) / p_ * payload / max(ms.value * 1e-3, 1e-12) / 1e9, 2) if p_ > 1 else None,
+                       rccl_library=(lib.nmfx_rccl_library(C.byref(ver)) or b"").decode(), rccl_version=ver.value,
+                       note="one process, one host thread, one stream + engine per device (what a MEX caller of nmf() gets); ingest / iterate include the per-device uploads")
+        print(json.dumps(out), flush=True)
 
 
 def self_launch(n):
@@ -362,6 +388,7 @@ def main():
                     help="engine: device-resident phase API (the metric).  blocking: ONE call of the host-buffer entry point a MATLAB user makes "
                          "(nmf.m:1 / cnmf.m:1) on float64 host arrays -- prints ingest_s / iterate_s / egress_s / GBps_h2d, not the metric")
     ap.add_argument("--host-dtype", default="f64", choices=["f64", "f32"], help="--api blocking: precision of the host arrays")
+    ap.add_argument("--backends", default="", help="--api blocking: comma list of exchange backends to run, one JSON line each (rccl, peer); default with --gpus N > 1: both")
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="device spin-up before the W warm-up steps: the W-step partial of the engine (it changes neither W nor H) is launched untimed until this much "
                          "wall time has passed, so that the warm-up and the timed region run at the sustained clock, not on the ramp from idle (rocm-smi: 1.36 -> 2.39 GHz over "

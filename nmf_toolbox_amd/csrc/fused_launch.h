@@ -6,8 +6,8 @@ namespace nmfx {
 
 template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, bool RAG>
 static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) {
-    const size_t ldsb = sizeof(float) * 2 * FT_C * (K + 4);
-    auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, EPI, 0, RAG>;
+    const size_t ldsb = sizeof(float) * 2 * (FT_C + (FUNC == 18 ? 1 : 0)) * (K + 4);
+    auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, EPI, RAG>;
     static bool attr_done = false;
     if (!attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
@@ -24,7 +24,7 @@ static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) 
 template <int K, int FUNC, bool DO_G2, int TT>
 static nmfx_status launch_one_T(hipStream_t st, const FusedParams &p, int nsplit) {
     const size_t ldsb = sizeof(float) * 2 * (FT_C + TT - 1) * (K / TT + 4);
-    auto kern = fused_kernel<K, true, FUNC, DO_G2, 0, 0, true, TT>;
+    auto kern = fused_kernel<K, true, FUNC, DO_G2, 0, true, TT>;
     static bool attr_done = false;
     if (!attr_done) {
         NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
@@ -65,6 +65,7 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 17: if constexpr (EPI == 0 && DO_G2) return launch_one<K, D_RC, 17, DO_G2, EPI, RAG>(st, p, nsplit); break;   // alpha-beta dual form (alpha == 0): numerators; any K
     case 15: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 15, DO_G2, EPI, RAG>(st, p, nsplit); break;   // 11 / 13 + the second map's values to p.Rout
     case 16: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 16, DO_G2, EPI, RAG>(st, p, nsplit); break;
+    case 18: if constexpr (DO_G2 && D_RC && EPI == 0 && K <= 128) return launch_one<K, D_RC, 18, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:257-263, one launch per slice
     case 9: if constexpr (!DO_G2 && D_RC && K <= 128) return launch_one<K, D_RC, 9, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:262 (K = components of one time slice)
     }
     set_error("launch_fused: unsupported functor %d", func);

@@ -782,6 +782,20 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         PScope ps(pf, SC_WTERMS);
         return launch_fused(st, f, nsplitK, true, 9, false, 0);
     };
+    // (fused) slice t >= 1 of the multiplicative W branch in ONE launch (functor 18): V_hat <- max(V_hat + dWprev * rshift_{t-1}(Hx), 0) -- the correction of slice
+    // t-1, cnmfsc.m:262 -- stored in place, and out (m x K) = V_hat * rshift_t(Hx)' from the same registers (the `pos` of slice t, cnmfsc.m:259): V_hat read once
+    // and written once per slice
+    auto pos_update_fused = [&](const float *dWprev, const float *Hx, int t, float *out) -> nmfx_status {
+        TRY(ensure_hpad(Hx));
+        FusedParams f; memset(&f, 0, sizeof(f));
+        f.X = dWprev; f.xs_r = 1; f.xs_k = m;
+        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = Vh.as<float>(); f.Rout = Vh.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
+        f.out = nsplitK == 1 ? out : slabsb.as<float>(); f.slab_stride = (long)mK; f.os_r = 1; f.os_k = m;
+        PScope ps(pf, SC_WTERMS);
+        TRY(launch_fused(st, f, nsplitK, true, 18, true, 0));
+        if (nsplitK > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitK, (long)mK, (long)mK, out, 0));
+        return NMFX_OK;
+    };
     auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
         if (fusedsc && !X2) return xht_fused(X, Hx, t, out);
         PScope ps(pf, SC_WTERMS);
@@ -904,8 +918,14 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 } else {
                     const float *negt = fusedsc ? G1.as<float>() + (size_t)t * mK : G1.as<float>();
                     if (!fusedsc) TRY(xht(V.as<float>(), H, t, G1.as<float>()));                 // neg = V * Hs'
+                    static const bool no_f18 = getenv("NMFX_SC_NO_F18") != nullptr;                  // dev switch (A/B runs): functor 0 + functor 9 per slice, as in round 4
+                    if (fusedsc && t > 0 && !no_f18) TRY(pos_update_fused(Wnew, H, t, G2.as<float>()));   // cnmfsc.m:262 of slice t-1 and pos = V_hat * Hs' of slice t in ONE launch
+                    else
                     TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
                     TRY(mu_plain_diff(st, W0t, negt, G2.as<float>(), (long)mK, Wt, Wnew));           // W_t = W0_t .* (neg ./ max(pos, eps)), dW = W_t - W0_t   cnmfsc.m:261 (one launch)
+                    // (fused) the correction of slice t is applied by the launch of slice t+1; the LAST slice's is never needed: cnmfsc.m:269 re-forms V_hat from
+                    // (W, H) right after the loop, so the result of cnmfsc.m:262 at t = T is dead in the reference too
+                    if (fusedsc && !no_f18) continue;
                     if (fusedsc) { TRY(vhat_update_fused(Wnew, H, t)); continue; }                   // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     g.M = m; g.N = n; g.Kc = K;

@@ -23,7 +23,7 @@ for f in files:
     for s in starts:
         key = lines[s].split(":")[0]
         end = next(i for i in range(s, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a body may hold several s_endpgm: early exits)
-        m = re.search(r"ILi(\d+)ELb([01])ELi(\d)ELb([01])ELi(\d)", key)
+        m = re.search(r"ILi(\d+)ELb([01])ELi(\d+)ELb([01])ELi(\d)", key)
         K, func, g2 = int(m.group(1)), int(m.group(3)), int(m.group(4))
         if func == 2 and not g2:
             continue                                  # instantiated but never launched (no cost, no second product)
