@@ -258,14 +258,13 @@ def bench_cnmfsc(args):
     its = args.steps / dt
     tries = info["triesH"]
     f = 2.0 * m * n * K * T
-    label = {names[0]: "objective passes: S = sum_t W_t*rshift_t(H) in registers -> 0.5||V - S||^2 (fused_kernel<K*T, ..., TT=T>, cost-only form; S stored as V_hat only where cnmfsc.m:215,269 keep it)",
+    label = {names[0]: "objective passes: S = sum_t W_t*rshift_t(H) in registers -> 0.5||V - S||^2 (fused_kernel<K*T, ..., TT=T>, cost-only form; S stored as V_hat only at cnmfsc.m:269, for the next H step)",
              names[2]: "dH = sum_t W_t'*lshift_t(V_hat - V) as Q = W_flat'*(V_hat - V) (two-operand GEMM) + shift-sum",
-             names[3]: "W-step terms (cnmfsc.m:257-263): V*H_stack' for all t in one fused pass; slice 0: V_hat*rshift_0(H)'; slice t >= 1 in ONE launch (functor 18): "
-                       "V_hat <- max(V_hat + dW_(t-1)*rshift_(t-1)(H), 0) stored in place and contracted with rshift_t(H) from the same registers"}
-    # flops / algorithmic bytes of a tag PER OUTER ITERATION (its launches differ: the W-step tag holds one K*T-wide pass, one K-wide pass and T-1 two-stage launches)
-    f18 = not os.environ.get("NMFX_SC_NO_F18")
+             names[3]: "W-step terms (cnmfsc.m:257-263) without V_hat: N = V*H_stack' for all t in ONE fused pass over V; G = Hs*Hs' from the T lag Grams of H; the slice loop "
+                       "pos_t = sum_s Wcur_s*G[(s,.),(t,.)], W_t = W0_t.*N_t./max(pos_t, eps) in one launch over the rows of W (aux.hip::cnmfsc_w_slices)"}
+    # flops / algorithmic bytes of a tag PER OUTER ITERATION.  The W-step tag: the pass over V (2*m*n*K*T), the lag Grams (2*K*KT*n) and the slice loop (2*m*KT*KT)
     per_it = {names[0]: (f * cnt[0] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[0] / total), names[2]: (f * cnt[2] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[2] / total),
-              names[3]: ((f * (3.0 - 1.0 / T), 4.0 * m * n * (2 + 2 * (T - 1))) if f18 else (3.0 * f, 4.0 * m * n * (1 + 3 * T)))}   # V once, V_hat once (slice 0) + read and written once per later slice
+              names[3]: (f + 2.0 * K * K * T * n + 2.0 * m * (K * T) ** 2, 4.0 * (m * n + 3 * m * K * T + 2 * K * n))}
     tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in per_it}
     roof = None
     if tags:
@@ -281,7 +280,7 @@ def bench_cnmfsc(args):
            "config": {"workload": "cnmfsc.m (Hoyer projection on H, H_sparsity=%g) outer iterations, V=%dx%d K=%d T=%d fp32 on 1 GPU" % (args.h_sparsity, m, n, K, T),
                       "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": "euclidean", "H_sparsity": args.h_sparsity, "line_search_tries_H": tries,
                       "timed_region": "outer iterations %d..%d of one blocking call, by the library's per-iteration completion times" % (args.warmup + 1, total)},
-           "effective_tflops": round((12.0 + 2.0 * float(np.mean(tries[args.warmup:]))) * m * n * K * T * its / 1e12, 3),
+           "effective_tflops": round((12.0 + 2.0 * float(np.mean(tries[args.warmup:]))) * m * n * K * T * its / 1e12, 3),   # the REFERENCE's flop count per outer iteration (cnmfsc.m), not what the kernels issue
            "cost_first_last": [float(c[0]), float(c[-1])], "roofline": roof}
     if not args.no_cpu_baseline:
         try:

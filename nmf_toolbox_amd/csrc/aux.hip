@@ -1112,6 +1112,86 @@ nmfx_status mu_plain_diff(hipStream_t st, const float *X0, const float *neg, con
     return NMFX_OK;
 }
 
+// cnmfsc.m:257-263, the whole slice loop of the multiplicative W branch in ONE launch and without V_hat.  The reference keeps V_hat = sum_s W_s*rshift_s(H) up to date
+// slice by slice (cnmfsc.m:262) only to contract it with rshift_t(H)' in the next slice (cnmfsc.m:259); with G = Hs*Hs' (KT x KT, the Gram of the stacked shifts)
+//   pos_t = V_hat*rshift_t(H)' = sum_s Wcur_s * G[(s,.),(t,.)],     Wcur_s = the UPDATED slice for s < t, W0_s for s >= t
+// row by row of W: no pass over an m x n array at all (per slice the reference's form costs one read and one write of V_hat).  The max(., 0) of cnmfsc.m:262 never
+// binds on the data cnmfsc accepts: V_hat + dW*Hs = sum_s Wcur_s*Hs_s is a sum of products of non-negative factors (V >= 0 is checked at cnmfsc.m:67, H leaves the
+// projection / the multiplicative update non-negative, W_t = W0_t .* neg ./ max(pos, eps) >= 0); it only removes negative ROUNDING residue, at the 1e-16 level in the
+// reference's float64.  One workgroup per 16 rows of W: the rows' KT entries live in LDS and are overwritten slice by slice, G streams through LDS in chunks of 32 rows
+// (prefetched into registers while the previous chunk is contracted), 32-term fp32 partial sums accumulated in double.  N = V*H_stack' (m x KT) from the one fused
+// pass over V.  The last slice's correction is dead in the reference too (cnmfsc.m:269 re-forms V_hat).
+template <int K>
+__global__ __launch_bounds__(256) void cnmfsc_w_slices_kernel(const float *W0, const float *Nn, const float *G, long m, int T, float *W) {
+    constexpr int ROWS = 16, RG = 256 / K, RPT = ROWS / RG, CH = 32, GPT = CH * K / 256;
+    extern __shared__ float lds_ws[];
+    const int KT = K * T, ldw = KT + 4;
+    float *w = lds_ws;               // [ROWS][ldw]: the current W of these rows
+    float *g = lds_ws + ROWS * ldw;  // [CH][K]: a chunk of G(:, (t,.)); afterwards pos_t of these rows, [ROWS][K]
+    const int tid = threadIdx.x, k = tid % K, rg = tid / K;
+    const long row0 = (long)blockIdx.x * ROWS;
+    for (int i = tid; i < ROWS * KT; i += 256) {
+        const int r = i % ROWS, c = i / ROWS;
+        w[r * ldw + c] = row0 + r < m ? W0[row0 + r + m * (long)c] : 0.0f;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float *Gt = G + (long)t * K;   // G is symmetric: column (t,k) read as row (t,k), contiguous along k
+        double acc[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) acc[r] = 0.0;
+        float gn[GPT];
+#pragma unroll
+        for (int q = 0; q < GPT; ++q) { const int i = tid + 256 * q; gn[q] = Gt[i % K + (long)KT * (i / K)]; }
+        for (int c0 = 0; c0 < KT; c0 += CH) {
+            __syncthreads();   // the previous chunk is consumed (first chunk: the rows' slice t-1 / the initial load is visible, pos_(t-1) is consumed)
+#pragma unroll
+            for (int q = 0; q < GPT; ++q) g[tid + 256 * q] = gn[q];
+            __syncthreads();
+            if (c0 + CH < KT) {
+#pragma unroll
+                for (int q = 0; q < GPT; ++q) { const int i = tid + 256 * q; gn[q] = Gt[i % K + (long)KT * (c0 + CH + i / K)]; }
+            }
+            float a32[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) a32[r] = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < CH; cc += 4) {
+                const float g0 = g[cc * K + k], g1 = g[(cc + 1) * K + k], g2 = g[(cc + 2) * K + k], g3 = g[(cc + 3) * K + k];
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(&w[(rg * RPT + r) * ldw + c0 + cc]);
+                    a32[r] += wv.x * g0 + wv.y * g1 + wv.z * g2 + wv.w * g3;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) acc[r] += (double)a32[r];
+        }
+        __syncthreads();       // every read of the last chunk and of the rows' W is done
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) g[(rg * RPT + r) * K + k] = (float)acc[r];
+        __syncthreads();
+        for (int i = tid; i < ROWS * K; i += 256) {   // W_t = W0_t .* (neg ./ max(pos, eps))   cnmfsc.m:261, 16 consecutive rows per column: 64-byte segments
+            const int r = i % ROWS, kk = i / ROWS;
+            if (row0 + r >= m) continue;
+            const long idx = row0 + r + m * ((long)t * K + kk);
+            const float xn = w[r * ldw + t * K + kk] * (Nn[idx] / fmaxf(g[r * K + kk], NMFX_EPS_F));
+            W[idx] = xn;
+            w[r * ldw + t * K + kk] = xn;
+        }
+    }
+}
+nmfx_status cnmfsc_w_slices(hipStream_t st, const float *W0, const float *Nn, const float *G, long m, int K, int T, float *W) {
+    if (m <= 0) return NMFX_OK;
+    const size_t lds = sizeof(float) * (16 * ((size_t)K * T + 4) + 32 * (size_t)K);
+    if ((K != 32 && K != 64 && K != 128) || lds > 64 * 1024) { set_error("cnmfsc_w_slices: K = %d, T = %d is not served", K, T); return NMFX_ERR_UNSUPPORTED; }
+    const dim3 grid((unsigned)((m + 15) / 16)), block(256);
+    if (K == 32) hipLaunchKernelGGL(cnmfsc_w_slices_kernel<32>, grid, block, lds, st, W0, Nn, G, m, T, W);
+    else if (K == 64) hipLaunchKernelGGL(cnmfsc_w_slices_kernel<64>, grid, block, lds, st, W0, Nn, G, m, T, W);
+    else hipLaunchKernelGGL(cnmfsc_w_slices_kernel<128>, grid, block, lds, st, W0, Nn, G, m, T, W);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+
 // X <- X .* (neg ./ (pos + eps))     cnmfsc.m:202 (plus, not max)
 __global__ void mu_plus_eps_kernel(float *X, const float *neg, const float *pos, long count) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -650,7 +650,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     const bool fusedsc = p->path != 1 && fused_supported_T(K, T) && fused_supported(K) && K <= 128 && m >= 64 && n >= 64 && m % 4 == 0 &&
                          (p->path == 2 || (!small64 && !small64h));
     if (p->path == 2 && !fusedsc) { set_error("cnmfsc: fused passes requested but the problem is not eligible (an instantiated (K, T) pair, m and n >= 64, m a multiple of 4)"); return NMFX_ERR_UNSUPPORTED; }
-    DevBuf Hpadb, slabsb, Qb, DDb, Dlb, Zb, qpartsb;
+    DevBuf Hpadb, slabsb, Qb, DDb, Dlb, Zb, qpartsb, Llagb, Ggb;
     long cpsT = 0, cpsK = 0;
     int nsplitT = 1, nsplitK = 1;
     // H line search: objectives from the quadratic expansion (see run_nmfsc): obj(H + D) - obj(H) = <dH, D> + 0.5*<Ds, (W_flat'*W_flat)*Ds>, Ds = D stacked with its
@@ -663,7 +663,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (fusedsc) {
         nsplitT = fused_split((m + 127) / 128, n, KT, &cpsT);
         nsplitK = fused_split((m + 127) / 128, n, K, &cpsK);
-        TRY(Hpadb.alloc((size_t)K * (n + T - 1) * 4));
+        TRY(Hpadb.alloc((size_t)K * (n + 2 * (T - 1)) * 4));   // [T-1 zero columns | H | T-1 zero columns (the lag Grams of the W branch)]
         TRY(slabsb.alloc(std::max((size_t)nsplitT * mKT, (size_t)nsplitK * mK) * 4));
         TRY(Qb.alloc((size_t)KT * n * 4));
     }
@@ -675,6 +675,12 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * std::max<size_t>(gemm_grid_blocks(m, n), (size_t)((m + 127) / 128) * std::max(nsplitT, nsplitK)))); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
     if (fusedsc) sb = std::max(sb, std::max(gemm_scratch_bytes(KT, n, m), std::max(gemm_scratch_bytes(KT, KT, m), gemm_scratch_bytes(KT, n, KT))));
+    // Multiplicative W branch without V_hat (aux.hip::cnmfsc_w_slices): the slice loop of cnmfsc.m:257-263 from N = V*H_stack' and the Gram of the stacked shifts
+    const bool gramW = fusedsc && !(sW > 0) && !fixW;
+    if (gramW) {
+        TRY(Llagb.alloc((size_t)K * KT * 4)); TRY(Ggb.alloc((size_t)KT * KT * 4));
+        sb = std::max(sb, gemm_scratch_bytes(K, KT, n));
+    }
     TRY(scratch.alloc(sb));
     TRY(upload(st, p->V, p->dtype, V.as<float>(), mn, vmax));
     TRY(upload(st, p->W_init, p->dtype, W0b.as<float>(), mKT, 1.0));
@@ -701,7 +707,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     const float *hpad_of = nullptr;
     auto ensure_hpad = [&](const float *Hx) -> nmfx_status {
         if (hpad_of == Hx) return NMFX_OK;
-        TRY(pad_left(st, Hx, K, n, T - 1, Hpadb.as<float>()));
+        TRY(pad_left(st, Hx, K, n, T - 1, Hpadb.as<float>(), T - 1));
         hpad_of = Hx;
         return NMFX_OK;
     };
@@ -886,10 +892,25 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
             }
         }
         if (!fixW) {
-            double begobj;
-            TRY(rfd(W0, H, &begobj));                                                            // cnmfsc.m:215
+            double begobj = 0;
+            if (!gramW) TRY(rfd(W0, H, &begobj));                                                // cnmfsc.m:215 (the multiplicative branch below uses neither V_hat nor its objective)
             if (fusedsc && !(sW > 0)) TRY(vht_all_fused(H, G1.as<float>()));                     // neg_t = V * rshift_t(H)' for every t: V and H do not change inside the loop
-            for (int t = 0; t < T && !early; ++t) {
+            if (gramW) {
+                // pos_t = V_hat*rshift_t(H)' = sum_s Wcur_s * (Hs*Hs')[(s,.),(t,.)] with the slices s < t already updated (cnmfsc.m:259-262): the Gram of the stacked
+                // shifts from the T lag Grams L_d = sum_u H(:,u) H(:,u+d)' (one K x KT x n product on the zero-padded copy, as cnmf's W step forms it) and the
+                // whole slice loop in one launch over the rows of W
+                PScope ps(pf, SC_WTERMS);
+                const float *Hc = Hpadb.as<float>() + (size_t)K * (T - 1);   // (vht_all_fused padded this H)
+                GemmParams g; memset(&g, 0, sizeof(g));
+                g.M = K; g.N = KT; g.Kc = n;
+                g.A = OpView{Hc, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{Hc + (size_t)K * (T - 1), nullptr, (long)K, VIEW_HSTACK_RC, K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, T - 1};
+                g.C = Llagb.as<float>(); g.ldc = K; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(st, g, scratch.p, sb));
+                TRY(gram_from_lags(st, Llagb.as<float>(), H, K, T, n, Ggb.as<float>()));
+                TRY(cnmfsc_w_slices(st, W0, G1.as<float>(), Ggb.as<float>(), m, K, T, W));
+            }
+            for (int t = 0; t < T && !early && !gramW; ++t) {
                 float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
                 if (sW > 0) {
                     if (small64) TRY(resid_xht64(st, V.as<float>(), Vh.as<float>(), m, n, H, K, t, s64.as<double>(), nch64, g64.as<double>()));   // dW in fp64 (small problems)
