@@ -42,6 +42,8 @@ WORKLOADS = {
     "c4kl": ("cnmf", "kl", 4096, 16384, 64, 8, 16.0),          # config 4's shape with the KL divergence (fused S / numerator passes; dev aid)
     "c2is": ("nmf", "is", 8192, 32768, 128, 1, 12.0),         # config 2's shape with the Itakura-Saito divergence (dual-map fused kernels; dev aid)
     "c2is256": ("nmf", "is", 8192, 32768, 256, 1, 12.0),      # ... with K = 256: above 192 the two element maps run as two single-map passes per half-iteration (dev aid)
+    "c4is": ("cnmf", "is", 4096, 16384, 64, 8, 12.0),          # config 4's shape with the Itakura-Saito divergence (dev aid)
+    "c2is512": ("nmf", "is", 8192, 32768, 512, 1, 12.0),      # ... and nmf with a factor wider than the register-stationary kernels hold (dev aid)
     "c5": ("nmfsc", "euclidean", 8192, 32768, 128, 1, 12.0),   # H_sparsity 0.5; F_alg = (5 + tries)*2mnK = 12 mnK at one try per line search
     "c4sc": ("cnmfsc", "euclidean", 4096, 16384, 64, 8, 14.0),  # config 4's shape through cnmfsc.m, H_sparsity 0.5; (12 + 2*tries)*mnKT per outer iteration
     "tiny": ("nmf", "kl", 512, 1024, 16, 1, 8.0),
@@ -51,10 +53,11 @@ WORKLOADS = {
 }
 
 
-CPU_SAMPLE_COLS = {"c3": 4096, "c2": 8192, "c2is": 8192, "c2is256": 4096, "c4": 4096, "c4kl": 4096, "tiny": 1024}
+CPU_SAMPLE_COLS = {"c3": 4096, "c2": 8192, "c2is": 8192, "c2is256": 4096, "c2is512": 2048, "c4": 4096, "c4kl": 4096, "c4is": 4096, "tiny": 1024}
 
 
-PMC_KERNEL_SOURCES = ("fused_kernel.h", "fused_launch.h", "fused.hip", "gemm_pipe.h", "gemm_common.h")
+# what decides a launch's HBM traffic: the kernels, and the files that set grid / column-split geometry (the workgroup order over the XCDs decides L2 reuse)
+PMC_KERNEL_SOURCES = ("fused_kernel.h", "fused_launch.h", "fused.hip", "gemm_pipe.h", "gemm_common.h", "engine.hip", "sc.hip")
 
 
 def kernel_sources_sha16():

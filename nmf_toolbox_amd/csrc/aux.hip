@@ -1588,31 +1588,24 @@ __global__ void scale_div_kernel(const float *X, long count, double divide_by, f
     if (i < count) out[i] = (float)((double)X[i] / divide_by);   // the value the host-side ingest of the blocking call produces (host_io.hip::narrow)
 }
 
-}  // namespace nmfx
-
-extern "C" {
-
-nmfx_status nmfx_minmax_dev(void *stream, const float *X_dev, int64_t count, double *out_dev) {
-    using namespace nmfx;
-    if (!X_dev || !out_dev || count <= 0) { set_error("nmfx_minmax_dev: bad arguments"); return NMFX_ERR_INVALID; }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+// out_dev[0] = max(X), out_dev[1] = -min(X): both combine under a MAX all-reduce (nmfsc.m:57-62 on a column shard).  The caller has selected X_dev's device.
+nmfx_status minmax_dev(hipStream_t st, const float *X_dev, long count, double *out_dev) {
     // stage-1 partials live in a per-call device buffer freed in stream order (a shard is preprocessed once per factorisation: not a hot path)
     float *part = nullptr;
     NMFX_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), sizeof(float) * 2 * MM_BLOCKS, st));
     const int nblk = (int)std::min<long>(MM_BLOCKS, (count + 255) / 256);
-    hipLaunchKernelGGL(minmax_stage1_kernel, dim3(nblk), dim3(256), 0, st, X_dev, (long)count, part);
+    hipLaunchKernelGGL(minmax_stage1_kernel, dim3(nblk), dim3(256), 0, st, X_dev, count, part);
     hipLaunchKernelGGL(minmax_stage2_kernel, dim3(1), dim3(256), 0, st, part, nblk, out_dev);
     hipError_t le = hipGetLastError();
     hipError_t fe = hipFreeAsync(part, st);
     if (le != hipSuccess || fe != hipSuccess) { set_error("nmfx_minmax_dev: %s", hipGetErrorString(le != hipSuccess ? le : fe)); return NMFX_ERR_HIP; }
     return NMFX_OK;
 }
-nmfx_status nmfx_scale_dev(void *stream, const float *X_dev, int64_t count, double divide_by, float *out_dev) {
-    using namespace nmfx;
-    if (!X_dev || !out_dev || count <= 0 || !(divide_by != 0.0)) { set_error("nmfx_scale_dev: bad arguments"); return NMFX_ERR_INVALID; }
-    hipLaunchKernelGGL(scale_div_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), X_dev, (long)count, divide_by, out_dev);
+// out = X / divide_by in double, rounded once (nmfsc.m:62).  divide_by == 0 divides all the same: an all-zero V becomes NaN as in the reference.
+nmfx_status scale_div(hipStream_t st, const float *X_dev, long count, double divide_by, float *out_dev) {
+    hipLaunchKernelGGL(scale_div_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, X_dev, count, divide_by, out_dev);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
 
-}  // extern "C"
+}  // namespace nmfx

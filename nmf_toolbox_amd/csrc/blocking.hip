@@ -66,7 +66,9 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     // K rounded up to a multiple of 32 with zero, fixed components opens the fused kernels to any K <= 256 on tileable shapes: the
     // padding contributes exact zeros to W*H and to every sum, and is never updated (it is stripped again on the way out)
     const int dv = p->divergence;
-    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256;   // fused IS / alpha-beta (above K = 192, and the dual form alpha == 0, in two passes)
+    // fused IS / alpha-beta (above K = 192, and the dual form alpha == 0, in two passes); constrainednmf has no dual-form kernels (fill_from_desc refuses
+    // dualz for algorithm 3): padding K there would only widen the general path
+    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256 && !(algorithm == 3 && dv == NMFX_DIV_AB && p->alpha == 0);
     int Kup = (Kt + 31) / 32 * 32;
     // cnmf: the same zero padding opens the fused shift-sum passes to any K below an instantiated (K, T) pair (K = 20, T = 8 runs as (32, 8); K = 20, T = 2 as
     // (64, 2), the smallest pair with that context length)
@@ -398,7 +400,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
     for (int g = 0; g < N; ++g) M.lo[g + 1] = M.lo[g] + n / N + (g < n % N ? 1 : 0);   // contiguous column blocks, as engine.shard_columns
     long nmin = n;
     for (int g = 0; g < N; ++g) nmin = std::min(nmin, M.lo[g + 1] - M.lo[g]);
-    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256;
+    const bool dual_ok = (dv == NMFX_DIV_IS || dv == NMFX_DIV_AB) && Kt <= 256 && !(algorithm == 3 && dv == NMFX_DIV_AB && p->alpha == 0);
     const bool pad = algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && m >= 64 && nmin >= 64)) && ((m >= 64 && nmin >= 64) || p->path == 2) &&
                      p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok);
     const int K = pad ? (Kt + 31) / 32 * 32 : Kt;
@@ -671,6 +673,25 @@ nmfx_status nmfx_projfunc_dev(void *stream, float *X_dev, int64_t N, int32_t cou
     if (hipPointerGetAttributes(&attr, X_dev) != hipSuccess) { (void)hipGetLastError(); set_error("nmfx_projfunc_dev: X_dev is not a device pointer"); return NMFX_ERR_INVALID; }
     TRY(check_device(attr.device));
     return projfunc_cols(static_cast<hipStream_t>(stream), X_dev, N, count, k1, k2, nn, usediters_dev, dir_dev, mu, src_dev);
+}
+
+// the device that owns a device pointer, selected (the caller's current device is restored by the DeviceGuard of the entry point)
+static nmfx_status select_owner(const void *ptr, const char *what) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); set_error("%s: not a device pointer", what); return NMFX_ERR_INVALID; }
+    return check_device(attr.device);
+}
+nmfx_status nmfx_minmax_dev(void *stream, const float *X_dev, int64_t count, double *out_dev) {
+    if (!X_dev || !out_dev || count <= 0) { set_error("nmfx_minmax_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;   // launch (and allocate the partials) on the device X lives on, whatever the caller's current device is
+    TRY(select_owner(X_dev, "nmfx_minmax_dev"));
+    return minmax_dev(static_cast<hipStream_t>(stream), X_dev, (long)count, out_dev);
+}
+nmfx_status nmfx_scale_dev(void *stream, const float *X_dev, int64_t count, double divide_by, float *out_dev) {
+    if (!X_dev || !out_dev || count <= 0) { set_error("nmfx_scale_dev: bad arguments"); return NMFX_ERR_INVALID; }
+    DeviceGuard dg_;
+    TRY(select_owner(X_dev, "nmfx_scale_dev"));
+    return scale_div(static_cast<hipStream_t>(stream), X_dev, (long)count, divide_by, out_dev);
 }
 
 nmfx_status nmfx_projfunc(int64_t N, int32_t count, int32_t dtype, const void *s, double k1, double k2, int32_t nn, void *v,

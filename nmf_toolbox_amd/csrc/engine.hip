@@ -1001,7 +1001,8 @@ static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const doub
                 TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
                 NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
                 NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
-                memset(e->exact_flag_host, 0, 64);
+                NMFX_HIP(hipStreamSynchronize(e->st));   // decisions of an earlier run of this engine may still be queued: their late writes into the stamped slots would
+                memset(e->exact_flag_host, 0, 64);       // satisfy the NEW run's wait for a decision of the same number (stamps restart at 1)
                 e->classic = false; e->decide_seq = 0;
             }
             if (e->dual && e->div == NMFX_DIV_AB) {   // sum(V.^(alpha+beta)) for the cost, V.^alpha as the kernels' data operand; once
@@ -1021,6 +1022,7 @@ static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const doub
             TRY(sum_vec(e->st, e->colV, e->n, e->sumVV));
             NMFX_HIP(hipMemcpyAsync(e->sumVV + 1, e->sumVV, sizeof(double), hipMemcpyDeviceToDevice, e->st));
             NMFX_HIP(hipMemsetAsync(e->exact_flag, 0, 64, e->st));
+            NMFX_HIP(hipStreamSynchronize(e->st));   // (as above: no decision of an earlier run may land in the slots after this)
             memset(e->exact_flag_host, 0, 64);
             e->classic = false; e->decide_seq = 0;
             e->cost_valid = false;
@@ -1630,13 +1632,14 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
         if (e->fusedT || e->fusedT_kl || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
+        if (e->dualz) { *flops = 1.5 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // alpha == 0: functor 17 (S + one contraction) and functor 0 (one contraction), averaged over the two launches
         if (e->dual2 && e->Vhat) { *flops = 1.5 * f; *bytes = 4.0 * (2.0 * m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch, averaged over the two of a W step: S + one contraction (+ the m x n store), then one contraction
         if (e->dual2) { *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch (two per W step): S + one contraction
         if (e->dual) { *flops = 3.0 * f; *bytes = 4.0 * (m * n + 3.0 * m * KT + e->K * n); return NMFX_OK; }   // S + two contractions
         if (e->wstep_gram) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // numerators only: one contraction
         *flops = 2.0 * f / ch; *bytes = 4.0 * (m * n / ch + 2.0 * m * KT / ch + e->K * n); return NMFX_OK;
     }
-    case TAG_FUSED_H: *flops = ((e->dual2 && e->Vhat && e->VT) ? 3.0 : e->dual2 ? 4.0 : e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
+    case TAG_FUSED_H: *flops = (e->dualz ? 3.0 : (e->dual2 && e->Vhat && e->VT) ? 3.0 : e->dual2 ? 4.0 : e->dual ? 3.0 : (mdiv(e) == NMFX_DIV_KL ? 2.0 : 1.0)) * f; *bytes = 4.0 * (m * n + m * KT + 2.0 * e->K * n); return NMFX_OK;
     case TAG_FUSED_COST: *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK;
     default: *flops = 0; *bytes = 0; return NMFX_OK;
     }

@@ -32,8 +32,7 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         V tile; nullptr = zeros) and contracts its own <= 256 components: 7 stores the raw partial S (p.Rout), 8 is the last block and goes on
 //         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes; 10 is the last block of a euclidean chain: the residual
 //         sum (V - S).^2 of the accumulated S (functor 1's terms), nothing stored
-//       9 (cost-only form, W-step form): R = max(D + S, 0) stored to p.Rout -- cnmfsc.m:262, V_hat = max(V_hat + dW_t * rshift_t(H), 0), in place (D = Rout = V_hat)
-//       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc keeps V_hat: its W branch updates it slice by slice)
+//       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc.m:269: the next H step contracts V_hat - V)
 //       11 / 12 (IS) and 13 / 14 (alpha-beta, alpha ~= 0): the two element maps of functors 4 / 5 as TWO single-map passes, for 192 < K <= 256 where a second
 //         accumulator set no longer fits the register file (nmf.m:154-164,185-195 have no K limit).  11: A = V./S.^2 (+ the IS cost terms), 12: B = 1./S,
 //         13: A = V.^alpha .* S.^(beta-1) (+ the alpha-beta cost terms; D holds V.^alpha), 14: B = S.^(alpha+beta-1).  Each is the KL pass with another map:
@@ -44,11 +43,6 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         by-products of the first map, so storing them costs one buffer_store per element -- for a no-first-product pass (functor 0 with D = that buffer) to
 //         contract: 4 + 2 = 6*m*n*K per W step instead of 8.  The stores ride behind the MFMAs of the second product; the LDS-DMA rows of the next tile are
 //         waited for right behind P2, while nothing but loads is in flight (stores and loads do not retire in order relative to each other)
-//       18 (W-step form, second product on, in place: D = Rout = V_hat): cnmfsc's multiplicative W branch, one launch per time slice (cnmfsc.m:257-263).  Launch t applies
-//         slice t-1's correction, R = max(V_hat + dW_{t-1} * rshift_{t-1}(H), 0) (first product: X = dW_{t-1}, the K components of ONE slice), stores R as the new
-//         V_hat and contracts the SAME registers with rshift_t(H): out = R * rshift_t(H)' = the `pos` of slice t.  V_hat is read once and written once per slice
-//         (functor 0 + functor 9 read it twice).  Both shifts come out of one LDS tile of FT_C + 1 columns of H: p.Y = column j - t of the padded copy, the first
-//         product reads LDS row c + 1 (column j - (t-1)), the second LDS row c
 // RAG: p.R / p.Cn need not be multiples of 128 / 64.  Stationary rows past R load zeros, keep their (garbage, row-local) results to
 // themselves and are neither stored nor costed; streamed indices past the end arrive as zero rows (buffer bounds) and their R
 // elements and cost terms are masked to zero, so they add nothing to the second product.  Two extra VALU ops per element.
@@ -65,8 +59,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int KH = K / TT;             // floats per column of H
     constexpr int LDY = KH + 4;            // LDS row stride (one column of H per row)
     constexpr int NKB = K / 32;
-    constexpr int XR = FUNC == 18 ? 1 : 0;    // functor 18: one more column of H (the previous slice's shift)
-    constexpr int TROWS = FT_C + TT - 1 + XR;   // LDS rows per tile
+    constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
     constexpr bool S_IN = FUNC == 7 || FUNC == 8 || FUNC == 10;   // S accumulated over several launches (column blocks of a wide factor)
@@ -77,8 +70,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // tile-top wait below counts on exactly 32 V loads standing behind the DMA rows in the in-order counter -- with fewer, `vmcnt(32)` returns before the rows
     // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
     constexpr bool NO_V = FUNC == 12 || FUNC == 14;
-    constexpr bool STB = FUNC == 15 || FUNC == 16 || FUNC == 18;                     // first map + store of the second map's values (18: of R itself, in place)
-    constexpr bool BQ = FUNC == 15 || FUNC == 16;                                    // ... held in bq[] on their way out (18 stores its R tile straight from sacc)
+    constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
     constexpr int EF = FUNC == 15 ? 11 : (FUNC == 16 ? 13 : FUNC);                   // the element map to run
     static_assert(!STB || (DO_G2 && D_RC && EPI == 0 && TT == 1), "functors 15 / 16: W-step form with the second product");
     // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
@@ -153,7 +145,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     };
     auto y_srd = [&](int t) {
         if (TT > 1) return make_srd(p.Y + (cbeg + (long)t * FT_C - (TT - 1)) * KH, (unsigned)((tile_rows(t) + TT - 1) * KH * 4));
-        return make_srd(Yz + (cbeg + (long)t * FT_C) * ystride, (unsigned)(tile_rows(t) > 0 ? ((tile_rows(t) - 1 + XR) * ystride + K) * 4 : 0));
+        return make_srd(Yz + (cbeg + (long)t * FT_C) * ystride, (unsigned)(tile_rows(t) > 0 ? ((tile_rows(t) - 1) * ystride + K) * 4 : 0));
     };
 
     // V tile of step t: d[jb*16 + reg] = V(r, c = c0 + 32*jb + rowmap(reg, h))
@@ -251,7 +243,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
         f32x16 sacc2[DUAL ? 2 : 1];                           // the second map's tile (B)
-        float bq[BQ ? 2 : 1][BQ ? 16 : 1];                    // the second map's values of this tile, on their way to p.Rout
+        float bq[STB ? 2 : 1][STB ? 16 : 1];                  // the second map's values of this tile, on their way to p.Rout
         const __amdgpu_buffer_rsrc_t rs_b = STB ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000)
                                                 : d_srd_fixed;
         float tc = 0.0f;
@@ -285,7 +277,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             } else if (EF == 11) {                            // IS, numerators only: A = V./S.^2, cost terms q - ln(q) (functor 4 without its B tile)
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) eq[sl] = v * er[sl];
-                if (BQ && u == 2) bq[BQ ? jb : 0][BQ ? reg : 0] = er[sl];           // B = 1./S
+                if (STB && u == 2) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = 1./S
                 if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
                 if (u == 4) er[sl] = __builtin_amdgcn_logf(eq[sl]);                  // log2(q)
                 if (u == 5) tc = live ? tc + eq[sl] : tc;
@@ -299,7 +291,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
                 if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)
                 if (u == 4) { eq[sl] = v * eq[sl]; sacc[jb][reg] = live ? eq[sl] : 0.0f; }
-                if (BQ && u == 5) bq[BQ ? jb : 0][BQ ? reg : 0] = er[sl];           // B = S.^(a+b-1)
+                if (STB && u == 5) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = S.^(a+b-1)
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
             } else if (FUNC == 17) {                          // alpha-beta, dual form (alpha == 0): A = S.^beta ./ V
@@ -310,10 +302,6 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             } else if (FUNC == 14) {                          // alpha-beta, denominators only: B = S.^(a+b-1)
                 if (u == 0) er[sl] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(sacc[jb][reg]), -3.0e38f, 3.0e38f);
                 if (u == 1) sacc[jb][reg] = live ? __builtin_amdgcn_exp2f(ab_e2 * er[sl]) : 0.0f;
-            } else if (FUNC == 9) {                           // V_hat <- max(V_hat + dW*Hs, 0)   (cnmfsc.m:262)
-                if (u == 0) sacc[jb][reg] = fmaxf(v + sacc[jb][reg], 0.0f);
-            } else if (FUNC == 18) {                          // the same, and R goes on into the second product (past the edge: 0, adds nothing)
-                if (u == 0) sacc[jb][reg] = live ? fmaxf(v + sacc[jb][reg], 0.0f) : 0.0f;
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
                 if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
             } else if (MF >= 2) {
@@ -338,7 +326,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
             for (int q = q0; q < q1; ++q) emap_u(jb, q / NU, q % NU);
         };
-        auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31 + XR) * LDY + kofs(8 * g) + 4 * h); };
+        auto g1_read = [&](int jb, int g) { return *reinterpret_cast<const float4 *>(Yt + (32 * jb + l31) * LDY + kofs(8 * g) + 4 * h); };
         if (NEED_S) {
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
@@ -393,9 +381,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     if (jb == 0 && NEED_S) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
                     if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 24 < ROWS_PER_WAVE ? (st + 1) * ROWS_PER_WAVE / 24 : ROWS_PER_WAVE);   // no first product: the DMA rides here, done by step 24
                     if (kb == NKB / 2 && jb == (NEED_S ? 1 : 0)) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4 (no first product: under P3 already)
-                    if (STB && kb == (NKB > 1 ? 1 : 0) && (jb == 1 || reg >= 8)) {   // the B values: half 0's (mapped under P2) two per step in the second half of P3, half 1's (mapped under P3) one per step of P4
+                    if (STB && kb == 1 && (jb == 1 || reg >= 8)) {   // the B values: half 0's (mapped under P2) two per step in the second half of P3, half 1's (mapped under P3) one per step of P4
                         auto put = [&](int j2, int r2) {
-                            const float bv = BQ ? bq[BQ ? j2 : 0][BQ ? r2 : 0] : sacc[j2][r2];
+                            const float bv = bq[STB ? j2 : 0][STB ? r2 : 0];
                             if (row_ok) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bv), rs_b, d_voff, (int)(p.ldd * (32 * j2 + (r2 & 3) + 8 * (r2 >> 2)) * 4), 0);
                         };
                         if (jb == 0) { put(0, 2 * (reg - 8)); put(0, 2 * (reg - 8) + 1); }
@@ -420,7 +408,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
-            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 9 || FUNC == 1) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
 #pragma unroll

@@ -6,7 +6,7 @@ namespace nmfx {
 
 template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, bool RAG>
 static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) {
-    const size_t ldsb = sizeof(float) * 2 * (FT_C + (FUNC == 18 ? 1 : 0)) * (K + 4);
+    const size_t ldsb = sizeof(float) * 2 * FT_C * (K + 4);
     auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, EPI, RAG>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -65,8 +65,6 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 17: if constexpr (EPI == 0 && DO_G2) return launch_one<K, D_RC, 17, DO_G2, EPI, RAG>(st, p, nsplit); break;   // alpha-beta dual form (alpha == 0): numerators; any K
     case 15: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 15, DO_G2, EPI, RAG>(st, p, nsplit); break;   // 11 / 13 + the second map's values to p.Rout
     case 16: if constexpr (K >= 224 && EPI == 0 && DO_G2 && D_RC) return launch_one<K, D_RC, 16, DO_G2, EPI, RAG>(st, p, nsplit); break;
-    case 18: if constexpr (DO_G2 && D_RC && EPI == 0 && K <= 128) return launch_one<K, D_RC, 18, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:257-263, one launch per slice
-    case 9: if constexpr (!DO_G2 && D_RC && K <= 128) return launch_one<K, D_RC, 9, DO_G2, EPI, RAG>(st, p, nsplit); break;   // cnmfsc.m:262 (K = components of one time slice)
     }
     set_error("launch_fused: unsupported functor %d", func);
     return NMFX_ERR_UNSUPPORTED;

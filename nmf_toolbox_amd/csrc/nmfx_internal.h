@@ -275,6 +275,8 @@ nmfx_status fill_f32(hipStream_t st, float *p, long count, float v);
 nmfx_status axpy_f32(hipStream_t st, long count, float a, const float *x, const float *y, float *out);  // out = y + a*x
 nmfx_status mu_plain(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ max(pos, eps))
 nmfx_status mu_plain_diff(hipStream_t st, const float *X0, const float *neg, const float *pos, long count, float *Xnew, float *dX);   // Xnew = X0 .* (neg ./ max(pos, eps)), dX = Xnew - X0
+nmfx_status minmax_dev(hipStream_t st, const float *X_dev, long count, double *out_dev);   // [max, -min] (aux.hip)
+nmfx_status scale_div(hipStream_t st, const float *X_dev, long count, double divide_by, float *out_dev);
 nmfx_status cnmfsc_w_slices(hipStream_t st, const float *W0, const float *Nn, const float *G, long m, int K, int T, float *W);   // cnmfsc.m:257-263 from N = V*H_stack' and G = Hs*Hs' (aux.hip)
 nmfx_status mu_plus_eps(hipStream_t st, float *X, const float *neg, const float *pos, long count);  // X .* (neg ./ (pos + eps))
 nmfx_status transpose_f32(hipStream_t st, const float *in, long rows, long cols, float *out);    // out (cols x rows)

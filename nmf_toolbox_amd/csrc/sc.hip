@@ -645,14 +645,14 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     if (small64h) TRY(g64h.alloc(sizeof(double) * (size_t)p->n * p->K_total));
     // Fused passes (the register-stationary kernels of cnmf) for every evaluation that is a whole-matrix contraction: objectives without a
     // stored V_hat inside the H line search, V_hat + objective in one pass where the algorithm keeps V_hat, all T products V*rshift_t(H)' in one pass,
-    // V_hat*rshift_t(H)' and the in-place update of cnmfsc.m:262 per slice, dH through Q = W_flat'*(V_hat - V) + shift-sum.  Default for problems
+    // the multiplicative W branch from the Gram of the stacked shifts (no V_hat: gramW below), dH through Q = W_flat'*(V_hat - V) + shift-sum.  Default for problems
     // past the float64-gradient sizes; path 2 asks for them by name, path 1 keeps the two-operand GEMMs.
     const bool fusedsc = p->path != 1 && fused_supported_T(K, T) && fused_supported(K) && K <= 128 && m >= 64 && n >= 64 && m % 4 == 0 &&
                          (p->path == 2 || (!small64 && !small64h));
     if (p->path == 2 && !fusedsc) { set_error("cnmfsc: fused passes requested but the problem is not eligible (an instantiated (K, T) pair, m and n >= 64, m a multiple of 4)"); return NMFX_ERR_UNSUPPORTED; }
     DevBuf Hpadb, slabsb, Qb, DDb, Dlb, Zb, qpartsb, Llagb, Ggb;
-    long cpsT = 0, cpsK = 0;
-    int nsplitT = 1, nsplitK = 1;
+    long cpsT = 0;
+    int nsplitT = 1;
     // H line search: objectives from the quadratic expansion (see run_nmfsc): obj(H + D) - obj(H) = <dH, D> + 0.5*<Ds, (W_flat'*W_flat)*Ds>, Ds = D stacked with its
     // shifts -- one KT x n x KT product on the stacked view, a shift-sum and two inner products instead of a 2*m*n*K*T pass per try
     static const bool no_quad_c = getenv("NMFX_SC_NO_QUAD") != nullptr;   // dev switch (A/B runs)
@@ -662,9 +662,8 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     }
     if (fusedsc) {
         nsplitT = fused_split((m + 127) / 128, n, KT, &cpsT);
-        nsplitK = fused_split((m + 127) / 128, n, K, &cpsK);
         TRY(Hpadb.alloc((size_t)K * (n + 2 * (T - 1)) * 4));   // [T-1 zero columns | H | T-1 zero columns (the lag Grams of the W branch)]
-        TRY(slabsb.alloc(std::max((size_t)nsplitT * mKT, (size_t)nsplitK * mK) * 4));
+        TRY(slabsb.alloc((size_t)nsplitT * mKT * 4));
         TRY(Qb.alloc((size_t)KT * n * 4));
     }
     TRY(rrs.alloc(row_reduce_scratch_bytes(K)));
@@ -672,7 +671,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     TRY(V.alloc(mn * 4)); TRY(Vh.alloc(mn * 4)); TRY(W0b.alloc(mKT * 4)); TRY(Wb.alloc(mKT * 4)); TRY(Wnb.alloc(mK * 4));
     TRY(Hb.alloc(Kn * 4)); TRY(Hnb.alloc(Kn * 4)); TRY(HTb.alloc(Kn * 4));
     const size_t gmax = std::max(Kn, mKT);
-    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * std::max<size_t>(gemm_grid_blocks(m, n), (size_t)((m + 127) / 128) * std::max(nsplitT, nsplitK)))); TRY(costd.alloc(64 + sizeof(double) * K));
+    TRY(G1.alloc(gmax * 4)); TRY(G2.alloc(gmax * 4));    TRY(part.alloc(sizeof(double) * std::max<size_t>(gemm_grid_blocks(m, n), (size_t)((m + 127) / 128) * nsplitT))); TRY(costd.alloc(64 + sizeof(double) * K));
     size_t sb = std::max(gemm_scratch_bytes(K, n, (long)T * m), gemm_scratch_bytes(m, K, n));
     if (fusedsc) sb = std::max(sb, std::max(gemm_scratch_bytes(KT, n, m), std::max(gemm_scratch_bytes(KT, KT, m), gemm_scratch_bytes(KT, n, KT))));
     // Multiplicative W branch without V_hat (aux.hip::cnmfsc_w_slices): the slice loop of cnmfsc.m:257-263 from N = V*H_stack' and the Gram of the stacked shifts
@@ -755,18 +754,6 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         g.C = out; g.ldc = K;
         return gemm(g, nullptr);
     };
-    // out (m x K) = X * rshift_t(H)'
-    // (fused) out (m x K) = X * rshift_t(Hx)' on the stationary kernel: streamed row j = column j - t of the padded copy
-    auto xht_fused = [&](const float *X, const float *Hx, int t, float *out) -> nmfx_status {
-        TRY(ensure_hpad(Hx));
-        FusedParams f; memset(&f, 0, sizeof(f));
-        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = X; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
-        f.out = nsplitK == 1 ? out : slabsb.as<float>(); f.slab_stride = (long)mK; f.os_r = 1; f.os_k = m;
-        PScope ps(pf, SC_WTERMS);
-        TRY(launch_fused(st, f, nsplitK, true, 0, true, 0));
-        if (nsplitK > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitK, (long)mK, (long)mK, out, 0));
-        return NMFX_OK;
-    };
     // (fused) out (m x K x T) = V * H_stack': the T products V * rshift_t(Hx)' in ONE pass over V
     auto vht_all_fused = [&](const float *Hx, float *out) -> nmfx_status {
         TRY(ensure_hpad(Hx));
@@ -778,32 +765,8 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         if (nsplitT > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitT, (long)mKT, (long)mKT, out, 0));
         return NMFX_OK;
     };
-    // (fused) V_hat = max(V_hat + dW * rshift_t(Hx), 0) in place   (cnmfsc.m:262)
-    auto vhat_update_fused = [&](const float *dW, const float *Hx, int t) -> nmfx_status {
-        TRY(ensure_hpad(Hx));
-        FusedParams f; memset(&f, 0, sizeof(f));
-        f.X = dW; f.xs_r = 1; f.xs_k = m;
-        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = Vh.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
-        f.Rout = Vh.as<float>();
-        PScope ps(pf, SC_WTERMS);
-        return launch_fused(st, f, nsplitK, true, 9, false, 0);
-    };
-    // (fused) slice t >= 1 of the multiplicative W branch in ONE launch (functor 18): V_hat <- max(V_hat + dWprev * rshift_{t-1}(Hx), 0) -- the correction of slice
-    // t-1, cnmfsc.m:262 -- stored in place, and out (m x K) = V_hat * rshift_t(Hx)' from the same registers (the `pos` of slice t, cnmfsc.m:259): V_hat read once
-    // and written once per slice
-    auto pos_update_fused = [&](const float *dWprev, const float *Hx, int t, float *out) -> nmfx_status {
-        TRY(ensure_hpad(Hx));
-        FusedParams f; memset(&f, 0, sizeof(f));
-        f.X = dWprev; f.xs_r = 1; f.xs_k = m;
-        f.Y = Hpadb.as<float>() + (size_t)K * (T - 1 - t); f.D = Vh.as<float>(); f.Rout = Vh.as<float>(); f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cpsK;
-        f.out = nsplitK == 1 ? out : slabsb.as<float>(); f.slab_stride = (long)mK; f.os_r = 1; f.os_k = m;
-        PScope ps(pf, SC_WTERMS);
-        TRY(launch_fused(st, f, nsplitK, true, 18, true, 0));
-        if (nsplitK > 1) TRY(reduce_slabs(st, slabsb.as<float>(), nsplitK, (long)mK, (long)mK, out, 0));
-        return NMFX_OK;
-    };
+    // out (m x K) = X * rshift_t(H)'  (X2 given: (X2 - X) * rshift_t(H)')
     auto xht = [&](const float *X, const float *Hx, int t, float *out, const float *X2 = nullptr) -> nmfx_status {
-        if (fusedsc && !X2) return xht_fused(X, Hx, t, out);
         PScope ps(pf, SC_WTERMS);
         GemmParams g; memset(&g, 0, sizeof(g));
         g.M = m; g.N = K; g.Kc = n;
@@ -937,17 +900,10 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                     NMFX_HIP(hipMemcpyAsync(Wt, Wnew, mK * 4, hipMemcpyDeviceToDevice, st));         // W(:,:,t) = Wnew
                     begobj = newobj;                                                                 // next t: 0.5*||V - V_hat||^2 of the V_hat left here
                 } else {
-                    const float *negt = fusedsc ? G1.as<float>() + (size_t)t * mK : G1.as<float>();
-                    if (!fusedsc) TRY(xht(V.as<float>(), H, t, G1.as<float>()));                 // neg = V * Hs'
-                    static const bool no_f18 = getenv("NMFX_SC_NO_F18") != nullptr;                  // dev switch (A/B runs): functor 0 + functor 9 per slice, as in round 4
-                    if (fusedsc && t > 0 && !no_f18) TRY(pos_update_fused(Wnew, H, t, G2.as<float>()));   // cnmfsc.m:262 of slice t-1 and pos = V_hat * Hs' of slice t in ONE launch
-                    else
+                    // (reached with the two-operand GEMMs only -- path 1, small problems, (K, T) pairs the fused passes do not serve: gramW took the fused case)
+                    TRY(xht(V.as<float>(), H, t, G1.as<float>()));                               // neg = V * Hs'
                     TRY(xht(Vh.as<float>(), H, t, G2.as<float>()));                              // pos = V_hat * Hs'
-                    TRY(mu_plain_diff(st, W0t, negt, G2.as<float>(), (long)mK, Wt, Wnew));           // W_t = W0_t .* (neg ./ max(pos, eps)), dW = W_t - W0_t   cnmfsc.m:261 (one launch)
-                    // (fused) the correction of slice t is applied by the launch of slice t+1; the LAST slice's is never needed: cnmfsc.m:269 re-forms V_hat from
-                    // (W, H) right after the loop, so the result of cnmfsc.m:262 at t = T is dead in the reference too
-                    if (fusedsc && !no_f18) continue;
-                    if (fusedsc) { TRY(vhat_update_fused(Wnew, H, t)); continue; }                   // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
+                    TRY(mu_plain_diff(st, W0t, G1.as<float>(), G2.as<float>(), (long)mK, Wt, Wnew));     // W_t = W0_t .* (neg ./ max(pos, eps)), dW = W_t - W0_t   cnmfsc.m:261 (one launch)
                     GemmParams g; memset(&g, 0, sizeof(g));                                          // V_hat = max(V_hat + dW * rshift_t(H), 0)   cnmfsc.m:262
                     g.M = m; g.N = n; g.Kc = K;
                     g.A = OpView{Wnew, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};

@@ -159,8 +159,10 @@ def run_sharded_iterations(backend, iters, dist, group=None, cost_out=None, tole
 def agree_on_workspace(flags, size_of, alloc, any_rank, release=lambda: None):
     """Allocate the engine workspace so that EVERY rank ends with the same descriptor flags.  size_of(flags) -> bytes, alloc(bytes) -> buffer (raises an
     out-of-memory error when it does not fit), any_rank(failed) -> True when the allocation failed on at least one rank (a MAX all-reduce; identity without a
-    process group).  First try with the flags as given; if any rank fails, all ranks drop theirs and retry without the transposed copy of V (flags bit 0).  A second
+    process group).  Bit 0 set on ANY rank at entry is set on all of them first.  Then try with those flags; if any rank fails, all ranks drop theirs and retry without the transposed copy of V (flags bit 0).  A second
     failure anywhere, or a first one with bit 0 already set, is NMFX_ERR_NOMEM on all ranks.  Errors other than out-of-memory propagate.  -> (buffer, flags)"""
+    if any_rank(bool(flags & 1)):        # flags that differ at the start (no_vt / NMFX_NO_VT on one rank only) are reconciled first: one rank without the copy -> all without
+        flags |= 1
     for attempt in range(2):
         nbytes = size_of(flags)
         buf, failed = None, False

@@ -11,8 +11,69 @@ if ROOT not in sys.path:
 EPS = 2.0 ** -52
 
 
+_THREAD_LIMIT = []
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    wi = getattr(config, "workerinput", None)
+    if wi is not None:
+        # an xdist worker shares the host with the others: the oracle's BLAS pool gets its share of the cores (128-thread pools of four workers spin against each
+        # other and against the single-threaded element-wise phases: the full-size oracle tests ran 3.5x slower that way, profiles/r5_09_gputests.log)
+        n = max(1, (os.cpu_count() or 4) // max(1, int(wi.get("workercount", 1))))
+        try:
+            from threadpoolctl import threadpool_limits
+            _THREAD_LIMIT.append(threadpool_limits(limits=n))
+        except Exception:
+            pass
+        try:
+            import torch
+            torch.set_num_threads(n)
+        except Exception:
+            pass
+
+
+_FIRST = ("test_gpu_golden.py", "test_gpu_fullsize_oracle.py", "test_gpu_pins.py")
+# the BASELINE-sized oracle comparisons, longest first (seconds on the GPU box's host cores, profiles/r5_10_gputests.log)
+_LONGEST = ("test_c3_full_kl", "test_c3_shard_kl", "test_c3_stop_rule_near_convergence", "test_c5_full_nmfsc", "test_c2_full_euclidean", "test_c4_full_cnmf[kl]",
+            "test_default_100_iterations[kl]", "test_c4_full_cnmf[euclidean]", "test_default_100_iterations[euclidean]")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The golden fixtures, the BASELINE-sized oracle comparisons and the pinned values first: a run that is cut short (-x, a time limit) has then already covered
+    C1-C5.  The long oracle comparisons lead, longest first and each followed by one short golden test: xdist's load scheduler (two consecutive tests per worker to
+    begin with, then one at a time: maxschedchunk = 1) then starts them on different workers at once and fills the gaps with the short tests."""
+    def key(it):
+        name = os.path.basename(str(it.fspath))
+        return _FIRST.index(name) if name in _FIRST else len(_FIRST)
+    items.sort(key=key)          # stable: the order inside a module and among the other modules is unchanged
+    long_ = {it.name: it for it in items if os.path.basename(str(it.fspath)) == "test_gpu_fullsize_oracle.py" and it.name in _LONGEST}
+    if not long_:
+        return
+    rest = [it for it in items if long_.get(it.name) is not it]
+    lead = []
+    for name in _LONGEST:
+        if name in long_:
+            lead.append(long_[name])
+            if rest and os.path.basename(str(rest[0].fspath)) == "test_gpu_golden.py":
+                lead.append(rest.pop(0))
+    items[:] = lead + rest
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`-m gpu` (the GPU box): most of the suite's wall time is the float64 oracle of the full-size tests on the HOST cores while the GPU idles, so the session is
+    spread over pytest-xdist workers (every worker is its own process with its own HIP context on the one GPU; 288 GB of HBM hold several BASELINE-sized problems at
+    once).  NMFX_TEST_WORKERS=<n> overrides (1 = in-process); an explicit -n wins.  Runs before xdist's own hook of the same name (conftest plugins register later)."""
+    if hasattr(config, "workerinput") or not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
+        return
+    nw = os.environ.get("NMFX_TEST_WORKERS")
+    if nw is None and (config.option.markexpr or "").strip() == "gpu":
+        nw = "4"
+    if nw and int(nw) > 1:
+        config.option.numprocesses = int(nw)
+        if getattr(config.option, "maxschedchunk", None) is None:
+            config.option.maxschedchunk = 1        # one test at a time after the first two: the long tests do not queue up behind each other on one worker
 
 
 # ---- worst relative errors per test, written to gpurun_out/parity_errors.json at the end of a -m gpu session -----------------
@@ -38,20 +99,33 @@ def record_err(**vals):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not _ERRORS:
-        return
+    import glob
     import json
     out = os.path.join(ROOT, "gpurun_out")
+    wid = getattr(session.config, "workerinput", {}).get("workerid")
     try:
+        if wid is not None:        # an xdist worker: its share goes to a file of its own, the controller merges (its sessionfinish runs after the workers')
+            if _ERRORS:
+                os.makedirs(out, exist_ok=True)
+                with open(os.path.join(out, ".parity_errors.%s.json" % wid), "w") as f:
+                    json.dump(_ERRORS, f)
+            return
+        tests = dict(_ERRORS)
+        for fn in glob.glob(os.path.join(out, ".parity_errors.*.json")):
+            with open(fn) as f:
+                tests.update(json.load(f))
+            os.remove(fn)
+        if not tests:
+            return
         os.makedirs(out, exist_ok=True)
         worst = {}
-        for t, d in _ERRORS.items():
+        for t, d in tests.items():
             for k, v in d.items():
                 if k not in worst or not (worst[k][0] >= v):
                     worst[k] = (v, t)
         with open(os.path.join(out, "parity_errors.json"), "w") as f:
             json.dump(dict(contract=dict(W=1e-5, H=1e-5, WH=1e-5, cost=1e-6), worst={k: dict(value=v, test=t) for k, (v, t) in worst.items()},
-                           tests=_ERRORS), f, indent=1, sort_keys=True)
+                           tests=tests), f, indent=1, sort_keys=True)
     except OSError:
         pass
 

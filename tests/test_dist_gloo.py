@@ -355,7 +355,7 @@ def _ws_worker(rank, world, port, q):
             return bytearray(8)
 
         try:
-            buf, flags = agree_on_workspace(flags0, lambda f: 600 if f & 1 else 1000, alloc, any_rank, lambda: released.append(1))
+            buf, flags = agree_on_workspace(flags0[rank] if isinstance(flags0, list) else flags0, lambda f: 600 if f & 1 else 1000, alloc, any_rank, lambda: released.append(1))
             return ("ok", flags, asked, len(released), buf is not None)
         except _lib.NmfxError as ex:
             return ("nomem", ex.status, asked, len(released), False)
@@ -366,7 +366,9 @@ def _ws_worker(rank, world, port, q):
            run([2000, 700]),                  # rank 1 is short: BOTH ranks drop the transposed copy and retry
            run([2000, 500]),                  # rank 1 cannot hold it either way: NOMEM on both ranks
            run([2000, 700], flags0=1),        # already without the copy and it fits
-           run([2000, 500], flags0=1)]        # already without the copy: no second attempt, NOMEM on both
+           run([2000, 500], flags0=1),        # already without the copy: no second attempt, NOMEM on both
+           run([2000, 2000], flags0=[0, 1]),  # the flags differ at entry (NMFX_NO_VT on rank 1 only): both run without the copy
+           run([2000, 500], flags0=[1, 0])]   # ... and a failure then is NOMEM on both ranks together (no rank is left waiting in a second all-reduce)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -388,7 +390,9 @@ def test_workspace_retry_is_collective():
         assert p.exitcode == 0
     from nmf_toolbox_amd import _lib
     for rank in (0, 1):
-        fits, short, never, pre, pre_never = res[rank]
+        fits, short, never, pre, pre_never, mixed, mixed_never = res[rank]
+        assert mixed == ("ok", 1, [600], 0, True)
+        assert mixed_never[:2] == ("nomem", _lib.NMFX_ERR_NOMEM) and mixed_never[2] == [600]
         assert fits == ("ok", 0, [1000], 0, True)
         assert short == ("ok", 1, [1000, 600], 1, True)                 # same flags, same two attempts on the rank that had room as on the one that had not
         assert never[:2] == ("nomem", _lib.NMFX_ERR_NOMEM) and never[2] == [1000, 600]

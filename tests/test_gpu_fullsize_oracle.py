@@ -57,22 +57,20 @@ def test_c3_shard_kl(gpu_lib):
 
 def test_c3_full_kl(gpu_lib):
     """BASELINE config 3 in full on one GPU: nmf KL, V = 16384 x 65536, K = 256 -- the bench workload.  The float64 oracle
-    needs ~100 GB of host memory for its m x n temporaries (the GPU box has 3 TB); 2 iterations."""
+    needs ~100 GB of host memory for its m x n temporaries (the GPU box has 3 TB).  ONE iteration (both half-steps and the two costs; round 4 ran two: the second
+    was the suite's longest single item, and state chained over iterations at these kernels is what test_c3_shard_kl covers)."""
     from oracle import nmf_oracle as O
     m, n, K = 16384, 65536, 256
     V, W0, H0 = synth(m, n, K)
-    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=1, tolerance=1e-300)
     got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
     _report("C3 16384x65536 K=256 kl", got, ref, tg, tc, wh=False)
-    # the advisor's point about the ABSOLUTE stop rule (nmf.m:221, default tolerance 1e-3): at this size the fp32 path's cost differs from
-    # float64 by a few units (1e8 * 5e-8), almost all of it a bias common to consecutive iterations; what the stop rule sees is the error of
-    # the DIFFERENCE cost(i-1) - cost(i), recorded here.  It is far above 1e-3 -- and far below the decreases of ~1e5 per iteration that
-    # this problem still makes at iteration 2, so the rule's decision is the reference's (DESIGN.md 4.1, "Cost precision and the stop rule")
+    # the ABSOLUTE stop rule (nmf.m:221, default tolerance 1e-3): at this size the fp32 path's cost differs from float64 by a few units (1e8 * 5e-8), almost all of
+    # it a bias common to consecutive iterations; what the rule sees is the error of the DIFFERENCE cost(i-1) - cost(i): test_c3_stop_rule_near_convergence measures
+    # that band at this size, where the decreases have become small (DESIGN.md 4.1, "Cost precision and the stop rule")
     abs_err = np.abs(got[2] - ref[2])
-    diff_err = abs((got[2][0] - got[2][1]) - (ref[2][0] - ref[2][1]))
-    record_err(cost_abs=float(abs_err.max()), cost_diff_abs=float(diff_err))
-    print("[C3 full] |cost - cost_f64| = %s, error of the decrease cost(1)-cost(2): %.3g (decrease %.4g)" % (abs_err, diff_err, ref[2][0] - ref[2][1]))
-    assert diff_err < 1e-3 * (ref[2][0] - ref[2][1])
+    record_err(cost_abs=float(abs_err.max()))
+    print("[C3 full] |cost - cost_f64| = %s" % (abs_err,))
     # W*H on a 2048-column sample (the full product would be another 8 GiB pair)
     j = np.arange(0, n, 32)
     e = rel_fro(got[0] @ got[1][:, j], ref[0] @ ref[1][:, j])
@@ -92,20 +90,6 @@ def test_c4_full_cnmf(gpu_lib, div):
     _report("C4 4096x16384 K=64 T=8 " + div, got, ref, tg, tc)
 
 
-def test_c5_nmfsc(gpu_lib):
-    """BASELINE config 5 geometry at a quarter of the columns: nmfsc, V = 8192 x 8192, K = 128, H_sparsity 0.5; 3 outer iterations
-    (the first line search alone takes ~10 objective evaluations) with IDENTICAL try counts."""
-    from oracle import nmf_oracle as O
-    m, n, K = 8192, 8192, 128
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=3, tolerance=1e-300)
-    i0, i1 = {}, {}
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
-    print("\n[C5] line-search tries H: HIP %s oracle %s" % (i1["triesH"], i0["triesH"]))
-    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
-    _report("C5 8192x8192 K=128 nmfsc sH=0.5", got, ref, tg, tc)
-
-
 def test_c5_full_nmfsc(gpu_lib):
     """BASELINE config 5 IN FULL: nmfsc.m (nmfsc.m:141-245), V = 8192 x 32768, K = 128, H_sparsity 0.5, 3 outer iterations against the float64 oracle on the
     host cores: identical line-search try counts (H and W), W / H / W*H within 1e-5, the cost vector within 1e-6."""
@@ -123,15 +107,16 @@ def test_c5_full_nmfsc(gpu_lib):
 
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
 def test_default_100_iterations(gpu_lib, div):
-    """The reference's defaults (nmf.m:404-411): maxiter = 100, tolerance = 1e-3, stop rule active, at 2048 x 8192, K = 128.
+    """The reference's defaults (nmf.m:404-411): maxiter = 100, tolerance = 1e-3, stop rule active, at 1024 x 4096, K = 128 (a quarter of round 4's 2048 x 8192: the
+    float64 oracle's 100 iterations were 80 s of the suite).
     The cost vectors must have the same length (the rule does not fire before 100 on this data in either implementation)."""
     from oracle import nmf_oracle as O
-    m, n, K = 2048, 8192, 128
+    m, n, K = 1024, 4096, 128
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence=div, W_init=W0, H_init=H0)          # no maxiter / tolerance: the defaults
     got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
     assert len(ref[2]) == 100
-    _report("100 iterations 2048x8192 K=128 " + div, got, ref, tg, tc)
+    _report("100 iterations 1024x4096 K=128 " + div, got, ref, tg, tc)
     d = -np.diff(ref[2])
     print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], ref[2][-1]))
 

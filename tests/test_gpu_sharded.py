@@ -880,13 +880,15 @@ def test_engine_without_the_transposed_copy_of_V(gpu_lib, div, K):
     assert rel_fro(out[1][0], out[0][0]) < 2e-6 and rel_fro(out[1][1], out[0][1]) < 2e-6 and rel_fro(out[1][2], out[0][2]) < 1e-7
 
 
-def _background_load(stop_after_s):
-    """a second process keeping the GPU busy with its own factorisations (different kernels, different timing) for a while"""
+def _background_load(stop_after_s, started=None, stop=None):
+    """a second process keeping the GPU busy with its own factorisations (different kernels, different timing) until told to stop (or for stop_after_s at most)"""
     import time
     import nmf_toolbox_amd as A
     V, W0, H0 = synth(512, 2048, 96)
     t0 = time.time()
-    while time.time() - t0 < stop_after_s:
+    while time.time() - t0 < stop_after_s and not (stop is not None and stop.is_set()):
+        if started is not None:
+            started.set()
         A.nmf(V, 96, dict(divergence="kl", W_init=W0, H_init=H0, maxiter=20, tolerance=1e-300))
         A.nmf(V, 96, dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=20, tolerance=1e-300))
 
@@ -898,9 +900,11 @@ def test_run_to_run_determinism_under_concurrent_load(gpu_lib):
     landed: right most of the time when nothing else ran)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    bg = ctx.Process(target=_background_load, args=(45.0,))
+    started, stop = ctx.Event(), ctx.Event()
+    bg = ctx.Process(target=_background_load, args=(120.0, started, stop))
     bg.start()
     try:
+        assert started.wait(timeout=300)                     # the load is on the GPU (its process has imported the library and entered the loop)
         m, n = 384, 1280
         cases = [("nmf", "kl", 256, 1), ("nmf", "euclidean", 128, 1), ("nmf", "is", 96, 1), ("nmf", "is", 256, 1), ("cnmf", "kl", 64, 4)]
         for alg, div, K, T in cases:
@@ -912,6 +916,7 @@ def test_run_to_run_determinism_under_concurrent_load(gpu_lib):
                 again = run()
                 assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1]) and np.array_equal(again[2], first[2]), (alg, div, K, rep)
     finally:
+        stop.set()
         bg.join(timeout=120)
         if bg.is_alive():
             bg.terminate()
