@@ -62,14 +62,12 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """`-m gpu` (the GPU box): most of the suite's wall time is the float64 oracle of the full-size tests on the HOST cores while the GPU idles, so the session is
-    spread over pytest-xdist workers (every worker is its own process with its own HIP context on the one GPU; 288 GB of HBM hold several BASELINE-sized problems at
-    once).  NMFX_TEST_WORKERS=<n> overrides (1 = in-process); an explicit -n wins.  Runs before xdist's own hook of the same name (conftest plugins register later)."""
+    """NMFX_TEST_WORKERS=<n> spreads a session over pytest-xdist workers (every worker its own process and HIP context on the one GPU).  Opt-in only: with the
+    full-size oracle comparisons served from fixtures (tests/golden/fullsize_*.npz) the suite is GPU-bound, and four workers sharing the host made the float64
+    oracle tests slower than they were in sequence (profiles/r5_13_gputests_xdist4.log: 730 s against 663 s).  Runs before xdist's own hook of the same name."""
     if hasattr(config, "workerinput") or not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
         return
     nw = os.environ.get("NMFX_TEST_WORKERS")
-    if nw is None and (config.option.markexpr or "").strip() == "gpu":
-        nw = "4"
     if nw and int(nw) > 1:
         config.option.numprocesses = int(nw)
         if getattr(config.option, "maxschedchunk", None) is None:
@@ -145,6 +143,42 @@ def synth(m, n, K, T=None, seed_v=1000, planted=False):
     W0 = np.fmax(rs(1).rand(m, K) if T is None else rs(1).rand(m, K, T), EPS)
     H0 = np.fmax(rs(2).rand(K, n), EPS)
     return V, W0, H0
+
+
+SKETCH_R, SKETCH_SEED = 64, 20261001
+
+
+def fullsize_sketch(W, H):
+    """What tests/golden/make_fullsize_golden.py keeps of a full-size factorisation and what the tests form of the HIP path's result (the same function on both
+    sides): norms, Gaussian sketches Om_W*W, H*Om_H, Om_W*V_hat*Om_H (Om from RandomState(SKETCH_SEED), r = SKETCH_R) and exact strided rows of W / columns of H."""
+    W = np.asarray(W, dtype=np.float64)
+    H = np.asarray(H, dtype=np.float64)
+    m, n, K = W.shape[0], H.shape[1], H.shape[0]
+    rs = np.random.RandomState(SKETCH_SEED)
+    OmW, OmH = rs.standard_normal((SKETCH_R, m)), rs.standard_normal((n, SKETCH_R))
+    Wf = W.reshape(m, -1, order="F")                       # (m, K) or (m, K*T) with slice t in columns t*K .. t*K+K-1
+    SW, SH = OmW @ Wf, H @ OmH
+    if W.ndim == 2:
+        SWH = SW @ SH
+    else:                                                  # V_hat = sum_t W_t * rshift_t(H)  (RFD.m:36-38):  Om_W*V_hat*Om_H = sum_t (Om_W*W_t) * (rshift_t(H)*Om_H)
+        SWH = np.zeros((SKETCH_R, SKETCH_R))
+        for t in range(W.shape[2]):
+            SWH += SW[:, t * K:(t + 1) * K] @ (H[:, :n - t] @ OmH[t:, :])
+    rows, cols = np.arange(0, m, max(1, m // 64)), np.arange(0, n, max(1, n // 64))
+    return dict(W_fro=np.linalg.norm(Wf), H_fro=np.linalg.norm(H), SW=SW, SH=SH, SWH=SWH, W_rows=Wf[rows], H_cols=H[:, cols], rows=rows, cols=cols)
+
+
+def fullsize_errors(got, name):
+    """relative errors of the HIP path's (W, H, cost) against the oracle fixture tests/golden/fullsize_<name>.npz -> dict(W, H, WH, cost, W_rows, H_cols) + the fixture"""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_" + name + ".npz"))
+    W, H, c = got
+    sk = fullsize_sketch(W, H)
+    nrm = np.linalg.norm
+    e = dict(W=nrm(sk["SW"] - fx["SW"]) / nrm(fx["SW"]), H=nrm(sk["SH"] - fx["SH"]) / nrm(fx["SH"]), WH=nrm(sk["SWH"] - fx["SWH"]) / nrm(fx["SWH"]),
+             W_rows=nrm(sk["W_rows"] - fx["W_rows"]) / nrm(fx["W_rows"]), H_cols=nrm(sk["H_cols"] - fx["H_cols"]) / nrm(fx["H_cols"]),
+             W_fro=abs(sk["W_fro"] - fx["W_fro"]) / fx["W_fro"], H_fro=abs(sk["H_fro"] - fx["H_fro"]) / fx["H_fro"],
+             cost=(rel_fro(c, fx["cost"]) if len(c) == len(fx["cost"]) else float("inf")))
+    return {k: float(v) for k, v in e.items()}, fx
 
 
 @pytest.fixture(scope="session")

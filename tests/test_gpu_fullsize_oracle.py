@@ -1,16 +1,21 @@
 """-m gpu: the HIP path against the float64 oracle AT BASELINE.json's geometry and at the reference's default iteration count.
-The oracle runs on the GPU box's host cores (minutes in total); every test prints and records its worst relative errors
-(gpurun_out/parity_errors.json).  Contract: <= 1e-5 relative Frobenius on W, H and W*H, cost <= 1e-6 relative, identical
-cost-vector length / line-search try counts.  Inputs are SURVEY 8(d)'s synthetic V, W_init, H_init (conftest.synth)."""
+The oracle's side comes from tests/golden/fullsize_*.npz -- its results at these sizes, kept as cost vectors, try counts, norms, Gaussian sketches and exact
+strided rows / columns (tests/golden/make_fullsize_golden.py: run once on a box with the memory; the largest case needs ~100 GB of host RAM, and the live runs
+were 60 % of the suite's wall time).  NMFX_LIVE_ORACLE=1 runs the oracle on the host cores as well and compares the complete matrices, as rounds 2-4 did.
+Every test prints and records its worst relative errors (gpurun_out/parity_errors.json).  Contract: <= 1e-5 relative Frobenius on W, H and W*H (sketch estimates
+AND the exact strided rows / columns), cost <= 1e-6 relative, identical cost-vector length / line-search try counts.  Inputs are SURVEY 8(d)'s synthetic V,
+W_init, H_init (conftest.synth)."""
+import os
 import time
 
 import numpy as np
 import pytest
 
-from conftest import record_err, rel_fro, synth
+from conftest import fullsize_errors, record_err, rel_fro, synth
 
 pytestmark = pytest.mark.gpu
 TOL, CTOL = 1e-5, 1e-6
+LIVE = bool(os.environ.get("NMFX_LIVE_ORACLE"))
 
 
 def _report(name, got, ref, t_gpu, t_cpu, wh=True):
@@ -24,15 +29,25 @@ def _report(name, got, ref, t_gpu, t_cpu, wh=True):
             from oracle import nmf_oracle as O
             e["WH"] = rel_fro(O.reconstruct_from_decomposition(W, H), O.reconstruct_from_decomposition(Wr, Hr))
     record_err(**e)
-    print("\n[%s] rel errors vs float64 oracle: %s   (HIP incl. transfers %.1f s, oracle %.1f s, %d iterations)"
+    print("\n[%s] rel errors vs float64 oracle (live): %s   (HIP incl. transfers %.1f s, oracle %.1f s, %d iterations)"
           % (name, "  ".join("%s %.2e" % kv for kv in sorted(e.items())), t_gpu, t_cpu, len(cr)))
     assert e["W"] <= TOL and e["H"] <= TOL and e.get("WH", 0.0) <= TOL and e["cost"] <= CTOL, e
     return e
 
 
-def _both(fn_gpu, fn_ref):
-    t0 = time.time(); got = fn_gpu(); t1 = time.time(); ref = fn_ref(); t2 = time.time()
-    return got, ref, t1 - t0, t2 - t1
+def _check(name, case, fn_gpu, fn_ref, wh=True):
+    """run the HIP path, compare with the oracle fixture `case` (and with the live oracle when asked to) -> (got, fixture)"""
+    t0 = time.time(); got = fn_gpu(); tg = time.time() - t0
+    e, fx = fullsize_errors(got, case)
+    assert len(got[2]) == len(fx["cost"]), (len(got[2]), len(fx["cost"]))
+    record_err(W=max(e["W"], e["W_rows"]), H=max(e["H"], e["H_cols"]), WH=e["WH"], cost=e["cost"])
+    print("\n[%s] rel errors vs float64 oracle (fixture fullsize_%s.npz): %s   (HIP incl. transfers %.1f s, %d cost entries)"
+          % (name, case, "  ".join("%s %.2e" % kv for kv in sorted(e.items())), tg, len(fx["cost"])))
+    assert max(e["W"], e["W_rows"], e["H"], e["H_cols"], e["WH"]) <= TOL and e["cost"] <= CTOL and max(e["W_fro"], e["H_fro"]) <= TOL, e
+    if LIVE:
+        t0 = time.time(); ref = fn_ref(); tc = time.time() - t0
+        _report(name, got, ref, tg, tc, wh=wh)
+    return got, fx
 
 
 def test_c2_full_euclidean(gpu_lib):
@@ -41,8 +56,7 @@ def test_c2_full_euclidean(gpu_lib):
     m, n, K = 8192, 32768, 128
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
-    _report("C2 8192x32768 K=128 euclidean", got, ref, tg, tc)
+    _check("C2 8192x32768 K=128 euclidean", "c2_full", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
 
 
 def test_c3_shard_kl(gpu_lib):
@@ -51,8 +65,7 @@ def test_c3_shard_kl(gpu_lib):
     m, n, K = 16384, 8192, 256
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
-    _report("C3 shard 16384x8192 K=256 kl", got, ref, tg, tc)
+    _check("C3 shard 16384x8192 K=256 kl", "c3_shard", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
 
 
 def test_c3_full_kl(gpu_lib):
@@ -63,20 +76,13 @@ def test_c3_full_kl(gpu_lib):
     m, n, K = 16384, 65536, 256
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=1, tolerance=1e-300)
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
-    _report("C3 16384x65536 K=256 kl", got, ref, tg, tc, wh=False)
+    got, fx = _check("C3 16384x65536 K=256 kl", "c3_full", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg), wh=False)
     # the ABSOLUTE stop rule (nmf.m:221, default tolerance 1e-3): at this size the fp32 path's cost differs from float64 by a few units (1e8 * 5e-8), almost all of
     # it a bias common to consecutive iterations; what the rule sees is the error of the DIFFERENCE cost(i-1) - cost(i): test_c3_stop_rule_near_convergence measures
     # that band at this size, where the decreases have become small ("Cost precision and the stop rule")
-    abs_err = np.abs(got[2] - ref[2])
+    abs_err = np.abs(got[2] - fx["cost"])
     record_err(cost_abs=float(abs_err.max()))
     print("[C3 full] |cost - cost_f64| = %s" % (abs_err,))
-    # W*H on a 2048-column sample (the full product would be another 8 GiB pair)
-    j = np.arange(0, n, 32)
-    e = rel_fro(got[0] @ got[1][:, j], ref[0] @ ref[1][:, j])
-    record_err(WH=e)
-    print("[C3 full] W*H on every 32nd column: %.2e" % e)
-    assert e <= TOL
 
 
 @pytest.mark.parametrize("div", ["euclidean", "kl"])
@@ -86,23 +92,22 @@ def test_c4_full_cnmf(gpu_lib, div):
     m, n, K, T = 4096, 16384, 64, 8
     V, W0, H0 = synth(m, n, K, T=T)
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
-    got, ref, tg, tc = _both(lambda: gpu_lib.cnmf(V, K, T, cfg), lambda: O.cnmf(V, K, T, cfg))
-    _report("C4 4096x16384 K=64 T=8 " + div, got, ref, tg, tc)
+    _check("C4 4096x16384 K=64 T=8 " + div, "c4_full_" + div, lambda: gpu_lib.cnmf(V, K, T, cfg), lambda: O.cnmf(V, K, T, cfg))
 
 
 def test_c5_full_nmfsc(gpu_lib):
-    """BASELINE config 5 IN FULL: nmfsc.m (nmfsc.m:141-245), V = 8192 x 32768, K = 128, H_sparsity 0.5, 3 outer iterations against the float64 oracle on the
-    host cores: identical line-search try counts (H and W), W / H / W*H within 1e-5, the cost vector within 1e-6."""
+    """BASELINE config 5 IN FULL: nmfsc.m (nmfsc.m:141-245), V = 8192 x 32768, K = 128, H_sparsity 0.5, 3 outer iterations against the float64 oracle: identical line-search try counts (H and W), W / H / W*H within 1e-5, the cost vector within 1e-6."""
     from oracle import nmf_oracle as O
     m, n, K = 8192, 32768, 128
     V, W0, H0 = synth(m, n, K)
     cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=3, tolerance=1e-300)
     i0, i1 = {}, {}
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
-    print("\n[C5 full] line-search tries H: HIP %s oracle %s; W: HIP %s oracle %s" % (i1["triesH"], i0["triesH"], i1["triesW"], i0["triesW"]))
-    assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
+    got, fx = _check("C5 8192x32768 K=128 nmfsc sH=0.5 (full size)", "c5_full", lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
+    print("[C5 full] line-search tries H: HIP %s oracle %s; W: HIP %s oracle %s" % (i1["triesH"], fx["triesH"].tolist(), i1["triesW"], fx["triesW"].tolist()))
+    assert list(i1["triesH"]) == fx["triesH"].tolist() and list(i1["triesW"]) == fx["triesW"].tolist()
+    if LIVE:
+        assert i1["triesH"] == i0["triesH"] and i1["triesW"] == i0["triesW"]
     assert len(got[2]) == 4                                   # nmfsc.m:137-139,238: the initial objective + one entry per outer iteration
-    _report("C5 8192x32768 K=128 nmfsc sH=0.5 (full size)", got, ref, tg, tc)
 
 
 @pytest.mark.parametrize("div", ["kl", "euclidean"])
@@ -114,11 +119,10 @@ def test_default_100_iterations(gpu_lib, div):
     m, n, K = 1024, 4096, 128
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence=div, W_init=W0, H_init=H0)          # no maxiter / tolerance: the defaults
-    got, ref, tg, tc = _both(lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
-    assert len(ref[2]) == 100
-    _report("100 iterations 1024x4096 K=128 " + div, got, ref, tg, tc)
-    d = -np.diff(ref[2])
-    print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], ref[2][-1]))
+    got, fx = _check("100 iterations 1024x4096 K=128 " + div, "default100_" + div, lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
+    assert len(fx["cost"]) == 100 and len(got[2]) == 100
+    d = -np.diff(fx["cost"])
+    print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], fx["cost"][-1]))
 
 
 def _kl_cost_f64(V, W, H, chunk=4096):
