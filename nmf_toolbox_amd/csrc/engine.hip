@@ -4,7 +4,7 @@
 
 namespace nmfx {
 
-inline bool dual2_store() { static const bool on = getenv("NMFX_DUAL2_NO_STORE") == nullptr; return on; }   // dev switch (A/B runs): IS / alpha-beta above K = 192, W step as 4 + 2 instead of 4 + 4 m*n*K
+inline bool dual2_store() { return true; }   // IS / alpha-beta above K = 192: the W step as 4 + 2 instead of 4 + 4 m*n*K (the second map's values kept in the m x n scratch)
 static thread_local char g_err[1024] = "";
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -109,7 +109,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->H64 = e->algo == 3 ? nullptr : f.take<double>(Kn);
         e->GW = euc ? f.take<float>((size_t)e->K * e->K) : nullptr;
         size_t g1 = gemm_scratch_bytes(e->K, e->K, e->n), g2 = gemm_scratch_bytes(e->K, e->K, e->m), g3 = gemm_scratch_bytes(e->K, e->n, e->m);
-        e->gemm_scratch_bytes = euc ? std::max(std::max(std::max(g1, g2), g3), std::max(gram_rc_scratch_bytes(e->K, e->K, e->n), gram_rc_scratch_bytes(e->K, e->K, e->m))) : 0;
+        e->gemm_scratch_bytes = euc ? std::max(std::max(std::max(g1, g2), g3), sizeof(float) * (size_t)e->K * e->K * 128)   /* gram_fused: up to 128 column slabs of K x K */ : 0;
         e->gemm_scratch = e->gemm_scratch_bytes ? f.take<float>(e->gemm_scratch_bytes / sizeof(float)) : nullptr;
         e->lamW = f.take<float>(e->K); e->lamH = f.take<float>(e->K);
         e->fixW = f.take<uint8_t>(e->K); e->fixH = f.take<uint8_t>(e->K);
@@ -249,11 +249,10 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // fused path eligibility: nmf rules, KL or euclidean, K a multiple of 32 up to 256, tileable shard
     // IS and alpha-beta (alpha ~= 0: the dual form has other equations) need two element maps per pass: with two accumulator sets in ONE pass up to K = 192
     // (registers), as two single-map passes above it (dual2, round 4)
-    static const bool no_dual2 = getenv("NMFX_NO_DUAL2") != nullptr;   // dev switch (A/B runs against the materialised path)
-    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && (e->K <= 192 || (e->K <= 256 && !no_dual2));
+    e->dual = (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K <= 256;
     e->dual2 = e->dual && e->K > 192;
     // alpha == 0: the dual update equations (nmf.m:124-128).  Two passes per half-iteration at any K: numerators through S (functor 17), denominators without it
-    e->dualz = e->div == NMFX_DIV_AB && e->alpha == 0 && e->K <= 256 && !no_dual2 && e->algo != 3;
+    e->dualz = e->div == NMFX_DIV_AB && e->alpha == 0 && e->K <= 256 && e->algo != 3;
     if (e->dualz) e->dual = e->dual2 = true;
     const bool eligible = (e->algo == 0 || e->algo == 2 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_KL || e->div == NMFX_DIV_EUCLIDEAN || e->dual) && fused_supported(e->K) &&
                           e->hL == 0 && e->hR == 0 && ((e->m >= 64 && e->n >= 64) || d->path == 2);   // ragged m / n: masked-edge kernels
@@ -274,23 +273,20 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
-    static const bool no_fusedT = getenv("NMFX_CNMF_NO_FUSED") != nullptr;   // dev switch: Gram form on the generic GEMM only (A/B runs)
-    e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1) && !no_fusedT;
+    e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1);
     // (column shards: the T-1 columns left of the shard are its halo -- or zeros on the first one --, and R = V./V_hat is also formed on the T-1 right-halo
     // columns, whose terms the shift-sum of the H step needs: cnmf.m:219)
     e->fusedT_kl = !e->fused && e->algo == 1 && e->div == NMFX_DIV_KL && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 &&
-                   (e->hL == 0 || e->hL >= e->T - 1) && d->path != 1 && !no_fusedT;
+                   (e->hL == 0 || e->hL >= e->T - 1) && d->path != 1;
     if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl) {
         set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or kl, T > 1, an instantiated (K, T) pair)");
         return NMFX_ERR_UNSUPPORTED;
     }
     if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
-    static const bool no_klw = getenv("NMFX_KL_WIDE_OFF") != nullptr;   // dev switch (A/B runs): K > 256 on the materialised path
     e->klw = !e->fused && e->algo != 1 && e->T == 1 && e->div == NMFX_DIV_KL && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
-             e->m >= 64 && e->n >= 64 && d->path != 1 && !no_klw;
-    static const bool no_eucw = getenv("NMFX_EUC_WIDE_OFF") != nullptr;   // dev switch (A/B runs): K > 256 in Gram form on the two-operand GEMM
+             e->m >= 64 && e->n >= 64 && d->path != 1;
     e->eucw = e->gram && (e->algo == 0 || e->algo == 3) && e->T == 1 && e->div == NMFX_DIV_EUCLIDEAN && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
-              e->m >= 64 && e->n >= 64 && !no_vt && room_vt && !no_eucw;
+              e->m >= 64 && e->n >= 64 && !no_vt && room_vt;
     if (e->eucw && !exact_cost_env) e->gram_cost = true;
     if (e->klw || e->eucw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
         const int units = e->K / 32;
@@ -304,16 +300,13 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
         e->klw_vt = e->klw && !no_vt && room_vt;
         e->klw_hsplit = fused_split((e->n + 127) / 128, e->m, 256, &e->klw_hcps);
     }
-    static const bool no_lagram = getenv("NMFX_CNMF_NO_LAGRAM") != nullptr;   // dev switch (A/B runs): T x T block Gram products
-    e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T && !no_lagram;
+    e->lagram = e->fusedT && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->n >= 2L * e->T;
     // cnmf on the fused passes, unsharded: the same Gram-form cost (its explicit residual pass is a third of the iteration)
     if (e->fusedT && e->div == NMFX_DIV_EUCLIDEAN && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && !exact_cost_env) e->gram_cost = true;
-    static const bool no_qgemm = getenv("NMFX_CNMF_NO_QGEMM") != nullptr;   // dev switch (A/B runs)
-    e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1 && !no_qgemm;
+    e->qgemm = !e->fused && e->algo == 1 && e->T > 1 && e->K % 4 == 0 && e->m % 4 == 0 && d->path != 1;
     {   // euclidean cnmf on the fused passes, unsharded: the Q product of the H step on a transposed copy of V (see nmfx_engine_hstep)
         static const bool no_vt = getenv("NMFX_NO_VT") != nullptr;
-        static const int vtq_env = getenv("NMFX_VTQ_BLOCK") ? atoi(getenv("NMFX_VTQ_BLOCK")) : 0;   // dev switch: 128 | 256
-        e->vtq_block = vtq_env ? vtq_env : 128;   // C4 (K*T = 512): four 128-wide blocks, two workgroups per CU, 0.526 ms; two 256-wide blocks 0.549; the two-operand GEMM 0.585
+        e->vtq_block = 128;   // C4 (K*T = 512): four 128-wide blocks, two workgroups per CU, 0.526 ms; two 256-wide blocks 0.549; the two-operand GEMM 0.585
         e->use_vtq = e->fusedT && e->qgemm && e->hL == 0 && e->hR == 0 && !no_vt && room_vt && e->KT % e->vtq_block == 0 && fused_supported(e->vtq_block);
     }
     e->nsplit_w = e->isplit_h = 1;
@@ -326,12 +319,11 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
 
 // X*X' (K x K) for X = K x len with contiguous columns, on the W-step form of the stationary kernel: D = X plays V (K "rows"), the columns of X
 // are streamed through LDS by DMA exactly like the columns of H in the W step -- out(k, r) = sum_c X(r, c) X(k, c)
-inline int gram_mode() { static const int m = getenv("NMFX_GRAM") ? atoi(getenv("NMFX_GRAM")) : 2; return m; }   // dev switch: 0 general GEMM, 1 gram_rc, 2 stationary kernel
 nmfx_status gram_fused(nmfx_engine *e, const float *X, long len, float *G) {
     const int K = e->K;
     const long blocks = (K + 127) / 128, tiles = (len + 63) / 64;
     long s = 1;
-    static const long gs_cap = getenv("NMFX_GRAM_WGS") ? atol(getenv("NMFX_GRAM_WGS")) : 256;   // dev switch
+    const long gs_cap = 256;
     while (blocks * s * 2 <= gs_cap && s * 4 <= tiles) s *= 2;          // one workgroup per CU, at least two tiles each
     const long per = (tiles + s - 1) / s;
     const int split = (int)((tiles + per - 1) / per);
@@ -344,7 +336,6 @@ nmfx_status gram_fused(nmfx_engine *e, const float *X, long len, float *G) {
     if (split > 1) TRY(reduce_slabs(e->st, e->gemm_scratch, split, g.slab_stride, g.slab_stride, G, 0));
     return NMFX_OK;
 }
-inline bool small_mm_on() { static const bool off = getenv("NMFX_NO_SMALLMM") != nullptr; return !off; }   // dev switch (A/B runs): the K x K products on the general GEMM
 inline int norm_mode(const nmfx_engine *e) { return e->algo == 3 ? 0 : e->algo; }   // w_normalize: 0 L2 columns, 1 cnmf slabs, 2 L1 (lnmf)
 inline int mdiv(const nmfx_engine *e) { return e->div == NMFX_DIV_EUCLIDEAN_NOCOST ? NMFX_DIV_EUCLIDEAN : e->div; }
 
@@ -1070,11 +1061,7 @@ static nmfx_status fused_wstep_tail(nmfx_engine *e) {
         // rowsum(H) was formed by fused_wpass_finish, whose cost finisher has also written it into the tail of `packed` (tail_with_cost)
     } else {   // Gram form: V_hat*H' = W*(H*H'); the K x K Gram is what gets all-reduced   
         Scope s(e, TAG_GRAM);
-        if (small_mm_on() && gram_mode() == 2) TRY(gram_fused(e, e->H, e->n, e->packed + mKT));
-        else if (small_mm_on() && gram_mode() == 1) TRY(gram_rc(e->st, e->H, e->K, e->K, e->H, e->K, e->K, e->n, e->packed + mKT, e->gemm_scratch, e->gemm_scratch_bytes));
-        else
-        TRY(small_gemm(e, e->K, e->K, e->n, OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                       OpView{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->packed + mKT, e->K));
+        TRY(gram_fused(e, e->H, e->n, e->packed + mKT));
     }
     return NMFX_OK;
 }
@@ -1270,14 +1257,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         if (e->all_fixH) return NMFX_OK;
         // euclidean: W'*V_hat = (W'*W)*H.  W'*W from the transposed copy of W (rows of W contiguous: every MFMA operand one coalesced load);
         // the product with H is folded into the H update (small_mm.hip), except for constrainednmf, whose update sums over label segments first
-        const bool hug = e->div == NMFX_DIV_EUCLIDEAN && e->algo != 3 && small_mm_on() && h_update_gram_supported(e->K);
+        const bool hug = e->div == NMFX_DIV_EUCLIDEAN && e->algo != 3 && h_update_gram_supported(e->K);
         if (e->div == NMFX_DIV_EUCLIDEAN) {
             Scope s(e, TAG_GRAM);
-            if (small_mm_on() && gram_mode() == 2) TRY(gram_fused(e, e->WT, e->m, e->GW));
-            else if (small_mm_on() && gram_mode() == 1) TRY(gram_rc(e->st, e->WT, e->K, e->K, e->WT, e->K, e->K, e->m, e->GW, e->gemm_scratch, e->gemm_scratch_bytes));
-            else
-            TRY(small_gemm(e, e->K, e->K, e->m, OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                           OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->GW, e->K));
+            TRY(gram_fused(e, e->WT, e->m, e->GW));
             if (!hug)
             TRY(small_gemm(e, e->K, e->n, e->K, OpView{e->GW, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
                            OpView{e->H, nullptr, (long)e->K, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, e->Gp, e->K));
@@ -1293,8 +1276,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = outer_exp(e);
             if (e->Valpha) f.D = e->Valpha;
         }
-        static const bool euc_fused_h = getenv("NMFX_EUC_HSTEP_FUSED") != nullptr;   // dev switch: previous behaviour
-        if (func == 0 && e->VT && !euc_fused_h) {
+        if (func == 0 && e->VT) {
             // euclidean: the numerator W'*V has no first product.  The H-step form of the stationary kernel reads its V tile with the lanes
             // ACROSS columns (16-byte pieces at stride m) and, with half the MFMA work per tile to hide that under, ran 0.61 ms at C2; the
             // pipelined two-operand GEMM 0.60 ms (0.75 of peak).  V never changes, so a transposed copy made once turns the product into
@@ -1318,7 +1300,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             else if (e->algo == 3) TRY(z_update(e->st, e->Z, e->H, e->Gn, e->Gp, e->Gpvec, e->K, e->nz, e->seg_dev, e->lamH, e->fixH, 1.0f, 0));
             else TRY(h_update(e->st, e->H, e->Gn, e->Gp, nullptr, e->K, e->n, e->lamH, e->fixH, 1.0f, 1, 0, e->H64));
             }
-        } else if (func == 0 && !euc_fused_h && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
+        } else if (func == 0 && e->K % 64 == 0) {   // K % 64 != 0 would drop the GEMM to its unaligned (general) kernel
             // euclidean: the numerator W'*V needs no first product, so the register-stationary kernel has half the MFMA work
             // per tile barrier; the pipelined GEMM runs this plain contraction faster (C2: 0.87 -> ~0.6 ms)
             {
@@ -1453,8 +1435,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
             }
             // euclidean Gram path, one GPU: the shift-sum over t rides in the H update below (h_update_shift), which also rewrites the padded copy of H
-            fuse_hupd = e->gram && e->algo == 1 && mdiv(e) == NMFX_DIV_EUCLIDEAN && outer_exp(e) == 1.0f && e->hL == 0 && e->hR == 0 && e->Hpad && !e->fusedT_kl &&
-                        getenv("NMFX_NO_HUPD_FUSE") == nullptr;
+            fuse_hupd = e->gram && e->algo == 1 && mdiv(e) == NMFX_DIV_EUCLIDEAN && outer_exp(e) == 1.0f && e->hL == 0 && e->hR == 0 && e->Hpad && !e->fusedT_kl;
             if (!fuse_hupd) {
                 Scope s(e, TAG_SMALL);
                 TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gn));

@@ -282,8 +282,7 @@ void gemm_tile_shape(long M, long N, int &bm, int &bn) {
     if (M % 128 != 0 && M % 64 == 0) bm = 64;   // (320, 448, ...: whole 64-row tiles instead of the guarded-edge kernel)
     if (bm == 128 && N % 128 != 0 && N % 64 == 0 && N <= 192) bn = 64;
     // few output tiles (W*(H*H'): 64 of them at C2): half-height tiles double the workgroups of a launch that cannot fill the chip anyway
-    static const bool no_half = getenv("NMFX_GEMM_NO_HALF_TILES") != nullptr;   // dev switch (A/B runs)
-    if (!no_half && bm == 128 && bn == 128 && M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) < 256 && M >= 256) bm = 64;
+    if (bm == 128 && bn == 128 && M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) < 256 && M >= 256) bm = 64;
 }
 
 // pipelined kernel: no powf maps.  vec = float4 loads: 16-byte aligned views
@@ -300,8 +299,7 @@ static bool pipe_ok(const GemmParams &p, int &bm, int &bn, bool &fast, bool &hea
     const bool a_dim = is_kc(p.A.mode) ? p.Kc % 4 == 0 : p.M % 4 == 0;
     const bool b_dim = is_kc(p.B.mode) ? p.Kc % 4 == 0 : p.N % 4 == 0;
     vec = views && a_dim && b_dim;
-    static const bool pipe_off = getenv("NMFX_GEMM_NOPIPE") != nullptr;   // dev switch: A/B the two kernels
-    return !heavy && !pipe_off && kview_ok(p.A) && kview_ok(p.B) && rview_ok(p.A) && rview_ok(p.B) && (p.splitk <= 1 || kspan % BK == 0);
+    return !heavy && kview_ok(p.A) && kview_ok(p.B) && rview_ok(p.A) && rview_ok(p.B) && (p.splitk <= 1 || kspan % BK == 0);
 }
 bool gemm_pipe_eligible(const GemmParams &p) {
     int bm, bn; bool fast, heavy, vec;
@@ -353,7 +351,7 @@ int gemm_pick_split(long M, long N, long Kc) {
 // slabs of the VALU kernel for tiny products (tiny_gemm_kernel below): a small output over a long contraction needs the contraction split
 // finely to put a few hundred waves on the chip
 static bool tiny_size(long M, long N, long Kc) {
-    static const double lim = getenv("NMFX_GEMM_TINY_LOG2") ? std::ldexp(1.0, atoi(getenv("NMFX_GEMM_TINY_LOG2"))) : (double)(1 << 25);   // dev switch (accuracy experiments: every plain product fp64-accumulated)
+    const double lim = (double)(1 << 25);
     return M > 0 && N > 0 && Kc > 0 && 2.0 * (double)M * (double)N * (double)Kc <= lim;
 }
 static long tiny_split(long M, long N, long Kc, long *per) {
@@ -390,8 +388,7 @@ __global__ __launch_bounds__(256) void tiny_gemm_kernel(const float *A, long lda
 static bool tiny_plain(const OpView &v) { return (v.mode == VIEW_RC || v.mode == VIEW_KC) && v.func == NMFX_PRO_NONE && !v.p2; }
 
 nmfx_status gemm_auto(hipStream_t st, GemmParams p, void *scratch, size_t scratch_bytes) {
-    static const bool no_tiny = getenv("NMFX_GEMM_NO_TINY") != nullptr;   // dev switch (A/B runs)
-    if (!no_tiny && p.epi == EPI_STORE && !p.accumulate && !p.clamp0 && p.zbatch == 0 && p.M > 0 && p.N > 0 && p.Kc > 0 && tiny_plain(p.A) && tiny_plain(p.B) &&
+    if (p.epi == EPI_STORE && !p.accumulate && !p.clamp0 && p.zbatch == 0 && p.M > 0 && p.N > 0 && p.Kc > 0 && tiny_plain(p.A) && tiny_plain(p.B) &&
         tiny_size(p.M, p.N, p.Kc)) {
         long per = p.Kc, S = (p.ldc == p.M && scratch) ? tiny_split(p.M, p.N, p.Kc, &per) : 1;
         if (S > 1) {

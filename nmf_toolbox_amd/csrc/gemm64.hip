@@ -3,7 +3,6 @@
 // The K-long fp32 accumulation chain of this product -- not the storage of W -- is what put H-fixed problems past the 1e-5 contract (round 4: 1.06e-5 ... 1.7e-5
 // on W; the chain's rounding differs from iteration to iteration and the W update amplifies it; scripts/emu_precision.py).  m*K*K multiply-adds: a few
 // per cent of the n-long contractions next to it, so it is simply done in double, with the float64 master copy of W as the left operand.
-#include <cstdlib>
 #include "nmfx_internal.h"
 
 namespace nmfx {
@@ -95,83 +94,6 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const void *__restrict__ Ap
     }
 }
 
-// The same product without LDS: every wave loads the MFMA operands of its 32 x 32 block straight into registers, one 32-deep slab of the contraction ahead of
-// the 32 MFMAs that consume the previous one (the LDS version keeps one 16-deep tile -- 16 MFMAs, ~0.4 us -- in flight per barrier: less than a trip to HBM, so
-// it ran at the memory latency, 106 us for cnmf's 4096 x 512 x 512 where the matrix core needs 27).  No barriers: the two waves of a SIMD overlap freely.
-template <bool A64, bool B64>
-__global__ __launch_bounds__(256) void gemm64_direct_kernel(const void *__restrict__ Ap, long lda, const void *__restrict__ Bp, long ldb, long M, long N, long Kc,
-                                                             double *__restrict__ C64, float *__restrict__ C32, long ldc) {
-    constexpr int CK = 32, KS = CK / 4;   // slab depth, MFMA k-steps per slab
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w & 1, wn = w >> 1, l15 = lane & 15, lk = lane >> 4;
-    const long i0 = (long)blockIdx.x * G64_BM + 32 * wm, j0 = (long)blockIdx.y * G64_BN + 32 * wn;
-    long ia[2], jb[2];
-    bool ia_ok[2], jb_ok[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) { const long i = i0 + 16 * a + l15; ia_ok[a] = i < M; ia[a] = ia_ok[a] ? i : 0; }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) { const long j = j0 + 16 * b + l15; jb_ok[b] = j < N; jb[b] = jb_ok[b] ? j : 0; }
-    double ra[2][KS], rb[2][KS], na[2][KS], nb[2][KS];
-    auto gload = [&](long k0, double (&xa)[2][KS], double (&xb)[2][KS]) {
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const long k = k0 + 4 * kk + lk;
-            const bool k_ok = k < Kc;
-            const long kc = k_ok ? k : 0;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const double v = A64 ? static_cast<const double *>(Ap)[ia[a] + lda * kc] : (double)static_cast<const float *>(Ap)[ia[a] + lda * kc];
-                xa[a][kk] = (k_ok && ia_ok[a]) ? v : 0.0;
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const double v = B64 ? static_cast<const double *>(Bp)[kc + ldb * jb[b]] : (double)static_cast<const float *>(Bp)[kc + ldb * jb[b]];
-                xb[b][kk] = (k_ok && jb_ok[b]) ? v : 0.0;
-            }
-        }
-    };
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.0;
-    auto compute = [&](const double (&xa)[2][KS], const double (&xb)[2][KS]) {
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[b][kk], xa[a][kk], acc[a][b], 0, 0, 0);   // D(row = j, col = i)
-    };
-    const long nslab = (Kc + CK - 1) / CK;
-    gload(0, ra, rb);
-    for (long sl = 0; sl < nslab; sl += 2) {   // two slabs per trip: the register sets swap roles without copies
-        if (sl + 1 < nslab) gload((sl + 1) * CK, na, nb);
-        compute(ra, rb);
-        if (sl + 1 < nslab) {
-            if (sl + 2 < nslab) gload((sl + 2) * CK, ra, rb);
-            compute(na, nb);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const long i = i0 + 16 * a + l15;
-        if (i >= M) continue;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long j = j0 + 16 * b + lk + 4 * e;
-                if (j >= N) continue;
-                const double v = acc[a][b][e];
-                if (C64) C64[i + ldc * j] = v;
-                if (C32) C32[i + ldc * j] = (float)v;
-            }
-    }
-}
-
 }  // namespace
 
 nmfx_status gemm64(hipStream_t st, long M, long N, long Kc, const double *A64, const float *A32, long lda, const double *B64, const float *B32, long ldb,
@@ -181,15 +103,6 @@ nmfx_status gemm64(hipStream_t st, long M, long N, long Kc, const double *A64, c
     dim3 grid((unsigned)((M + G64_BM - 1) / G64_BM), (unsigned)((N + G64_BN - 1) / G64_BN));
     const void *A = A64 ? static_cast<const void *>(A64) : static_cast<const void *>(A32);
     const void *B = B64 ? static_cast<const void *>(B64) : static_cast<const void *>(B32);
-    static const bool lds_version = getenv("NMFX_GEMM64_LDS") != nullptr;   // dev switch (A/B runs): the LDS-tiled kernel of the round's first build
-    if (!lds_version) {
-        if (A64 && B64) hipLaunchKernelGGL((gemm64_direct_kernel<true, true>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
-        else if (A64) hipLaunchKernelGGL((gemm64_direct_kernel<true, false>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
-        else if (B64) hipLaunchKernelGGL((gemm64_direct_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
-        else hipLaunchKernelGGL((gemm64_direct_kernel<false, false>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
-        NMFX_HIP(hipGetLastError());
-        return NMFX_OK;
-    }
     if (A64 && B64) hipLaunchKernelGGL((gemm64_kernel<true, true>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
     else if (A64) hipLaunchKernelGGL((gemm64_kernel<true, false>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);
     else if (B64) hipLaunchKernelGGL((gemm64_kernel<false, true>), grid, dim3(256), 0, st, A, lda, B, ldb, M, N, Kc, C64, C32, ldc);

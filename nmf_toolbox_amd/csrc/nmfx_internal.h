@@ -148,9 +148,6 @@ bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of 
 nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi);
 
 // ---- small products of the Gram form (small_mm.hip) ----------------------------------------------------------------------
-size_t gram_rc_scratch_bytes(int K1, int K2, long n);
-nmfx_status gram_rc(hipStream_t st, const float *A, long lda, int K1, const float *B, long ldb, int K2, long n, float *C, void *scratch, size_t scratch_bytes,
-                    long b_tshift = 0, int b_tblk = 0);
 bool h_update_gram_supported(int K);
 nmfx_status h_update_gram(hipStream_t st, float *H, const float *G, const float *Gn, int n_slabs, long slab_stride, int K, long n, const float *lam,
                           const uint8_t *fix, double *H64 = nullptr);   // H64: the float64 master of H (K x n), see h_update

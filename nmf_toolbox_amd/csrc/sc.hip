@@ -308,8 +308,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
     // G (K x n) = Wx' * V and Den (K x n) = (Wx'*Wx) * Hx      (Hx: K x n)
     auto fast_h_terms = [&](const float *Wx, const float *Hx) -> nmfx_status {
         PScope ps(pf, SC_HTERMS);
-        static const bool sc_fused_env = getenv("NMFX_SC_FUSED_HTERMS") != nullptr;   // dev switch: A/B
-        const bool sc_fused_terms = sc_fused_env || K % 64 != 0;   // the GEMM is only pipelined for tile-aligned outputs
+        const bool sc_fused_terms = K % 64 != 0;   // the GEMM is only pipelined for tile-aligned outputs
         if (sc_fused_terms) {
         TRY(transpose_f32(st, Wx, m, K, WTb.as<float>()));
         FusedParams f;
@@ -331,17 +330,14 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         PScope ps(pf, SC_WTERMS);
         float *KK = N_ + mK;
         // V*H' (N = K wide): the register-stationary kernel (R = V, two workgroups per CU at K <= 128) beats the split-K GEMM here
-        static const bool sc_fused_terms = getenv("NMFX_SC_GEMM_WTERMS") == nullptr;   // dev switch: A/B
-        if (sc_fused_terms) {
+        {
         FusedParams f;
         memset(&f, 0, sizeof(f));
         f.X = Wx; f.xs_r = 1; f.xs_k = m; f.Y = Hx; f.D = Vp; f.ldd = m; f.R = m; f.Cn = n; f.K = K; f.c_per_split = cps_w;
         f.out = nsplit_w == 1 ? N_ : slabs.as<float>(); f.slab_stride = (long)m * K; f.os_r = 1; f.os_k = m;
         TRY(launch_fused(st, f, nsplit_w, true, 0, true, 0));
         if (nsplit_w > 1) TRY(reduce_slabs(st, slabs.as<float>(), nsplit_w, f.slab_stride, f.slab_stride, N_, 0));
-        } else
-        TRY(kk_gemm(m, K, n, OpView{Vp, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
-                    N_, m));
+        }
         TRY(kk_gemm(K, K, n, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, OpView{Hx, nullptr, (long)K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f}, KK, K));
         if (comm.active()) TRY(comm.allreduce(N_, (long)(mK + (size_t)K * K), NMFX_F32, NMFX_REDUCE_SUM));   // the ONE large exchange of an outer iteration
         return kk_gemm(m, K, K, OpView{Wx, nullptr, m, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f},
@@ -382,8 +378,7 @@ nmfx_status run_nmfsc(const nmfx_problem *p, nmfx_result *r, ScDev *dev = nullpt
         const bool lsH = !fixH && sH > 0;
         // With BOTH line searches active every objective evaluation is made by the residual pass of the OTHER factor: the try that is
         // accepted (4 of 5 are) has then already produced the gradient the next line search starts from, and a 4*mnK pass per search is gone.
-        static const bool no_spec = getenv("NMFX_SC_NO_SPEC") != nullptr;   // dev switch (A/B runs)
-        const bool spec = lsH && !fixW && sW > 0 && !no_spec;
+        const bool spec = lsH && !fixW && sW > 0;
         bool have_dW = false;   // G2 (g64w) = dW of the current (Wd, Hcur), not yet summed over the shards
         bool have_dH = false;   // Denb = dH of the current (Wd, Hcur)
         if (lsH && p->maxiter >= 1) { TRY(resid_h(Wd, Hcur, &r->cost[0])); have_dH = true; }

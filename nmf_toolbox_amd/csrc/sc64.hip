@@ -105,8 +105,7 @@ inline dim3 g1(long count) { return dim3((unsigned)((count + 255) / 256)); }
 namespace nmfx {
 
 bool nmfsc_f64_eligible(const nmfx_problem *p) {
-    static const bool off = getenv("NMFX_SC_NO_F64") != nullptr;   // dev switch (A/B runs against the fp32-storage paths)
-    return !off && p && p->path == 0 && p->T == 1 && p->n_gpus <= 1 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
+    return p && p->path == 0 && p->T == 1 && p->n_gpus <= 1 && (double)p->m * (double)p->n * (double)p->K_total <= (double)(1 << 27);
 }
 
 nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {

@@ -4,10 +4,6 @@
 // 128 x 128 output is ONE tile of that kernel: all its parallelism is split-K through a two-k-tile-ahead LDS pipeline that never fills),
 // plus slab-reduction launches; together with the H update they were 190 us of BASELINE config 2's 1.71 ms iteration.
 //
-//   gram_rc_kernel   C_z (K1 x K2) = sum_{c in slab z} A(:, c) * B(:, c)'     both operands contiguous along the OUTPUT index (columns of H,
-//                    rows of W through its transposed copy): every MFMA operand is one coalesced dword load straight from global memory / L2
-//                    -- no LDS, no barrier.  A workgroup owns a whole 128-wide block of the output, so a pair of columns (1 KB) feeds 16
-//                    MFMAs; the contraction is cut into one slab per workgroup and the slabs are summed by reduce_slabs (fixed order).
 //   h_update_gram    H(:, j) <- H(:, j) .* sum_z Gn_z(:, j) ./ max(G*H(:, j) + lambda, eps)   (nmf.m:181,199): G*H for 32 columns per wave on
 //                    the MFMA (G from L2, H's columns as the other operand), the numerator slabs summed on the fly, H rewritten in place.
 #include "gemm_common.h"
@@ -21,79 +17,6 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
     for (int e = 0; e < 16; ++e) z[e] = 0.0f;
     return z;
-}
-
-// NWI waves along i (32 rows each), 4 / NWI waves along j, JB 32-column blocks per wave: workgroup block (32 NWI) x (32 JB 4/NWI)
-template <int NWI, int JB>
-__global__ __launch_bounds__(256) void gram_rc_kernel(const float *__restrict__ A, long lda, int K1, const float *__restrict__ B, long ldb, int K2, long n,
-                                                      long cps, long b_tshift, int b_tblk, float *__restrict__ C, long ldc, long slab_stride, int nbi) {
-    constexpr int NWJ = 4 / NWI;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wi = wave % NWI, wj = wave / NWI;
-    const int bi = blockIdx.y % nbi, bj = blockIdx.y / nbi;
-    const int i = bi * 32 * NWI + 32 * wi + l31;
-    const bool iok = i < K1;
-    const float *ap = A + (iok ? i : 0);
-    const float *bp[JB];
-    bool jok[JB];
-#pragma unroll
-    for (int b = 0; b < JB; ++b) {
-        const int j = bj * 32 * JB * NWJ + 32 * (wj * JB + b) + l31;
-        jok[b] = j < K2;
-        const int jj = jok[b] ? j : 0;
-        // stacked second operand (cnmf lag Grams): output column j = (t, k) reads B(k, c + t * shift)
-        bp[b] = b_tblk > 0 ? B + (jj % b_tblk) + b_tshift * (jj / b_tblk) : B + jj;
-    }
-    const long c0 = (long)blockIdx.x * cps, c1 = c0 + cps < n ? c0 + cps : n;
-    f32x16 acc[JB];
-#pragma unroll
-    for (int b = 0; b < JB; ++b) acc[b] = zero16();
-    // groups of 4 MFMA steps = 8 contraction indices; lane half h takes the odd / even one of each pair
-    float a0[4], b0[JB][4], a1[4], b1[JB][4];
-    auto load = [&](long c, float (&a)[4], float (&bb)[JB][4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long cc = c + 2 * s + h;
-            const bool ok = cc < c1;
-            const long co = ok ? cc : c0;
-            const float av = ap[lda * co];
-            a[s] = (ok && iok) ? av : 0.0f;
-#pragma unroll
-            for (int b = 0; b < JB; ++b) {
-                const float bv = bp[b][ldb * co];
-                bb[b][s] = (ok && jok[b]) ? bv : 0.0f;
-            }
-        }
-    };
-    auto mma = [&](const float (&a)[4], const float (&bb)[JB][4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int b = 0; b < JB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb[b][s], a[s], acc[b], 0, 0, 0);
-    };
-    long c = c0;
-    if (c < c1) load(c, a0, b0);
-    for (; c < c1; c += 16) {
-        if (c + 8 < c1) load(c + 8, a1, b1);
-        mma(a0, b0);
-        if (c + 8 < c1) {
-            if (c + 16 < c1) load(c + 16, a0, b0);
-            mma(a1, b1);
-        }
-    }
-    // acc[b][e] = C(i, j), j = j_block + (e & 3) + 8 (e >> 2) + 4 h: lanes run along i (128-byte segments)
-    float *Cz = C + (long)blockIdx.x * slab_stride;
-    if (iok) {
-#pragma unroll
-        for (int b = 0; b < JB; ++b) {
-            const int jb0 = bj * 32 * JB * NWJ + 32 * (wj * JB + b);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = jb0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (j < K2) Cz[i + ldc * j] = acc[b][e];
-            }
-        }
-    }
 }
 
 // one workgroup = 32 columns of H; its NW = min(KB, 4) waves share them and split the KB = K / 32 blocks of 32 output rows k among themselves
@@ -241,37 +164,6 @@ nmfx_status quad_cols(hipStream_t st, const float *H, const float *Hc, const flo
     }
 #undef NMFX_QC
     NMFX_HIP(hipGetLastError());
-    return NMFX_OK;
-}
-
-size_t gram_rc_scratch_bytes(int K1, int K2, long n) {
-    const long nb = ((K1 + 127) / 128) * (long)((K2 + 127) / 128);
-    long S = std::max<long>(1, 512 / nb);
-    S = std::min<long>(S, std::max<long>(1, n / 64));
-    return sizeof(float) * (size_t)K1 * K2 * (size_t)(S + 1);
-}
-
-// C (K1 x K2, ld K1) = A * B' with A (K1 x n, ld lda), B (K2 x n, ld ldb); b_tblk > 0: output column j = (t, k), k < b_tblk, reads B(k, c) shifted by
-// t * b_tshift elements (the lag Grams of cnmf).  Deterministic: the slab decomposition depends on the shape alone.
-nmfx_status gram_rc(hipStream_t st, const float *A, long lda, int K1, const float *B, long ldb, int K2, long n, float *C, void *scratch, size_t scratch_bytes,
-                    long b_tshift, int b_tblk) {
-    if (K1 <= 0 || K2 <= 0 || n <= 0) return NMFX_OK;
-    const bool narrow = K1 <= 64;                      // 64-row outputs: two waves along i, 256 columns per workgroup
-    const int bi_rows = narrow ? 64 : 128, bj_cols = narrow ? 256 : 128;
-    const int nbi = (K1 + bi_rows - 1) / bi_rows, nbj = (K2 + bj_cols - 1) / bj_cols;
-    const long nb = (long)nbi * nbj;
-    long S = std::max<long>(1, 512 / nb);
-    S = std::min<long>(S, std::max<long>(1, n / 64));
-    const size_t slab = (size_t)K1 * K2;
-    while (S > 1 && sizeof(float) * slab * (size_t)S > scratch_bytes) --S;
-    long cps = ((n + S - 1) / S + 7) & ~7L;
-    S = (n + cps - 1) / cps;
-    float *dst = S > 1 ? static_cast<float *>(scratch) : C;
-    dim3 grid((unsigned)S, (unsigned)nb);
-    if (narrow) hipLaunchKernelGGL((gram_rc_kernel<2, 4>), grid, dim3(256), 0, st, A, lda, K1, B, ldb, K2, n, cps, b_tshift, b_tblk, dst, (long)K1, (long)slab, nbi);
-    else hipLaunchKernelGGL((gram_rc_kernel<4, 4>), grid, dim3(256), 0, st, A, lda, K1, B, ldb, K2, n, cps, b_tshift, b_tblk, dst, (long)K1, (long)slab, nbi);
-    NMFX_HIP(hipGetLastError());
-    if (S > 1) return reduce_slabs(st, dst, (int)S, (long)slab, (long)slab, C, 0);
     return NMFX_OK;
 }
 
