@@ -337,7 +337,10 @@ def bench_blocking(args):
     lib = _lib.load()
     backends = [None] if args.gpus <= 1 and not args.backends else [b for b in (args.backends or "rccl,peer").split(",") if b]
     for be in backends:
-        c2 = dict(cfg) if be is None else dict(cfg, nmfx_gpus=list(range(max(args.gpus, 1))), nmfx_multi_backend=be)
+        # NMFX_BENCH_ONE_DEVICE: the N shards all on device 0 (peer backend only: RCCL refuses one device twice) -- what a 1-GPU box can say about the peer
+        # reduce kernel: N-1 of N slices of `packed` pulled per shard at HBM instead of xGMI speed, an upper bound of its bandwidth
+        devs = [0] * max(args.gpus, 1) if os.environ.get("NMFX_BENCH_ONE_DEVICE") else list(range(max(args.gpus, 1)))
+        c2 = dict(cfg) if be is None else dict(cfg, nmfx_gpus=devs, nmfx_multi_backend=be)
         run = (lambda: A.nmf(V, K, c2)) if alg == "nmf" else (lambda: A.cnmf(V, K, T, c2))
         t0 = time.perf_counter()
         try:

@@ -182,6 +182,7 @@ struct nmfx_engine {
     bool wstep_gram;          // the W step in flight runs in this mode (set by wstep_partial, read by wstep_finish)
     bool classic;             // host-side latch: the decision of two W updates ago had the flag set (or the caller chunks the W step): the one-pass kernel with the cost inside again
     unsigned decide_seq;      // gram_decide launches since init: decision s publishes (s+1) << 1 | flag into exact_flag_host[s & 7]
+    bool p1gram;              // path 1 (materialised V_hat), euclidean nmf: the W-step denominators all the same as W*(H*H') in float64 (engine.hip::generic_wstep_partial)
     bool dist_seen, sumvv_global_set;   // column shards: the decision needs the GLOBAL ||V||^2 (nmfx_engine_sumvv_ptr); without it the mode stays off
     double *sumVV;            // device [2]: ||V_local||^2, ||V_global||^2
     double *dndp;             // device [2*K]: column sums dn = cs(W.*P), dp = cs(W.*N) of the last W update

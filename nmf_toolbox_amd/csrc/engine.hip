@@ -147,6 +147,7 @@ Layout layout(nmfx_engine *e, void *ws) {
             if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
         }
     }
+    if (e->p1gram) e->CC = c.take<float>((size_t)e->K * e->K);
     if (e->gram_cost) {   // (cnmf on the fused passes)
         e->sumVV = c.take<double>(2);
         e->dndp = c.take<double>(2 * (size_t)e->KT);
@@ -273,6 +274,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // euclidean problems the register-stationary kernels do not take (cnmf; nmf / constrainednmf with K > 256 or tiny shapes) still never
     // materialise V_hat: denominators from Gram products, the cost from a store-less residual pass
     e->gram = !e->fused && (e->algo == 0 || e->algo == 1 || e->algo == 3) && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST) && d->path != 1;
+    e->p1gram = !e->fused && !e->gram && (e->algo == 0 || e->algo == 3) && e->T == 1 && (e->div == NMFX_DIV_EUCLIDEAN || e->div == NMFX_DIV_EUCLIDEAN_NOCOST);
     e->fusedT = e->gram && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 && (e->hL == 0 || e->hL >= e->T - 1);
     // (column shards: the T-1 columns left of the shard are its halo -- or zeros on the first one --, and R = V./V_hat is also formed on the T-1 right-halo
     // columns, whose terms the shift-sum of the H step needs: cnmf.m:219)
@@ -1134,6 +1136,14 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         Scope s(e, TAG_GRAM);
         OpView hs{e->H, nullptr, (long)e->K, e->T == 1 ? VIEW_RC : VIEW_HSTACK_RC, e->K, 0, 0, NMFX_PRO_NONE, 0.f, 0.f, e->hL};
         TRY(small_gemm(e, e->KT, e->KT, e->n, hs, hs, e->packed + mKT, e->KT));
+    } else if (e->p1gram) {
+        // path 1 keeps V_hat for the cost and the H step, but V_hat*H' (nmf.m:150) as an fp32 product of the fp32 V_hat is what put over-complete problems with
+        // H fixed at 1e-5 ... 3e-5 on W (profiles/r5_05_fuzz_campaign_fixed_factor.log): the shard's share of it is formed as W*(H*H') in float64 from the
+        // master copy of W, like every other euclidean path, and rounded ONCE into the fp32 slot that travels in the all-reduce
+        Scope s(e, TAG_WDEN);
+        OpView hv{e->H, nullptr, (long)e->K, VIEW_RC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        TRY(small_gemm(e, e->K, e->K, e->n, hv, hv, e->CC, e->K));
+        TRY(gemm64(e->st, e->m, e->K, e->K, e->W64, nullptr, e->m, nullptr, e->CC, e->K, nullptr, e->packed + mKT, e->m));
     } else if (div_has_matrix_den(e->div)) {
         den_view(e, b);
         TRY(x_times_ht(e, b, e->packed + mKT, TAG_WDEN));

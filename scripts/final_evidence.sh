@@ -7,7 +7,7 @@ for w in c3 c2 c4 c4kl c5 c2is c2is256 c4sc; do
 done
 NMFX_BENCH_BACKEND=gloo NMFX_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 10 --warmup 3 --workload c3_shard2 --no-cpu-baseline > gpurun_out/${TAG}_bench_selflaunch_2ranks_gloo.json 2> gpurun_out/${TAG}_bench_selflaunch.err
 cd /tmp && export TMPDIR=/tmp
-for w in c3 c2 c4 c4kl c5; do
+for w in c3 c2 c4 c4kl c5 c4sc c2is256; do
   rm -rf /tmp/ks_$w
   rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o ks -- python $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
   python $R/profiles/summarize_rocprof.py /tmp/ks_$w/ks_results.db "python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline   (rocprofv3 --kernel-trace --stats; 5 warm-up + 20 timed iterations, averages include the warm-up launches)" > $R/gpurun_out/${TAG}_${w}_kernel_stats.md

@@ -1,6 +1,6 @@
 """One-off campaign (not part of the suite) for the class that was outside the contract until round 4: nmf / cnmf with ONE factor fixed for 9-14 iterations,
 over-complete or not, random or planted data, on every kernel path (register-stationary kernels, K > 256 in column blocks, Gram form on the GEMM, materialised,
-column shards) -- against the float64 oracle.     scripts/fuzz_campaign_fixed_factor.py <seed> <seconds>"""
+column shards) -- against the float64 oracle.     scripts/fuzz_campaign_fixed_factor.py <seed> <seconds> [kind,kind,...]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
@@ -9,10 +9,11 @@ import nmf_toolbox_amd as A
 from oracle import nmf_oracle as O
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
+KINDS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["wide", "wide", "fused", "fused", "gram_small", "path1", "cnmf", "shards", "kl"]
 rs = np.random.RandomState(seed)
-t0 = time.time(); counts = {}; worst = dict(W=0.0, H=0.0, cost=0.0); bad = 0
+t0 = time.time(); counts = {}; worst = dict(W=0.0, H=0.0, cost=0.0); bad = 0; cost_only = 0
 while time.time() - t0 < budget:
-    kind = str(rs.choice(["wide", "wide", "fused", "fused", "gram_small", "path1", "cnmf", "shards", "kl"]))
+    kind = str(rs.choice(KINDS))
     planted = bool(rs.rand() < 0.5)
     fixed = "H_fixed" if rs.rand() < 0.8 else "W_fixed"
     it = int(rs.randint(9, 15))
@@ -41,6 +42,8 @@ while time.time() - t0 < budget:
     counts[kind] = counts.get(kind, 0) + 1
     e = dict(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]) if len(got[2]) == len(ref[2]) else 1.0)
     for k in worst: worst[k] = max(worst[k], e[k])
+    if e["W"] <= 1e-5 and e["H"] <= 1e-5 and 1e-6 < e["cost"] <= 1e-5:
+        cost_only += 1   # inside north_star's 1e-5 on every output; past this repo's own 1e-6 on the cost (KL, W fixed, near-perfect fits: cost << sum(V))
     if not (e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6):
         bad += 1; print("BAD", (kind, m, n, K, T, planted, fixed, it, extra, {k: v for k, v in cfg.items() if k.endswith("sparsity")}), e, flush=True)
-print("seed", seed, "cases", counts, "total", sum(counts.values()), "worst", worst, "bad", bad)
+print("seed", seed, "cases", counts, "total", sum(counts.values()), "worst", worst, "bad", bad, "of which only the cost, between 1e-6 and 1e-5:", cost_only)
