@@ -276,7 +276,10 @@ def bench_cnmfsc(args):
              names[3]: "W-step terms (cnmfsc.m:257-263) without V_hat: N = V*H_stack' for all t in ONE fused pass over V; G = Hs*Hs' from the T lag Grams of H; the slice loop "
                        "pos_t = sum_s Wcur_s*G[(s,.),(t,.)], W_t = W0_t.*N_t./max(pos_t, eps) in one launch over the rows of W (aux.hip::cnmfsc_w_slices)"}
     # flops / algorithmic bytes of a tag PER OUTER ITERATION.  The W-step tag: the pass over V (2*m*n*K*T), the lag Grams (2*K*KT*n) and the slice loop (2*m*KT*KT)
-    per_it = {names[0]: (f * cnt[0] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[0] / total), names[2]: (f * cnt[2] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[2] / total),
+    # objective tag: ONE whole-matrix pass per outer iteration (cnmfsc.m:269, V_hat stored for the next H step) + the initial one (cnmfsc.m:152); every line-search
+    # try is a quadratic-expansion evaluation, one KT x n x KT product on the stacked shifts (2*KT*KT*n flops, K*n-sized operands) -- not a pass over V
+    ntry = float(sum(tries))
+    per_it = {names[0]: ((f * (total + 1) + 2.0 * (K * T) ** 2 * n * ntry) / total, (4.0 * (2 * m * n + m * K * T + K * n) * (total + 1) + 4.0 * (2 * K * T * n + (K * T) ** 2) * ntry) / total), names[2]: (f * cnt[2] / total, 4.0 * (2 * m * n + m * K * T + K * n) * cnt[2] / total),
               names[3]: (f + 2.0 * K * K * T * n + 2.0 * m * (K * T) ** 2, 4.0 * (m * n + 3 * m * K * T + 2 * K * n))}
     tags = {names[t]: (ms[t], cnt[t]) for t in range(nt) if cnt[t] > 0 and names[t] in per_it}
     roof = None
@@ -285,7 +288,7 @@ def bench_cnmfsc(args):
         ms_it = tags[name][0] / total
         ach = per_it[name][0] / (ms_it * 1e-3) / 1e12
         pm, tsrc = pmc_traffic_for(args.workload)   # HBM bytes per outer iteration of that tag's launches, from the separate --pmc passes (not measured in this run)
-        roof = dict(bound="mfma", kernel=label[name], achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pm.get(name),
+        roof = dict(bound="mfma", kernel=label[name], achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=([v for k, v in pm.items() if name.startswith(k)] or [None])[0],
                     traffic_source=tsrc, ms_per_outer_iteration=round(ms_it, 4), launch_groups=int(tags[name][1]), flops_per_outer_iteration=per_it[name][0], algorithmic_bytes_per_outer_iteration=per_it[name][1],
                     tag_frac_of_peak={k: round(per_it[k][0] / (tags[k][0] / total * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) for k in tags},
                     phases_ms_per_iteration_whole_call={names[t]: round(ms[t] / total, 4) for t in range(nt) if cnt[t] > 0})

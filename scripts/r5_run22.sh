@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+python -m pytest tests/test_gpu_golden.py tests/test_gpu_pins.py tests/test_gpu_conditioning.py -x -q 2>&1 | tail -2
+for w in c3 c2 c4; do
+python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/r5_22_bench_$w.json 2>/dev/null
+tail -1 gpurun_out/r5_22_bench_$w.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$w', d['value'], d['ms_per_step'], d['roofline']['phases_ms_per_step'], d['cost_first_last'])"
+done
+bash scripts/prof_cmd.sh r5_22_c3 python $GRAFT_REPO_ROOT/bench.py --workload c3 --steps 20 --warmup 5 --no-cpu-baseline
+cd $GRAFT_REPO_ROOT; grep -E "w_update|w_normalize" gpurun_out/r5_22_c3_kernel_stats.md | cut -c1-160
