@@ -1139,9 +1139,9 @@ nmfx_status mu_plain_diff(hipStream_t st, const float *X0, const float *neg, con
 // reference's float64.  One workgroup per 16 rows of W: the rows' KT entries live in LDS and are overwritten slice by slice, G streams through LDS in chunks of 32 rows
 // (prefetched into registers while the previous chunk is contracted), 32-term fp32 partial sums accumulated in double.  N = V*H_stack' (m x KT) from the one fused
 // pass over V.  The last slice's correction is dead in the reference too (cnmfsc.m:269 re-forms V_hat).
-template <int K>
+template <int K, int ROWS, int CH>
 __global__ __launch_bounds__(256) void cnmfsc_w_slices_kernel(const float *W0, const float *Nn, const float *G, long m, int T, float *W) {
-    constexpr int ROWS = 16, RG = 256 / K, RPT = ROWS / RG, CH = 32, GPT = CH * K / 256;
+    constexpr int RG = 256 / K, RPT = ROWS / RG, GPT = CH * K / 256;
     extern __shared__ float lds_ws[];
     const int KT = K * T, ldw = KT + 4;
     float *w = lds_ws;               // [ROWS][ldw]: the current W of these rows
@@ -1200,12 +1200,19 @@ __global__ __launch_bounds__(256) void cnmfsc_w_slices_kernel(const float *W0, c
 }
 nmfx_status cnmfsc_w_slices(hipStream_t st, const float *W0, const float *Nn, const float *G, long m, int K, int T, float *W) {
     if (m <= 0) return NMFX_OK;
-    const size_t lds = sizeof(float) * (16 * ((size_t)K * T + 4) + 32 * (size_t)K);
-    if ((K != 32 && K != 64 && K != 128) || lds > 64 * 1024) { set_error("cnmfsc_w_slices: K = %d, T = %d is not served", K, T); return NMFX_ERR_UNSUPPORTED; }
-    const dim3 grid((unsigned)((m + 15) / 16)), block(256);
-    if (K == 32) hipLaunchKernelGGL(cnmfsc_w_slices_kernel<32>, grid, block, lds, st, W0, Nn, G, m, T, W);
-    else if (K == 64) hipLaunchKernelGGL(cnmfsc_w_slices_kernel<64>, grid, block, lds, st, W0, Nn, G, m, T, W);
-    else hipLaunchKernelGGL(cnmfsc_w_slices_kernel<128>, grid, block, lds, st, W0, Nn, G, m, T, W);
+    if (K != 32 && K != 64 && K != 128) { set_error("cnmfsc_w_slices: K = %d, T = %d is not served", K, T); return NMFX_ERR_UNSUPPORTED; }
+    // rows per workgroup: 16, or 8 while that still leaves the CUs with fewer than two workgroups each (the kernel is a chain of LDS round trips: the CUs want
+    // several workgroups to switch between); G chunks of 64 rows at K = 64 (16 KB; K*T is then a multiple of 64): half the barriers
+    const bool small = (m + 15) / 16 < 512 && K <= 64;
+    const int rows = small ? 8 : 16, ch = K == 64 ? 64 : 32;
+    const size_t lds = sizeof(float) * ((size_t)rows * ((size_t)K * T + 4) + (size_t)ch * K);
+    if (lds > 64 * 1024) { set_error("cnmfsc_w_slices: K = %d, T = %d is not served", K, T); return NMFX_ERR_UNSUPPORTED; }
+    const dim3 grid((unsigned)((m + rows - 1) / rows)), block(256);
+    if (K == 32 && small) hipLaunchKernelGGL((cnmfsc_w_slices_kernel<32, 8, 32>), grid, block, lds, st, W0, Nn, G, m, T, W);
+    else if (K == 32) hipLaunchKernelGGL((cnmfsc_w_slices_kernel<32, 16, 32>), grid, block, lds, st, W0, Nn, G, m, T, W);
+    else if (K == 64 && small) hipLaunchKernelGGL((cnmfsc_w_slices_kernel<64, 8, 64>), grid, block, lds, st, W0, Nn, G, m, T, W);
+    else if (K == 64) hipLaunchKernelGGL((cnmfsc_w_slices_kernel<64, 16, 64>), grid, block, lds, st, W0, Nn, G, m, T, W);
+    else hipLaunchKernelGGL((cnmfsc_w_slices_kernel<128, 16, 32>), grid, block, lds, st, W0, Nn, G, m, T, W);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

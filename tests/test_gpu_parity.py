@@ -389,8 +389,8 @@ def _cnmfsc_fused_cases():
 def test_cnmfsc_fused_passes_match_oracle(gpu_lib, sW, sH, m, n, K, T):
     """cnmfsc.m:155-277 with every whole-matrix contraction on the register-stationary kernels (nmfx_path = 2; the default above the float64-gradient
     sizes): objectives of the H line search without a stored V_hat, V_hat + objective in one pass (cnmfsc.m:215,269), the T products V*rshift_t(H)' in
-    one pass, V_hat*rshift_t(H)' and V_hat = max(V_hat + dW*rshift_t(H), 0) (cnmfsc.m:262, functor 9, in place) per slice, dH through Q + shift-sum.
-    Identical line-search tries; also against the two-operand GEMM path (nmfx_path = 1)."""
+    one pass, the multiplicative W branch from the Gram of the stacked shifts without V_hat (cnmfsc.m:257-263, aux.hip::cnmfsc_w_slices), dH through Q + shift-sum.
+    Identical line-search tries; also against the two-operand GEMM path (nmfx_path = 1), which keeps V_hat = max(V_hat + dW*rshift_t(H), 0) slice by slice."""
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K, T=T)
     cfg = dict(W_init=W0, H_init=H0, maxiter=8, tolerance=1e-12)
@@ -405,6 +405,21 @@ def test_cnmfsc_fused_passes_match_oracle(gpu_lib, sW, sH, m, n, K, T):
     _check(got, ref)
     gen = gpu_lib.cnmfsc(2.0 * V, K, T, dict(cfg, nmfx_path=1), info=i2)
     assert i2["triesH"] == i1["triesH"] and rel_fro(got[0], gen[0]) <= 5e-6 and rel_fro(got[1], gen[1]) <= 5e-6
+
+
+@pytest.mark.parametrize("m,n,K,T", [(8200, 256, 64, 2), (8192, 192, 32, 3), (260, 640, 128, 2), (512, 512, 32, 16), (4096, 320, 64, 8), (132, 200, 64, 3)])
+def test_cnmfsc_multiplicative_w_branch_every_slice_kernel(gpu_lib, m, n, K, T):
+    """cnmfsc.m:257-263 on the fused passes (no W / H sparsity: both branches multiplicative), one case per instantiation of the slice-loop kernel
+    (aux.hip::cnmfsc_w_slices: K = 32 / 64 / 128, 8 or 16 rows of W per workgroup -- 16 from m >= 8177 on --, G in chunks of 32 or 64 rows), ragged m, K*T up to
+    512 and an odd multiple of 32; against the oracle, whose V_hat = max(V_hat + dW*rshift_t(H), 0) this path never forms, and against the GEMM path, which does."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12)
+    ref = O.cnmfsc(V, K, T, cfg)
+    got = gpu_lib.cnmfsc(V, K, T, dict(cfg, nmfx_path=2))
+    _check(got, ref)
+    gen = gpu_lib.cnmfsc(V, K, T, dict(cfg, nmfx_path=1))
+    assert rel_fro(got[0], gen[0]) <= 5e-6 and rel_fro(got[1], gen[1]) <= 5e-6
 
 
 # ---- lnmf (SURVEY 8(f) row f3) on the generic and the fused KL kernels ------------------------------------------------
