@@ -8,7 +8,9 @@
 // stream / event create + destroy of round 3 back.  Every multi-device result is compared with the one-device result of the same call
 // (no oracle needed: the property is "sharding changes only the summation order").
 //
-//   fuzz_multi <seconds> <seed> [kinds: e = multi_edge, s = nmfsc on shards, x = error paths, 1 = one-device calls]   e.g.  fuzz_multi 600 12 esx1
+//   fuzz_multi <seconds> <seed> [kinds: e = multi_edge, s = nmfsc on shards, x = error paths, 1 = one-device calls,
+//                                 round 5: r = the RCCL backend (one shard: the 1-GPU box) against the plain call, c = cnmfsc / small nmfsc on one device (the
+//                                 Gram-form W branch, the float64 nmfsc), p = nmf on path 1 (materialised V_hat, float64 W*(H*H'))]   e.g.  fuzz_multi 600 12 esx1rcp
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -76,9 +78,10 @@ void churn(unsigned seed) {
 }
 
 struct Case {
-    int alg;   // 0 nmf, 1 cnmf, 2 lnmf, 4 nmfsc
+    int alg;   // 0 nmf, 1 cnmf, 2 lnmf, 4 nmfsc, 5 cnmfsc
     long m, n;
     int K, T, div, N, it;
+    int backend = 0, path = 0;   // nmfx_problem.multi_backend (2 = RCCL), nmfx_problem.path (1 = two-operand GEMMs, 2 = fused passes by name)
     double lamW, lamH, sH, sW;
     double tol;
 };
@@ -114,17 +117,19 @@ Out run(const Case &c, const std::vector<double> &V, const std::vector<double> &
     p.maxiter = c.it; p.tolerance = c.tol; p.device = 0;
     p.sc_W_sparsity = c.sW; p.sc_H_sparsity = c.sH;
     p.n_gpus = N; p.device_ids = ids;
+    p.multi_backend = c.backend; p.path = c.path;
     snprintf(g_current, sizeof(g_current), "alg %d %ldx%ld K %d T %d div %d N %d it %d f32 %d lamW %g tol %g sW %g sH %g", c.alg, (long)c.m, (long)c.n, c.K, c.T, c.div, N, c.it,
              (int)f32, c.lamW, c.tol, c.sW, c.sH);
     nmfx_result r;
     memset(&r, 0, sizeof(r));
     r.W = f32 ? (void *)Wo.data() : (void *)o.W.data(); r.H = f32 ? (void *)Ho.data() : (void *)o.H.data(); r.cost = o.cost.data();
-    std::vector<int32_t> tH((size_t)c.it, 0), tW((size_t)c.it, 0);
+    std::vector<int32_t> tH((size_t)c.it, 0), tW((size_t)c.it * (size_t)(c.T > 1 ? c.T : 1), 0);   // (cnmfsc: one W search per time slice)
     r.tries_H = tH.data(); r.tries_W = tW.data();
     switch (c.alg) {
     case 0: o.rc = nmfx_nmf(&p, &r); break;
     case 1: o.rc = nmfx_cnmf(&p, &r); break;
     case 2: o.rc = nmfx_lnmf(&p, &r); break;
+    case 5: o.rc = nmfx_cnmfsc(&p, &r); break;
     default: o.rc = nmfx_nmfsc(&p, &r); break;
     }
     g_progress.fetch_add(1);
@@ -196,6 +201,38 @@ int main(int argc, char **argv) {
             ++ncalls;
             if (o.rc == NMFX_OK) { ++nbad; printf("BAD: error case %d returned NMFX_OK\n", which); }
             else ++nerr_expected;
+            continue;
+        }
+        if (kind == 'c') {   // cnmfsc (fused passes where the shape allows them, else the default) or a small nmfsc (float64 end to end): no reference run, ASan is the judge
+            Case e = c;
+            const bool conv = ri(0, 3) != 0;
+            e.div = NMFX_DIV_EUCLIDEAN; e.lamW = e.lamH = 0; e.it = ri(1, 4); e.tol = 1e-300;
+            if (conv) {
+                static const int kt[][2] = {{32, 4}, {64, 2}, {32, 3}, {64, 3}, {6, 2}, {20, 3}};
+                const int w = ri(0, 6);
+                e.alg = 5; e.K = kt[w][0]; e.T = kt[w][1]; e.m = 4 * ri(16, 80); e.n = ri(64, 500);
+                e.path = (w < 4 && ri(0, 2)) ? 2 : 0;
+                e.sH = ri(0, 2) ? 0.4 : 0.0; e.sW = 0.0;
+            } else { e.alg = 4; e.T = 1; e.K = ri(2, 40); e.m = ri(16, 120); e.n = ri(64, 300); e.sH = ri(0, 2) ? 0.5 : 0.0; e.sW = e.sH == 0.0 ? 0.4 : 0.0; }
+            std::vector<double> V2((size_t)e.m * e.n), W2((size_t)e.m * e.K * e.T), H2((size_t)e.K * e.n);
+            fill(V2, rng); fill(W2, rng); fill(H2, rng);
+            Out a = run(e, V2, W2, H2, 1, ids0, f32);
+            ++ncalls;
+            if (a.rc != NMFX_OK) { ++nbad; printf("BAD: rc %d (%s) alg %d %ldx%ld K %d T %d path %d\n", (int)a.rc, a.err.c_str(), e.alg, e.m, e.n, e.K, e.T, e.path); continue; }
+            for (double x : a.W) if (!std::isfinite(x)) { ++nbad; printf("BAD: non-finite W: alg %d %ldx%ld K %d T %d path %d\n", e.alg, e.m, e.n, e.K, e.T, e.path); break; }
+            continue;
+        }
+        if (kind == 'r' || kind == 'p') {   // one device: the RCCL branch of the sharded driver with ONE shard / the materialised path, against the plain call
+            Case e = c;
+            if (kind == 'r') e.backend = 2; else { e.alg = 0; e.T = 1; e.div = NMFX_DIV_EUCLIDEAN; e.path = 1; W0.resize((size_t)e.m * e.K); }
+            Out a = run(e, V, W0, H0, 1, ids0, f32);
+            Case e0 = e; e0.backend = 0; e0.path = 0;
+            Out b = run(e0, V, W0, H0, 1, ids0, f32);
+            ncalls += 2;
+            if (a.rc != NMFX_OK || b.rc != NMFX_OK) { ++nbad; printf("BAD: rc %d / %d (%s) kind %c alg %d %ldx%ld K %d T %d div %d\n", (int)a.rc, (int)b.rc, a.err.c_str(), kind, e.alg, e.m, e.n, e.K, e.T, e.div); continue; }
+            const double eW = rel(a.W, b.W), eH = rel(a.H, b.H);
+            worst = std::max(worst, std::max(eW, eH));
+            if (!(eW < 2e-5 && eH < 2e-5) || a.cost_len != b.cost_len) { ++nbad; printf("BAD: kind %c vs the plain call W %.3g H %.3g len %d/%d alg %d %ldx%ld K %d T %d div %d\n", kind, eW, eH, a.cost_len, b.cost_len, e.alg, e.m, e.n, e.K, e.T, e.div); }
             continue;
         }
         const int N = kind == '1' ? 1 : c.N;
