@@ -387,7 +387,8 @@ __device__ void w_update64_body(const WUpdateParams &p, double *red) {
     const float *pp = p.P ? p.P + p.m * c : nullptr;
     const double *pp64 = p.P64 ? p.P64 + p.m * c : nullptr;
     const double pv = p.Pvec ? p.Pvec[c] : (p.Pvecf ? (double)p.Pvecf[c] : 0.0);
-    auto nat = [&](long i) { const long ch = i / cr; return (double)p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
+    const float *ncol = p.N + p.m * c;   // (one chunk: column c of N is contiguous -- and the 64-bit division below is most of a sweep's instructions)
+    auto nat = [&](long i) { if (nch == 1) return (double)ncol[i]; const long ch = i / cr; return (double)p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
     auto pat = [&](long i) { return pp64 ? pp64[i] : (pp ? (double)pp[i] : pv); };
     const bool fixed = p.fixW && p.fixW[k];
     const bool plain = p.rule == 1;   // lnmf.m:69
