@@ -21,7 +21,7 @@ R4_18 = [(493, 383, 640, 10, 0.0883035381731506, 0.0631358004042333, 1), (366, 5
 @pytest.mark.parametrize("planted", [False, True])
 @pytest.mark.parametrize("m,n,K,iters,lW,lH,shards", R4_18)
 def test_overcomplete_euclidean_h_fixed_wide(gpu_lib, m, n, K, iters, lW, lH, shards, planted):
-    """K > 256: column blocks of the stationary kernel (engine path 6) and, with nmfx_path = 1, the materialised path"""
+    """K > 256: column blocks of the stationary kernel (engine path 6), one GPU and ragged shards"""
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K, planted=planted)
     cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300, H_fixed=True)
@@ -30,6 +30,25 @@ def test_overcomplete_euclidean_h_fixed_wide(gpu_lib, m, n, K, iters, lW, lH, sh
     ref = O.nmf(V, K, cfg)
     extra = dict(nmfx_gpus=[0] * shards) if shards > 1 else {}
     got = gpu_lib.nmf(V, K, dict(cfg, **extra))
+    e = record_err(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
+    assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
+
+
+# path 1 (materialised V_hat): the cases of profiles/r5_05_fuzz_campaign_fixed_factor.log that were at 1.0e-5 ... 3.0e-5 on W while its V_hat*H' was an fp32 product of the
+# fp32 V_hat (m, n, K, iterations, planted, W_sparsity, H_sparsity); since round 5 that term is W*(H*H') in float64 there too (engine.p1gram)
+R5_05_PATH1 = [(325, 223, 320, 14, True, 0.0, 0.0), (315, 186, 320, 12, True, 0.005228251617938995, 0.009358852346354208), (298, 211, 320, 11, True, 0.0, 0.0),
+               (352, 400, 320, 14, True, 0.017432133862210177, 0.009908722964069971), (266, 240, 320, 13, False, 0.0, 0.0), (177, 720, 320, 12, True, 0.0, 0.0)]
+
+
+@pytest.mark.parametrize("m,n,K,iters,planted,lW,lH", R5_05_PATH1)
+def test_overcomplete_euclidean_h_fixed_materialised_path(gpu_lib, m, n, K, iters, planted, lW, lH):
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, planted=planted)
+    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300, H_fixed=True)
+    if lW:
+        cfg["W_sparsity"], cfg["H_sparsity"] = lW, lH
+    ref = O.nmf(V, K, cfg)
+    got = gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1))
     e = record_err(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
     assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
 
