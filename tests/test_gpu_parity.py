@@ -293,6 +293,24 @@ def test_cnmf_ab_divergence(gpu_lib, alpha, beta):
     _check(gpu_lib.cnmf(V, 5, 3, cfg), O.cnmf(V, 5, 3, cfg))
 
 
+@pytest.mark.parametrize("alg,div,ab,m,n,K,T", [("cnmf", "is", None, 192, 512, 64, 8), ("cnmf", "is", None, 128, 400, 32, 4), ("cnmf", "ab", (0.5, 1.5), 128, 400, 32, 4),
+                                                ("cnmf", "ab", (2.0, -0.5), 192, 512, 64, 8), ("nmf", "is", None, 200, 600, 320, 1), ("nmf", "is", None, 256, 700, 512, 1),
+                                                ("nmf", "ab", (0.5, 1.5), 200, 600, 320, 1), ("nmf", "ab", (1.5, -1.5), 256, 700, 512, 1)])
+def test_is_and_alpha_beta_where_v_hat_is_still_materialised(gpu_lib, alg, div, ab, m, n, K, T):
+    """The two families that still run with V_hat in HBM (the TT kernels have no room for a second product, and beyond K = 256 both element maps
+    would have to be stored): IS / alpha-beta cnmf at the instantiated (K, T) pairs the other divergences use fused (cnmf.m:179-194,227-231) and IS / alpha-beta nmf
+    with K > 256 (nmf.m:154-164,185-195) -- against the oracle at the contract, sparsity terms on."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=(T if alg == "cnmf" else None))
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    if ab:
+        cfg["alpha"], cfg["beta"] = ab
+    if alg == "cnmf":
+        _check(gpu_lib.cnmf(V, K, T, cfg), O.cnmf(V, K, T, cfg))
+    else:
+        _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg))
+
+
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
 @pytest.mark.parametrize("K", [64, 96])
 def test_nmfsc_fused_path_matches_oracle(gpu_lib, sW, sH, K):
