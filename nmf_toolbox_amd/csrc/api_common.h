@@ -136,6 +136,9 @@ struct nmfx_engine {
     // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
     // H-step numerator as ONE (KT x n x m) GEMM Q = W_flat' * V followed by the shift-sum over t
     bool fusedT, hpad_valid;
+    bool fusedT_dual;         // IS / alpha-beta cnmf (unsharded, the common (K, T) pairs): an S pass stores BOTH element maps' values (A in the V_hat buffer, B in Vhat2)
+                              // and yields the cost of the state it starts from; the numerator passes and the H-step products contract those; V_hat itself is never formed
+    float *Vhat2;
     bool fusedT_kl;           // KL cnmf on the fused passes: an S pass stores R = V./V_hat (in the V_hat buffer) and yields the cost of the state it
                               // started from (lagged, like the nmf fused path); the numerator passes then read R instead of V
     double *sumV_g, *colV_g;  // its closed-form cost term sum(V)

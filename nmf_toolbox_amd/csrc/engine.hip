@@ -164,6 +164,16 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->sumV_g = c.take<double>(1);
         e->colV_g = c.take<double>(e->n);
     }
+    if (e->fusedT_dual) {
+        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
+        const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        e->Vhat2 = c.take<float>(mn);
+        e->Valpha = (e->div == NMFX_DIV_AB && e->alpha != 1.0) ? c.take<float>(mn) : nullptr;
+        e->sumVab = c.take<double>(1);
+        e->colV = c.take<double>(e->n);
+    }
     if (e->klw) {
         e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * e->m * 256) : nullptr;
         const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
@@ -280,11 +290,15 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // columns, whose terms the shift-sum of the H step needs: cnmf.m:219)
     e->fusedT_kl = !e->fused && e->algo == 1 && e->div == NMFX_DIV_KL && e->T > 1 && fused_supported_T(e->K, e->T) && e->m >= 64 && e->n >= 64 &&
                    (e->hL == 0 || e->hL >= e->T - 1) && d->path != 1;
-    if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl) {
+    // IS / alpha-beta (alpha != 0) cnmf, unsharded, the common (K, T) pairs: S pass with both element maps stored (functors 11 / 13 in the cost-only form),
+    // numerator passes on either buffer, the H-step products as two well-shaped GEMMs on them (cnmf.m:179-194,227-231 without V_hat)
+    e->fusedT_dual = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->T > 1 && fused_supported_T_dual(e->K, e->T) &&
+                     e->m >= 64 && e->n >= 64 && e->K % 4 == 0 && e->m % 4 == 0 && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && d->path != 1;
+    if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl && !e->fusedT_dual) {
         set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or kl, T > 1, an instantiated (K, T) pair)");
         return NMFX_ERR_UNSUPPORTED;
     }
-    if (e->fusedT || e->fusedT_kl) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
+    if (e->fusedT || e->fusedT_kl || e->fusedT_dual) e->nsplit_T = fused_split((e->m + 127) / 128, e->n, e->KT, &e->cps_T);
     e->klw = !e->fused && e->algo != 1 && e->T == 1 && e->div == NMFX_DIV_KL && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
              e->m >= 64 && e->n >= 64 && d->path != 1;
     e->eucw = e->gram && (e->algo == 0 || e->algo == 3) && e->T == 1 && e->div == NMFX_DIV_EUCLIDEAN && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
@@ -444,7 +458,7 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
     }
     double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
     if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
-    if (e->fused && e->dual) {
+    if ((e->fused && e->dual) || e->fusedT_dual) {
         // fused IS: partials hold sum(V./V_hat - log(V./V_hat)); nmf.m:212 subtracts 1 per element.  Fused alpha-beta: partials hold
         // sum(V.^a.*V_hat.^b - b/(a+b)*V_hat.^(a+b)); nmf.m:214 subtracts (a*sum(V.^(a+b)) + b*m*n) / (a+b) inside the scaled sum
         const double cnt = (double)e->m * (double)e->n;
@@ -605,7 +619,7 @@ nmfx_status fused_wpass(nmfx_engine *e, bool do_g2) {
 
 // cnmf fused passes (fused_kernel TT > 1) over the local columns: do_g2 -> N_all = V * H_stack' into `out` (m x KT), else the residual cost
 // partials of the CURRENT (W, H).  H's T-1 columns to the left of the shard are its halo, or zeros (Hpad) on the first / only shard.
-enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3 };
+enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3, FT_S_DUAL = 4, FT_COST_DUAL = 5 };   // 4 / 5: IS / alpha-beta, both element maps stored / cost only
 nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-1 zero columns (lag-form Gram products only)]
     if (e->hpad_valid) return NMFX_OK;      // H changed since the last pass (init, H step)
     Scope s(e, TAG_SMALL);
@@ -613,7 +627,7 @@ nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-
     e->hpad_valid = true;
     return NMFX_OK;
 }
-nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if = nullptr) {
+nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if = nullptr, const float *Dnum = nullptr) {   // Dnum: the numerator pass's data operand (default: V, KL: R)
     const bool do_g2 = mode == FT_NUM;
     const float *Hy = e->H;
     if (e->hL < e->T - 1) {
@@ -625,14 +639,20 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if 
     f.X = e->W; f.xs_r = 1; f.xs_k = e->m; f.xs_t = e->m * (long)e->K; f.T = e->T;
     f.Y = Hy; f.ldd = e->m; f.R = e->m; f.Cn = e->n; f.K = e->KT;
     f.D = (mode == FT_NUM && e->fusedT_kl) ? e->Vhat : e->V;      // KL: the numerators contract R = V./V_hat (left in the V_hat buffer by the S pass)
+    if (mode == FT_NUM && Dnum) f.D = Dnum;
     if (mode == FT_S_KL) f.Rout = e->Vhat;
+    if (mode == FT_S_DUAL || mode == FT_COST_DUAL) {   // A = V./S.^2 | V.^a.*S.^(b-1) (+ the cost terms), B = 1./S | S.^(a+b-1)
+        f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = 1.0f;
+        if (e->Valpha) f.D = e->Valpha;
+        if (mode == FT_S_DUAL) { f.Rout = e->Vhat; f.Rout2 = e->Vhat2; }
+    }
     f.c_per_split = e->cps_T;
     const long mKT = e->m * (long)e->KT;
     f.out = e->nsplit_T == 1 ? out : e->slabsT;
     f.slab_stride = mKT; f.os_r = 1; f.os_k = e->m; f.os_t = e->m * (long)e->K;
     f.cost_partials = do_g2 ? nullptr : e->cost_partials;
     f.run_if = run_if;
-    const int func = mode == FT_NUM ? 0 : (mode == FT_COST_EUC ? 1 : 3);
+    const int func = mode == FT_NUM ? 0 : (mode == FT_COST_EUC ? 1 : ((mode == FT_S_DUAL || mode == FT_COST_DUAL) ? (e->div == NMFX_DIV_IS ? 11 : 13) : 3));
     {
         Scope s(e, run_if ? TAG_SMALL : (do_g2 ? TAG_FUSED_W : TAG_FUSED_COST));
         TRY(launch_fused(e->st, f, e->nsplit_T, true, func, do_g2, 0));
@@ -952,7 +972,7 @@ nmfx_status nmfx_engine_master_ptrs(nmfx_engine *e, double **W64_dev, double **H
 }
 // 0: the cost of iteration i is ready after hstep(i); 1: after wstep_partial(i+1); 2: after wstep_finish(i+1) (read it there; engines of kind 2
 // may also deliver it at point 1 -- reading at point 2 is always right for them)
-int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->klw) ? 1 : 0); }
+int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->fusedT_dual || e->klw) ? 1 : 0); }
 
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat.
 // The normalisation runs on the float64 masters: one fp32 rounding of the INITIAL state is a perturbation the iteration carries to the end, and problems that
@@ -1029,6 +1049,16 @@ static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const doub
         if (e->klw_vt) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
         return sum_vec(e->st, e->colV, e->n, e->sumV);
     }
+    if (e->fusedT_dual) {          // nor here: the constants of the alpha-beta cost and V.^alpha, the S pass's data operand, once
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = false;
+        if (e->div == NMFX_DIV_AB) {
+            TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
+            TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
+            if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+        }
+        return NMFX_OK;
+    }
     if (e->fusedT_kl) {            // nor here: sum(V) for the closed-form part of the KL cost, once
         Scope s(e, TAG_SMALL);
         e->cost_valid = false;
@@ -1104,6 +1134,12 @@ nmfx_status nmfx_engine_packed_chunk(nmfx_engine *e, int32_t chunk, int32_t nchu
 
 static nmfx_status generic_wstep_partial(nmfx_engine *e) {
     const size_t mKT = (size_t)e->m * e->KT;
+    if (e->fusedT_dual) {   // S pass: both element maps' values into the two m x n buffers + the (lagged) cost of the state this iteration starts from
+        TRY(fusedT_pass(e, e->all_fixW ? FT_COST_DUAL : FT_S_DUAL, nullptr));
+        Scope s(e, TAG_SMALL);
+        TRY(cost_from_partials(e, e->n_cost_used));
+        e->cost_valid = true;
+    }
     if (e->fusedT_kl) {   // S pass: R = V./V_hat into the V_hat buffer + the (lagged) cost of the state this iteration starts from
         TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
         TRY(fusedT_kl_cost(e));
@@ -1121,6 +1157,10 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
     if (e->all_fixW) return NMFX_OK;
     OpView a{}, b{};
     num_view(e, a);
+    if (e->fusedT_dual) {   // [N | P] = [A | B] * H_stack': two numerator passes, no first product
+        TRY(fusedT_pass(e, FT_NUM, e->packed, nullptr, e->Vhat));
+        return fusedT_pass(e, FT_NUM, e->packed + mKT, nullptr, e->Vhat2);
+    }
     if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
     else if (e->klw) TRY(klw_num_pass(e, e->packed, e->Vhat));
     else if (e->eucw) TRY(klw_num_pass(e, e->packed, e->V));
@@ -1254,7 +1294,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr, 0, e->W64));
         e->cost_valid = false;
     }
-    if (e->gram || e->fusedT_kl || e->klw) return NMFX_OK;
+    if (e->gram || e->fusedT_kl || e->fusedT_dual || e->klw) return NMFX_OK;
     return recon(e, false);
 }
 
@@ -1396,6 +1436,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
         num_view(e, a);
         bool fuse_hupd = false;
         if (e->lagram) TRY(ensure_hpad(e));   // the denominator below reads the padded copy of the CURRENT H
+        if (e->fusedT_dual) {   // both element maps' values with the W just updated
+            TRY(fusedT_pass(e, FT_S_DUAL, nullptr));
+            a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        }
         if (e->fusedT_kl) {   // R = V./V_hat with the W just updated
             TRY(fusedT_pass(e, FT_S_KL, nullptr));
             a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -1488,6 +1532,19 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
                 }
             }
             }
+        } else if (e->fusedT_dual) {   // sum_t W_t' * lshift_t(B) as Q = W_flat' * B + a shift-sum, like the numerator above
+            {
+                Scope s(e, TAG_HDEN);
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.M = e->KT; g.N = e->nvalid; g.Kc = e->m;
+                g.A = OpView{e->W, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.B = OpView{e->Vhat2, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+                g.C = e->Qbuf; g.ldc = e->KT; g.epi = EPI_STORE; g.splitk = 1;
+                TRY(gemm_auto(e->st, g, e->gemm_scratch, e->gemm_scratch_bytes));
+            }
+            Scope s(e, TAG_SMALL);
+            TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gp));
         } else if (div_has_matrix_den(e->div)) {
             den_view(e, b);
             TRY(wt_times_x(e, b, e->Gp, TAG_HDEN));
@@ -1514,7 +1571,7 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    if (e->fusedT_kl || e->klw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT_kl || e->fusedT_dual || e->klw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
     if ((e->fusedT || e->eucw) && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
     if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
@@ -1533,6 +1590,12 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     if (e->cost_valid) return NMFX_OK;
     if (e->fused) return fused_wpass(e, false);
     if (e->fusedT_kl) { TRY(fusedT_pass(e, FT_COST_KL, nullptr)); return fusedT_kl_cost(e); }
+    if (e->fusedT_dual) {
+        TRY(fusedT_pass(e, FT_COST_DUAL, nullptr));
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = true;
+        return cost_from_partials(e, e->n_cost_used);
+    }
     if (e->klw) { TRY(klw_s_pass(e, false, true)); return klw_cost(e); }
     if ((e->fusedT || e->eucw) && e->gram_cost) {
         if (e->eucw) TRY(eucw_cost_pass(e, nullptr));
@@ -1545,7 +1608,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : (e->fusedT_kl ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->eucw ? 6 : (e->gram ? 2 : 0))))); }   // 6 euclidean with K > 256 in column blocks, 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : ((e->fusedT_kl || e->fusedT_dual) ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->eucw ? 6 : (e->gram ? 2 : 0))))); }   // 6 euclidean with K > 256 in column blocks, 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {
@@ -1622,7 +1685,7 @@ nmfx_status nmfx_engine_tag_work(nmfx_engine *e, int32_t tag, double *flops, dou
     // fused passes: V streamed once; both contractions counted when both are issued (KL; euclidean W step with cost)
     case TAG_FUSED_W: {   // one launch covers m / w_chunks rows when the partial is row-chunked
         const double ch = e->w_chunks > 1 ? (double)e->w_chunks : 1.0;
-        if (e->fusedT || e->fusedT_kl || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
+        if (e->fusedT || e->fusedT_kl || e->fusedT_dual || e->klw || e->eucw) { *flops = f; *bytes = 4.0 * (m * n + m * KT + e->K * n); return NMFX_OK; }   // cnmf numerator pass: one contraction (klw: the launches of all column blocks together)
         if (e->dualz) { *flops = 1.5 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // alpha == 0: functor 17 (S + one contraction) and functor 0 (one contraction), averaged over the two launches
         if (e->dual2 && e->Vhat) { *flops = 1.5 * f; *bytes = 4.0 * (2.0 * m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch, averaged over the two of a W step: S + one contraction (+ the m x n store), then one contraction
         if (e->dual2) { *flops = 2.0 * f; *bytes = 4.0 * (m * n + 2.0 * m * KT + e->K * n); return NMFX_OK; }   // per launch (two per W step): S + one contraction

@@ -35,6 +35,13 @@ bool fused_supported_T(int Kh, int T) {
     return false;
 }
 
+// ... and the pairs whose S pass also exists in the IS / alpha-beta form that stores both element maps (functors 11 / 13, cost-only form; fused_cnmf_{a,b,c}.hip)
+bool fused_supported_T_dual(int Kh, int T) {
+    static const int ok[][2] = {{64, 8}, {64, 4}, {32, 8}, {32, 16}, {64, 2}, {32, 4}, {128, 2}, {128, 4}};
+    for (const auto &c : ok) if (c[0] == Kh && c[1] == T) return true;
+    return false;
+}
+
 // one translation unit per K group and per extent kind (fused_k*.hip, fused_rag_k*.hip): the instantiations compile in parallel
 #define NMFX_DECL(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi)
 NMFX_DECL(launch_fused_k32_96); NMFX_DECL(launch_fused_k128_192); NMFX_DECL(launch_fused_k224_256);

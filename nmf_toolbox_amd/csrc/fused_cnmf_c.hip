@@ -4,10 +4,10 @@
 namespace nmfx {
 
 nmfx_status launch_fused_cnmf_c(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2) {
-    if (p.K == 128 && p.T == 2) return launch_T<64, 2>(st, p, nsplit, func, do_g2);
-    if (p.K == 128 && p.T == 4) return launch_T<32, 4>(st, p, nsplit, func, do_g2);
-    if (p.K == 256 && p.T == 2) return launch_T<128, 2>(st, p, nsplit, func, do_g2);
-    if (p.K == 512 && p.T == 4) return launch_T<128, 4>(st, p, nsplit, func, do_g2);
+    if (p.K == 128 && p.T == 2) return launch_T<64, 2, true>(st, p, nsplit, func, do_g2);
+    if (p.K == 128 && p.T == 4) return launch_T<32, 4, true>(st, p, nsplit, func, do_g2);
+    if (p.K == 256 && p.T == 2) return launch_T<128, 2, true>(st, p, nsplit, func, do_g2);
+    if (p.K == 512 && p.T == 4) return launch_T<128, 4, true>(st, p, nsplit, func, do_g2);
     set_error("launch_fused_T: (K = %d, T = %d) not in this group", p.K, p.T);
     return NMFX_ERR_UNSUPPORTED;
 }

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
     constexpr int EF = FUNC == 15 ? 11 : (FUNC == 16 ? 13 : FUNC);                   // the element map to run
     static_assert(!STB || (DO_G2 && D_RC && EPI == 0 && TT == 1), "functors 15 / 16: W-step form with the second product");
+    // functors 11 / 13 in the cost-only form: BOTH element maps' values go to HBM (p.Rout the first, p.Rout2 the second) -- the S pass of IS / alpha-beta cnmf, whose
+    // numerator passes (functor 0 on either buffer) have no room for a first product next to K*T = 512 accumulators
+    constexpr bool ST2 = (EF == 11 || EF == 13) && !DO_G2 && D_RC;
+    constexpr bool BQ = STB || ST2;                                                  // the second map's values of a tile are kept in bq[] on their way out
     // first-product-only passes wait for the next tile's DMA rows right behind P2 -- they went out during P1 -- instead of at the next tile top, where
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
         f32x16 sacc2[DUAL ? 2 : 1];                           // the second map's tile (B)
-        float bq[STB ? 2 : 1][STB ? 16 : 1];                  // the second map's values of this tile, on their way to p.Rout
+        float bq[BQ ? 2 : 1][BQ ? 16 : 1];                    // the second map's values of this tile, on their way to p.Rout (ST2: p.Rout2)
         const __amdgpu_buffer_rsrc_t rs_b = STB ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000)
                                                 : d_srd_fixed;
         float tc = 0.0f;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             } else if (EF == 11) {                            // IS, numerators only: A = V./S.^2, cost terms q - ln(q) (functor 4 without its B tile)
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) eq[sl] = v * er[sl];
-                if (STB && u == 2) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = 1./S
+                if (BQ && u == 2) bq[BQ ? jb : 0][BQ ? reg : 0] = er[sl];           // B = 1./S
                 if (u == 3) sacc[jb][reg] = live ? eq[sl] * er[sl] : 0.0f;
                 if (u == 4) er[sl] = __builtin_amdgcn_logf(eq[sl]);                  // log2(q)
                 if (u == 5) tc = live ? tc + eq[sl] : tc;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 2) eq[sl] = __builtin_amdgcn_exp2f(eq[sl]);                 // S.^(b-1)
                 if (u == 3) er[sl] = __builtin_amdgcn_exp2f(ab_e2 * er[sl]);         // S.^(a+b-1)
                 if (u == 4) { eq[sl] = v * eq[sl]; sacc[jb][reg] = live ? eq[sl] : 0.0f; }
-                if (STB && u == 5) bq[STB ? jb : 0][STB ? reg : 0] = er[sl];         // B = S.^(a+b-1)
+                if (BQ && u == 5) bq[BQ ? jb : 0][BQ ? reg : 0] = er[sl];           // B = S.^(a+b-1)
                 if (u == 6) eq[sl] = fmaf(-ab_kappa, er[sl], eq[sl]);
                 if (u == 7) { tc = live ? fmaf(es[sl], eq[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
             } else if (FUNC == 17) {                          // alpha-beta, dual form (alpha == 0): A = S.^beta ./ V
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
-            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1 || ST2) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
 #pragma unroll
@@ -416,6 +420,17 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                         const int jb = e >> 4, reg = e & 15;
                         const float rv = sacc[jb][reg];   // (a bit_cast applied to the vector element itself reads element 0)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rv), rs, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0);
+                    }
+                }
+            }
+            if (ST2 && p.Rout2) {   // wave-uniform: the second map's values of this tile (masked like the first: a streamed index past the end stores nothing real)
+                const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout2 + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
+                if (row_ok) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int jb = e >> 4, reg = e & 15;
+                        const float bv = bq[BQ ? jb : 0][BQ ? reg : 0];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bv), rs2, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0);
                     }
                 }
             }

@@ -123,6 +123,7 @@ struct FusedParams {
     long c_per_split;     // streamed rows per grid.y slice (multiple of 64)
     int K;
     float *out;           // EPI 0: O(k, r) -> out[split*slab_stride + r*os_r + k*os_k]
+    float *Rout2;         // func 11 / 13, cost-only pass (cnmf, IS / alpha-beta): the SECOND element map's values (1./S, S.^(a+b-1)) next to the first one's in Rout
     float *Rout;          // func 2 / 3, cost-only pass, W-step form: also store R = V./S (m x n, ld = ldd); nullptr = don't.  func 7: the partial S; func 8: R
     const float *Sin;     // func 7 / 8: partial S (m x n, ld = ldd) of the column blocks contracted by earlier launches, or nullptr (first block)
     float *out2;          // func 4 / 5 (dual-map divergences), EPI 0: the second contraction (denominators), same indexing
@@ -142,6 +143,7 @@ struct FusedParams {
     const int *run_if;    // when set: every workgroup returns at once unless *run_if != 0 (a device-side decision, no host round trip)
 };
 bool fused_supported(int K);
+bool fused_supported_T_dual(int Kh, int T);   // ... of the IS / alpha-beta S pass (both element maps stored)
 bool fused_supported_T(int Kh, int T);   // cnmf: instantiated (Kh, T) pairs of the W-step-form kernels (numerator pass, cost pass)
 // func: 0 R=V (no S) | 1 R=V + euclidean cost from S | 2 R=V./S (KL) | 3 R=V./S + KL cost | 4 IS | 5 alpha-beta (K <= 192) | 6 R=S-V + euclidean cost (do_g2, slabs out)
 //       | 7 / 8 (do_g2=false): S over column blocks of a wide factor, see fused_kernel.h;  do_g2=false: cost-only pass

@@ -293,22 +293,57 @@ def test_cnmf_ab_divergence(gpu_lib, alpha, beta):
     _check(gpu_lib.cnmf(V, 5, 3, cfg), O.cnmf(V, 5, 3, cfg))
 
 
-@pytest.mark.parametrize("alg,div,ab,m,n,K,T", [("cnmf", "is", None, 192, 512, 64, 8), ("cnmf", "is", None, 128, 400, 32, 4), ("cnmf", "ab", (0.5, 1.5), 128, 400, 32, 4),
-                                                ("cnmf", "ab", (2.0, -0.5), 192, 512, 64, 8), ("nmf", "is", None, 200, 600, 320, 1), ("nmf", "is", None, 256, 700, 512, 1),
-                                                ("nmf", "ab", (0.5, 1.5), 200, 600, 320, 1), ("nmf", "ab", (1.5, -1.5), 256, 700, 512, 1)])
-def test_is_and_alpha_beta_where_v_hat_is_still_materialised(gpu_lib, alg, div, ab, m, n, K, T):
-    """The two families that still run with V_hat in HBM (the TT kernels have no room for a second product, and beyond K = 256 both element maps
-    would have to be stored): IS / alpha-beta cnmf at the instantiated (K, T) pairs the other divergences use fused (cnmf.m:179-194,227-231) and IS / alpha-beta nmf
-    with K > 256 (nmf.m:154-164,185-195) -- against the oracle at the contract, sparsity terms on."""
+@pytest.mark.parametrize("div,ab,m,n,K,T", [("is", None, 192, 512, 64, 8), ("is", None, 128, 400, 32, 4), ("ab", (0.5, 1.5), 128, 400, 32, 4), ("ab", (2.0, -0.5), 192, 512, 64, 8),
+                                            ("ab", (1.0, 0.5), 132, 777, 64, 2), ("is", None, 516, 1031, 32, 8), ("ab", (1.5, -1.5), 256, 300, 128, 2), ("is", None, 64, 2050, 32, 16),
+                                            ("is", None, 260, 640, 64, 4), ("ab", (0.5, 0.5), 320, 515, 128, 4)])
+def test_cnmf_is_and_alpha_beta_on_the_fused_passes(gpu_lib, div, ab, m, n, K, T):
+    """IS / alpha-beta cnmf (cnmf.m:179-194,227-231) without V_hat, round 5 (engine.fusedT_dual): an S pass on the cnmf kernel stores BOTH element maps' values
+    (functors 11 / 13 in the cost-only form: A = V./S.^2 | V.^a.*S.^(b-1) with the cost terms, B = 1./S | S.^(a+b-1)), two numerator passes contract them with
+    H_stack', the H step two W_flat'*(.) GEMMs + shift-sums.  All eight (K, T) pairs it is instantiated for, ragged m and n, sparsity terms on: against the oracle at the
+    contract, against the materialised path (nmfx_path = 1), and by name (nmfx_path = 2 must not fall back)."""
     from oracle import nmf_oracle as O
-    V, W0, H0 = synth(m, n, K, T=(T if alg == "cnmf" else None))
+    V, W0, H0 = synth(m, n, K, T=T)
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
     if ab:
         cfg["alpha"], cfg["beta"] = ab
-    if alg == "cnmf":
-        _check(gpu_lib.cnmf(V, K, T, cfg), O.cnmf(V, K, T, cfg))
-    else:
-        _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg))
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, cfg)
+    _check(got, ref)
+    named = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
+    assert np.array_equal(named[0], got[0]) and np.array_equal(named[1], got[1]) and np.array_equal(named[2], got[2])   # the default IS that path
+    _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1)), ref)
+
+
+def test_cnmf_is_on_the_fused_passes_fixed_factors_sources_and_stop(gpu_lib):
+    """the same path with what the engine's generic update kernels add around it: two sources with one fixed W / one fixed H, all of W fixed (the S pass is then
+    cost-only), all of H fixed, and the stop rule with the cost lagging one pass"""
+    from oracle import nmf_oracle as O
+    m, n, K, T = 192, 640, 64, 4
+    V, W0, H0 = synth(m, n, K, T=T)
+    base = dict(divergence="is", maxiter=5, tolerance=1e-12)
+    for extra in (dict(W_sparsity=[0.05, 0.0], H_fixed=[False, True]), dict(W_fixed=[True, False], H_sparsity=[0.0, 0.03])):
+        cfg = dict(base, W_init=[W0[:, :24], W0[:, 24:]], H_init=[H0[:24], H0[24:]], **extra)
+        _check(gpu_lib.cnmf(V, [24, 40], T, dict(cfg, nmfx_path=2)), O.cnmf(V, [24, 40], T, cfg))
+    for fixed in ("W_fixed", "H_fixed"):
+        cfg = dict(base, W_init=W0, H_init=H0, **{fixed: True})
+        _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2)), O.cnmf(V, K, T, cfg))
+    cfg = dict(divergence="is", W_init=W0, H_init=H0, maxiter=200, tolerance=100.0)
+    got, ref = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2)), O.cnmf(V, K, T, cfg)
+    assert len(ref[2]) < 200
+    _check_stop(got[2], ref[2], 100.0)
+    if len(got[2]) == len(ref[2]):
+        assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[1], ref[1]) <= TOL
+
+
+@pytest.mark.parametrize("div,ab,m,n,K", [("is", None, 200, 600, 320), ("is", None, 256, 700, 512), ("ab", (0.5, 1.5), 200, 600, 320), ("ab", (1.5, -1.5), 256, 700, 512)])
+def test_nmf_is_and_alpha_beta_above_256_materialised(gpu_lib, div, ab, m, n, K):
+    """the one family that still runs with V_hat in HBM: IS / alpha-beta nmf with K > 256 (nmf.m:154-164,185-195) -- against the oracle at the contract"""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    if ab:
+        cfg["alpha"], cfg["beta"] = ab
+    _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg))
 
 
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
@@ -1000,6 +1035,6 @@ def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
     if len(got[2]) == len(ref[2]):
         assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[1], ref[1]) <= TOL
     with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.cnmf(V, 64, 4, dict(divergence="is", W_init=W0, H_init=H0, maxiter=1, nmfx_path=2))     # the fused passes are euclidean / kl
+        gpu_lib.cnmf(V[:, :300], 32, 3, dict(divergence="is", maxiter=1, nmfx_path=2))                  # IS / alpha-beta on the fused passes: the eight common (K, T) pairs only
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.cnmf(V[:, :300], 100, 7, dict(maxiter=1, nmfx_path=2))                                  # no pair with T = 7 reaches K = 100, padded or not
