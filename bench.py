@@ -597,8 +597,8 @@ def main():
                        "name": args.workload, "m": m, "n": n, "K": K, "T": T, "divergence": div, "cost_every_iteration": True,
                        "path": {1: "fused kernels (V_hat never materialised)", 2: "Gram form on the generic GEMM (V_hat never materialised)",
                                 3: "fused cnmf passes, shift-sum in LDS + Gram denominators (V_hat never materialised)",
-                                4: "fused cnmf passes, shift-sum in LDS; R = V./V_hat in HBM, V_hat never",
-                                5: "KL with K > 256: S = W*H over column blocks on the stationary kernel, R = V./S in HBM, V_hat never",
+                                4: "fused cnmf passes, shift-sum in LDS; the element maps' values (KL: R = V./V_hat; IS / alpha-beta: both maps) in HBM, V_hat never",
+                                5: "K > 256 (KL, IS, alpha-beta): S = W*H over column blocks on the stationary kernel, the element maps' values in HBM, V_hat never",
                                 6: "euclidean with K > 256: numerators block by block on the stationary kernel, Gram-form cost, V_hat never",
                                 0: "generic GEMM (materialised V_hat)"}[path_kind]},
             "effective_tflops": round(f_alg * its / 1e12, 3),

@@ -136,6 +136,8 @@ struct nmfx_engine {
     // cnmf euclidean on the register-stationary kernels (fused_kernel TT > 1): numerator and cost passes with the shift-sum in LDS,
     // H-step numerator as ONE (KT x n x m) GEMM Q = W_flat' * V followed by the shift-sum over t
     bool fusedT, hpad_valid;
+    bool dualw;               // IS / alpha-beta nmf with K > 256 (unsharded): klw's column-block chain for S, whose last block stores both element maps' values (functors
+                              // 19 / 20; A in the V_hat buffer, B in Vhat2); numerator passes per column block on either; the H-step products as two GEMMs
     bool fusedT_dual;         // IS / alpha-beta cnmf (unsharded, the common (K, T) pairs): an S pass stores BOTH element maps' values (A in the V_hat buffer, B in Vhat2)
                               // and yields the cost of the state it starts from; the numerator passes and the H-step products contract those; V_hat itself is never formed
     float *Vhat2;

@@ -188,6 +188,15 @@ Layout layout(nmfx_engine *e, void *ws) {
             if (needh > e->n_cost_partials) { e->n_cost_partials = needh; e->cost_partials = c.take<double>(needh); }
         }
     }
+    if (e->dualw) {
+        e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * e->m * 256) : nullptr;
+        const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
+        if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
+        e->Vhat2 = c.take<float>(mn);
+        e->Valpha = (e->div == NMFX_DIV_AB && e->alpha != 1.0) ? c.take<float>(mn) : nullptr;
+        e->sumVab = c.take<double>(1);
+        e->colV = c.take<double>(e->n);
+    }
     if (e->eucw) {
         e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * e->m * 256) : nullptr;
         e->VT = c.take<float>((size_t)e->m * e->n);
@@ -304,7 +313,9 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     e->eucw = e->gram && (e->algo == 0 || e->algo == 3) && e->T == 1 && e->div == NMFX_DIV_EUCLIDEAN && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 && e->hL == 0 && e->hR == 0 &&
               e->m >= 64 && e->n >= 64 && !no_vt && room_vt;
     if (e->eucw && !exact_cost_env) e->gram_cost = true;
-    if (e->klw || e->eucw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
+    e->dualw = !e->fused && e->algo == 0 && e->T == 1 && (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->K > 256 && e->K % 32 == 0 && e->K <= 8 * 256 &&
+               e->hL == 0 && e->hR == 0 && e->nvalid == e->n && e->m >= 64 && e->n >= 64 && d->path != 1;
+    if (e->klw || e->eucw || e->dualw) {   // column blocks: as few as fit 256, as even as multiples of 32 allow (320 = 160 + 160, 288 = 160 + 128, 512 = 256 + 256)
         const int units = e->K / 32;
         e->klw_nb = (e->K + 255) / 256;
         for (int b = 0, k0 = 0; b < e->klw_nb; ++b) {
@@ -458,7 +469,7 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
     }
     double scale = mdiv(e) == NMFX_DIV_EUCLIDEAN ? 0.5 : 1.0;
     if (mdiv(e) == NMFX_DIV_AB) scale = -1.0 / (e->alpha * e->beta);   // nmf.m:214
-    if ((e->fused && e->dual) || e->fusedT_dual) {
+    if ((e->fused && e->dual) || e->fusedT_dual || e->dualw) {
         // fused IS: partials hold sum(V./V_hat - log(V./V_hat)); nmf.m:212 subtracts 1 per element.  Fused alpha-beta: partials hold
         // sum(V.^a.*V_hat.^b - b/(a+b)*V_hat.^(a+b)); nmf.m:214 subtracts (a*sum(V.^(a+b)) + b*m*n) / (a+b) inside the scaled sum
         const double cnt = (double)e->m * (double)e->n;
@@ -707,7 +718,14 @@ nmfx_status klw_s_pass(nmfx_engine *e, bool store_R, bool with_cost) {
         f.Sin = b > 0 ? e->Vhat : nullptr;
         f.Rout = (!last || store_R) ? e->Vhat : nullptr;
         f.cost_partials = (last && with_cost) ? e->cost_partials : nullptr;
-        TRY(launch_fused(e->st, f, split, true, last ? 8 : 7, false, 0));
+        int func_last = 8;
+        if (e->dualw) {   // IS / alpha-beta: the last block runs map 11 / 13 on the accumulated S and stores both maps' values (A over the partial sums, B next to them)
+            func_last = e->div == NMFX_DIV_IS ? 19 : 20;
+            f.ab_alpha = (float)e->alpha; f.ab_beta = (float)e->beta; f.inv_exp = 1.0f;
+            if (last && e->Valpha) f.D = e->Valpha;
+            if (last && store_R) f.Rout2 = e->Vhat2;
+        }
+        TRY(launch_fused(e->st, f, split, true, last ? func_last : 7, false, 0));
         if (last) e->n_cost_used = (int)((e->m + 127) / 128) * split;
     }
     return NMFX_OK;
@@ -972,7 +990,7 @@ nmfx_status nmfx_engine_master_ptrs(nmfx_engine *e, double **W64_dev, double **H
 }
 // 0: the cost of iteration i is ready after hstep(i); 1: after wstep_partial(i+1); 2: after wstep_finish(i+1) (read it there; engines of kind 2
 // may also deliver it at point 1 -- reading at point 2 is always right for them)
-int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->fusedT_dual || e->klw) ? 1 : 0); }
+int32_t nmfx_engine_cost_lag(nmfx_engine *e) { return e->gram_cost ? 2 : ((e->fused || e->fusedT_kl || e->fusedT_dual || e->klw || e->dualw) ? 1 : 0); }
 
 // nmf.m:130-139 / cnmf.m:155-171: normalise W (all sources, fixed or not), cnmf also rescales H; then V_hat.
 // The normalisation runs on the float64 masters: one fp32 rounding of the INITIAL state is a perturbation the iteration carries to the end, and problems that
@@ -1049,7 +1067,7 @@ static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const doub
         if (e->klw_vt) TRY(transpose_f32(e->st, e->V, e->m, e->n, e->VT));   // once: V is constant over the iterations
         return sum_vec(e->st, e->colV, e->n, e->sumV);
     }
-    if (e->fusedT_dual) {          // nor here: the constants of the alpha-beta cost and V.^alpha, the S pass's data operand, once
+    if (e->fusedT_dual || e->dualw) {   // nor here: the constants of the alpha-beta cost and V.^alpha, the S pass's data operand, once
         Scope s(e, TAG_SMALL);
         e->cost_valid = false;
         if (e->div == NMFX_DIV_AB) {
@@ -1144,6 +1162,12 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         TRY(fusedT_pass(e, e->all_fixW ? FT_COST_KL : FT_S_KL, nullptr));
         TRY(fusedT_kl_cost(e));
     }
+    if (e->dualw) {       // IS / alpha-beta nmf with K > 256: S in column blocks, both element maps' values out of the last one, the (lagged) cost
+        TRY(klw_s_pass(e, !e->all_fixW, true));
+        Scope s(e, TAG_SMALL);
+        TRY(cost_from_partials(e, e->n_cost_used));
+        e->cost_valid = true;
+    }
     if (e->klw) {         // the same for nmf with K > 256
         TRY(klw_s_pass(e, !e->all_fixW, true));
         TRY(klw_cost(e));
@@ -1162,6 +1186,10 @@ static nmfx_status generic_wstep_partial(nmfx_engine *e) {
         return fusedT_pass(e, FT_NUM, e->packed + mKT, nullptr, e->Vhat2);
     }
     if (e->fusedT || e->fusedT_kl) TRY(fusedT_pass(e, FT_NUM, e->packed));   // all T numerators in one pass over V (KL: over R), the shifted H tile in LDS
+    else if (e->dualw) {   // [N | P] = [A | B] * H', column block by column block
+        TRY(klw_num_pass(e, e->packed, e->Vhat));
+        return klw_num_pass(e, e->packed + mKT, e->Vhat2);
+    }
     else if (e->klw) TRY(klw_num_pass(e, e->packed, e->Vhat));
     else if (e->eucw) TRY(klw_num_pass(e, e->packed, e->V));
     else TRY(x_times_ht(e, a, e->packed, TAG_WNUM));
@@ -1294,7 +1322,7 @@ nmfx_status nmfx_engine_wstep_finish(nmfx_engine *e) {
         TRY(w_normalize(e->st, e->W, e->m, e->K, e->T, e->sumsq, e->fixW, norm_mode(e), nullptr, 0, e->W64));
         e->cost_valid = false;
     }
-    if (e->gram || e->fusedT_kl || e->fusedT_dual || e->klw) return NMFX_OK;
+    if (e->gram || e->fusedT_kl || e->fusedT_dual || e->klw || e->dualw) return NMFX_OK;
     return recon(e, false);
 }
 
@@ -1444,6 +1472,10 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(fusedT_pass(e, FT_S_KL, nullptr));
             a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
         }
+        if (e->dualw) {                     // both element maps' values with the W just updated; W'*A and W'*B below are plain two-operand products (K x n x m)
+            TRY(klw_s_pass(e, true, false));
+            a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
+        }
         if (e->klw && !e->klw_vt) {         // likewise
             TRY(klw_s_pass(e, true, false));
             a = OpView{e->Vhat, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
@@ -1547,6 +1579,7 @@ nmfx_status nmfx_engine_hstep(nmfx_engine *e) {
             TRY(shift_sum(e->st, e->Qbuf, e->K, e->T, e->n, e->nvalid, e->Gp));
         } else if (div_has_matrix_den(e->div)) {
             den_view(e, b);
+            if (e->dualw) b = OpView{e->Vhat2, nullptr, e->m, VIEW_KC, 0, 0, 0, NMFX_PRO_NONE, 0.f, 0.f};
             TRY(wt_times_x(e, b, e->Gp, TAG_HDEN));
         }
         Scope s(e, TAG_SMALL);
@@ -1571,7 +1604,7 @@ nmfx_status nmfx_engine_hstep_finish(nmfx_engine *e) {
     NMFX_HIP(hipSetDevice(e->device));
     if (e->fused) return NMFX_OK;
     const bool nocost = e->div == NMFX_DIV_EUCLIDEAN_NOCOST;
-    if (e->fusedT_kl || e->fusedT_dual || e->klw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
+    if (e->fusedT_kl || e->fusedT_dual || e->klw || e->dualw) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: by-product of the next S pass, or nmfx_engine_cost_pass
     if ((e->fusedT || e->eucw) && e->gram_cost) { e->cost_valid = false; return NMFX_OK; }   // the cost lags: Gram form out of the next W update, or nmfx_engine_cost_pass
     if (e->fusedT) { if (!nocost) TRY(fusedT_pass(e, FT_COST_EUC, nullptr)); }   // S = sum_t W_t * rshift_t(H) in registers -> residual
     else if (e->gram) { if (!nocost) TRY(recon(e, true, false)); }   // residual reduction only, V_hat is not stored
@@ -1597,6 +1630,12 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
         return cost_from_partials(e, e->n_cost_used);
     }
     if (e->klw) { TRY(klw_s_pass(e, false, true)); return klw_cost(e); }
+    if (e->dualw) {
+        TRY(klw_s_pass(e, false, true));
+        Scope s(e, TAG_SMALL);
+        e->cost_valid = true;
+        return cost_from_partials(e, e->n_cost_used);
+    }
     if ((e->fusedT || e->eucw) && e->gram_cost) {
         if (e->eucw) TRY(eucw_cost_pass(e, nullptr));
         else
@@ -1608,7 +1647,7 @@ nmfx_status nmfx_engine_cost_pass(nmfx_engine *e) {
     set_error("nmfx_engine_cost_pass: no cost available yet (call hstep first)");
     return NMFX_ERR_INVALID;
 }
-int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : ((e->fusedT_kl || e->fusedT_dual) ? 4 : (e->klw ? 5 : (e->fusedT ? 3 : (e->eucw ? 6 : (e->gram ? 2 : 0))))); }   // 6 euclidean with K > 256 in column blocks, 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
+int32_t nmfx_engine_is_fused(nmfx_engine *e) { return e->fused ? 1 : ((e->fusedT_kl || e->fusedT_dual) ? 4 : ((e->klw || e->dualw) ? 5 : (e->fusedT ? 3 : (e->eucw ? 6 : (e->gram ? 2 : 0))))); }   // 6 euclidean with K > 256 in column blocks, 1 fused kernels, 3 fused cnmf passes + Gram denominators, 4 KL cnmf on the fused passes, 5 KL with K > 256 in column blocks, 2 Gram form on the GEMM, 0 materialised V_hat
 
 nmfx_status nmfx_engine_cost_ptr(nmfx_engine *e, double **dev_cost) { *dev_cost = e->cost; return NMFX_OK; }
 nmfx_status nmfx_engine_copy_cost(nmfx_engine *e, double *dst_dev) {

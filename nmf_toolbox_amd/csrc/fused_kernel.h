@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int TROWS = FT_C + TT - 1;   // LDS rows per tile
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
-    constexpr bool S_IN = FUNC == 7 || FUNC == 8 || FUNC == 10;   // S accumulated over several launches (column blocks of a wide factor)
+    constexpr bool S_IN = FUNC == 7 || FUNC == 8 || FUNC == 10 || FUNC == 19 || FUNC == 20;   // S accumulated over several launches (column blocks of a wide factor)
     constexpr int MF = FUNC == 8 ? 3 : (FUNC == 10 ? 1 : FUNC);   // the element map
     static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
     constexpr bool NO_V = FUNC == 12 || FUNC == 14;
     constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
-    constexpr int EF = FUNC == 15 ? 11 : (FUNC == 16 ? 13 : FUNC);                   // the element map to run
+    // 19 / 20: the LAST block of an IS / alpha-beta chain over a factor wider than 256 (like 8 for KL): the accumulated S goes through map 11 / 13 and both maps'
+    // values are stored
+    constexpr int EF = (FUNC == 15 || FUNC == 19) ? 11 : ((FUNC == 16 || FUNC == 20) ? 13 : FUNC);   // the element map to run
     static_assert(!STB || (DO_G2 && D_RC && EPI == 0 && TT == 1), "functors 15 / 16: W-step form with the second product");
     // functors 11 / 13 in the cost-only form: BOTH element maps' values go to HBM (p.Rout the first, p.Rout2 the second) -- the S pass of IS / alpha-beta cnmf, whose
     // numerator passes (functor 0 on either buffer) have no room for a first product next to K*T = 512 accumulators

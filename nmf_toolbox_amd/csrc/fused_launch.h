@@ -61,6 +61,8 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
     case 7: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 7, DO_G2, EPI, RAG>(st, p, nsplit); break;   // S over column blocks of a factor wider than 256
     case 8: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 8, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 10: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 10, DO_G2, EPI, RAG>(st, p, nsplit); break;   // ... of a euclidean chain: residual cost
+    case 19: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 19, DO_G2, EPI, RAG>(st, p, nsplit); break;   // ... of an IS chain: both element maps stored
+    case 20: if constexpr (!DO_G2 && D_RC && K >= 128) return launch_one<K, D_RC, 20, DO_G2, EPI, RAG>(st, p, nsplit); break;   // ... of an alpha-beta chain
     // the dual-map divergences above K = 192 as two single-map passes (K = 224, 256 only): 11 / 13 also in the cost-only form, 12 / 14 with the second product only
     case 11: if constexpr (K >= 224 && EPI == 0) return launch_one<K, D_RC, 11, DO_G2, EPI, RAG>(st, p, nsplit); break;
     case 13: if constexpr (K >= 224 && EPI == 0) return launch_one<K, D_RC, 13, DO_G2, EPI, RAG>(st, p, nsplit); break;

@@ -335,15 +335,39 @@ def test_cnmf_is_on_the_fused_passes_fixed_factors_sources_and_stop(gpu_lib):
         assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[1], ref[1]) <= TOL
 
 
-@pytest.mark.parametrize("div,ab,m,n,K", [("is", None, 200, 600, 320), ("is", None, 256, 700, 512), ("ab", (0.5, 1.5), 200, 600, 320), ("ab", (1.5, -1.5), 256, 700, 512)])
-def test_nmf_is_and_alpha_beta_above_256_materialised(gpu_lib, div, ab, m, n, K):
-    """the one family that still runs with V_hat in HBM: IS / alpha-beta nmf with K > 256 (nmf.m:154-164,185-195) -- against the oracle at the contract"""
+@pytest.mark.parametrize("div,ab,m,n,K", [("is", None, 200, 600, 320), ("is", None, 256, 700, 512), ("ab", (0.5, 1.5), 200, 600, 320), ("ab", (1.5, -1.5), 256, 700, 512),
+                                          ("is", None, 257, 4160, 288), ("ab", (1.0, 0.5), 384, 1024, 800), ("is", None, 130, 2051, 2048), ("ab", (2.0, -0.5), 512, 768, 544)])
+def test_nmf_is_and_alpha_beta_above_256_in_column_blocks(gpu_lib, div, ab, m, n, K):
+    """IS / alpha-beta nmf with K > 256 (nmf.m:154-164,185-195 have no K limit) without V_hat, round 5 (engine.dualw): S = W*H accumulated over <= 256-wide column
+    blocks (functor 7), the last block runs the first element map with its cost terms on the accumulated S and stores BOTH maps' values (functors 19 / 20), numerator
+    passes block by block on either buffer, W'*A and W'*B as plain products.  Two to eight blocks, ragged shapes, sparsity terms on: against the oracle at the
+    contract and against the materialised path (nmfx_path = 1)."""
     from oracle import nmf_oracle as O
     V, W0, H0 = synth(m, n, K)
     cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
     if ab:
         cfg["alpha"], cfg["beta"] = ab
-    _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg))
+    ref = O.nmf(V, K, cfg)
+    _check(gpu_lib.nmf(V, K, cfg), ref)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_path=1)), ref)
+
+
+def test_nmf_is_above_256_fixed_factors_sources_and_stop(gpu_lib):
+    from oracle import nmf_oracle as O
+    m, n, K = 256, 900, 320
+    V, W0, H0 = synth(m, n, K)
+    base = dict(divergence="is", maxiter=5, tolerance=1e-12)
+    cfg = dict(base, W_init=[W0[:, :120], W0[:, 120:]], H_init=[H0[:120], H0[120:]], W_sparsity=[0.05, 0.0], H_fixed=[False, True])
+    _check(gpu_lib.nmf(V, [120, 200], cfg), O.nmf(V, [120, 200], cfg))
+    for fixed in ("W_fixed", "H_fixed"):
+        cfg = dict(base, W_init=W0, H_init=H0, **{fixed: True})
+        _check(gpu_lib.nmf(V, K, cfg), O.nmf(V, K, cfg))
+    # column shards of nmf carry no halos: every shard's engine takes the same path, [N | P] is what the shards sum (three ragged shards on one device)
+    cfg = dict(base, W_init=W0, H_init=H0, W_sparsity=0.02)
+    ref = O.nmf(V, K, cfg)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0, 0, 0])), ref)
+    cfg = dict(divergence="ab", alpha=0.5, beta=1.5, W_init=W0, H_init=H0, maxiter=4, tolerance=1e-12)
+    _check(gpu_lib.nmf(V, K, dict(cfg, nmfx_gpus=[0, 0])), O.nmf(V, K, cfg))
 
 
 @pytest.mark.parametrize("sW,sH", [(0.0, 0.5), (0.4, 0.6), (0.0, 0.0), (0.3, 0.0)])
