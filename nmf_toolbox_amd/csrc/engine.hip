@@ -165,7 +165,7 @@ Layout layout(nmfx_engine *e, void *ws) {
         e->colV_g = c.take<double>(e->n);
     }
     if (e->fusedT_dual) {
-        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->T - 1));
+        e->Hpad = c.take<float>((size_t)e->K * (e->n + e->hR + e->T - 1));
         e->slabsT = e->nsplit_T > 1 ? c.take<float>((size_t)e->nsplit_T * mKT) : nullptr;
         const int need = (int)((e->m + 127) / 128) * e->nsplit_T;
         if (need > e->n_cost_partials) { e->n_cost_partials = need; e->cost_partials = c.take<double>(need); }
@@ -302,7 +302,7 @@ nmfx_status fill_from_desc(nmfx_engine *e, const nmfx_engine_desc *d) {
     // IS / alpha-beta (alpha != 0) cnmf, unsharded, the common (K, T) pairs: S pass with both element maps stored (functors 11 / 13 in the cost-only form),
     // numerator passes on either buffer, the H-step products as two well-shaped GEMMs on them (cnmf.m:179-194,227-231 without V_hat)
     e->fusedT_dual = !e->fused && e->algo == 1 && (e->div == NMFX_DIV_IS || (e->div == NMFX_DIV_AB && e->alpha != 0)) && e->T > 1 && fused_supported_T_dual(e->K, e->T) &&
-                     e->m >= 64 && e->n >= 64 && e->K % 4 == 0 && e->m % 4 == 0 && e->hL == 0 && e->hR == 0 && e->nvalid == e->n && d->path != 1;
+                     e->m >= 64 && e->n >= 64 && e->K % 4 == 0 && e->m % 4 == 0 && (e->hL == 0 || e->hL >= e->T - 1) && d->path != 1;   // (column shards as for KL: halos)
     if (d->path == 2 && e->algo == 1 && !e->fusedT && !e->fusedT_kl && !e->fusedT_dual) {
         set_error("nmfx_engine: fused cnmf kernels requested but the problem is not eligible (euclidean or kl, T > 1, an instantiated (K, T) pair)");
         return NMFX_ERR_UNSUPPORTED;
@@ -634,7 +634,7 @@ enum FusedTMode { FT_NUM = 0, FT_COST_EUC = 1, FT_S_KL = 2, FT_COST_KL = 3, FT_S
 nmfx_status ensure_hpad(nmfx_engine *e) {   // Hpad = [T-1 zero columns | H | T-1 zero columns (lag-form Gram products only)]
     if (e->hpad_valid) return NMFX_OK;      // H changed since the last pass (init, H step)
     Scope s(e, TAG_SMALL);
-    TRY(pad_left(e->st, e->H, e->K, e->n + (e->fusedT_kl ? e->hR : 0), e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));   // (KL shards: the S pass also runs over the right-halo columns)
+    TRY(pad_left(e->st, e->H, e->K, e->n + ((e->fusedT_kl || e->fusedT_dual) ? e->hR : 0), e->T - 1, e->Hpad, e->lagram ? e->T - 1 : 0));   // (KL shards: the S pass also runs over the right-halo columns)
     e->hpad_valid = true;
     return NMFX_OK;
 }
@@ -673,6 +673,14 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if 
         TRY(reduce_slabs(e->st, e->slabsT, e->nsplit_T, mKT, mKT, out, 0));
     }
     if (!do_g2) e->n_cost_used = (int)((e->m + 127) / 128) * e->nsplit_T;
+    if (mode == FT_S_DUAL && e->hR > 0) {   // column shard: both element maps' values on the T-1 right-halo columns too, as for KL below
+        FusedParams h = f;
+        h.Y = Hy + (size_t)e->K * e->n; h.D = (e->Valpha ? e->Valpha : e->V) + (size_t)e->m * e->n;
+        h.Rout = e->Vhat + (size_t)e->m * e->n; h.Rout2 = e->Vhat2 + (size_t)e->m * e->n;
+        h.Cn = e->hR; h.c_per_split = 64; h.cost_partials = nullptr; h.out = nullptr;
+        Scope s(e, TAG_SMALL);
+        TRY(launch_fused(e->st, h, 1, true, func, false, 0));
+    }
     if (mode == FT_S_KL && e->hR > 0) {
         // column shard: R = V./V_hat on the T-1 right-halo columns too (Q((t,k), j+t) of the last local columns reads them, cnmf.m:219); they belong to
         // the neighbour's cost, so this second, tiny launch carries none
@@ -1073,7 +1081,7 @@ static nmfx_status engine_init_impl(nmfx_engine *e, const double *W0, const doub
         if (e->div == NMFX_DIV_AB) {
             TRY(col_reduce_pow(e->st, e->V, e->m, e->m, (int)e->n, (float)(e->alpha + e->beta), e->colV));
             TRY(sum_vec(e->st, e->colV, e->n, e->sumVab));
-            if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * e->n, (float)e->alpha));
+            if (e->Valpha) TRY(pow_map(e->st, e->V, e->Valpha, (long)e->m * (e->n + e->hR), (float)e->alpha));   // (the right-halo columns of a cnmf shard too)
         }
         return NMFX_OK;
     }

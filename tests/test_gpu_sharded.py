@@ -746,6 +746,24 @@ def test_blocking_api_n_gpus_cnmf_matches_oracle(gpu_lib, div, ndev, m, n, K, T)
     assert rel_fro(got[0], one[0]) <= 3e-6 and rel_fro(got[1], one[1]) <= 3e-6      # vs one shard: summation order only
 
 
+@pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5))])
+@pytest.mark.parametrize("ndev,m,n,K,T", [(8, 192, 1030, 32, 8), (2, 256, 520, 64, 4), (3, 132, 1024, 64, 2), (2, 96, 200, 6, 4)])
+def test_blocking_api_n_gpus_cnmf_is_and_alpha_beta(gpu_lib, div, ab, ndev, m, n, K, T):
+    """IS / alpha-beta cnmf on column shards: with the fused passes (the eight pairs, m a multiple of 4) both element maps' values are also formed on a shard's T-1
+    right-halo columns (as KL's R is); the last case (K = 6) runs the materialised path on its shards.  Against the oracle and the one-shard call."""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    if ab:
+        cfg["alpha"], cfg["beta"] = ab
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_gpus=[0] * ndev))
+    one = gpu_lib.cnmf(V, K, T, cfg)
+    assert len(got[2]) == len(ref[2])
+    assert rel_fro(got[0], ref[0]) <= 1e-5 and rel_fro(got[1], ref[1]) <= 1e-5 and rel_fro(got[2], ref[2]) <= 1e-6
+    assert rel_fro(got[0], one[0]) <= 3e-6 and rel_fro(got[1], one[1]) <= 3e-6      # vs one shard: summation order only
+
+
 def test_blocking_api_n_gpus_cnmf_stop_rule_and_sources(gpu_lib):
     from oracle import nmf_oracle as O
     m, n, K, T = 128, 600, 16, 4
