@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-#define NMFX_VERSION 200
+/* ABI version: bumped whenever a struct below grows or an entry point changes (600: nmfx_problem.multi_backend, the RCCL / exchange hooks, nmfx_abi_sizes).
+ * A client compares nmfx_version() with the NMFX_VERSION it was BUILT against and nmfx_abi_sizes() with its own sizeof()s before the first call:
+ * the library reads every field of the structs it is handed, so a client built against an older, shorter nmfx_problem must not call in
+ * (matlab/nmfx_mex.c and nmf_toolbox_amd/_lib.py both refuse to). */
+#define NMFX_VERSION 600
 
 typedef enum {
     NMFX_OK = 0,
@@ -192,6 +196,8 @@ const char *nmfx_rccl_library(int32_t *version);
 const char *nmfx_last_error(void);
 int32_t nmfx_device_count(void);   /* 0 when no HIP device is usable */
 int32_t nmfx_version(void);
+/* sizeof(nmfx_problem), sizeof(nmfx_result), sizeof(nmfx_engine_desc) as THIS library was compiled (any pointer may be NULL) */
+void nmfx_abi_sizes(int32_t *problem_bytes, int32_t *result_bytes, int32_t *engine_desc_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Phase API on DEVICE buffers (fp32), asynchronous on the caller's HIP stream.  This is what

@@ -180,6 +180,12 @@ static void constrained(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     char algo[24];
+    int32_t sz_p = 0, sz_r = 0;
+    /* the library reads every field of nmfx_problem: a gateway compiled against another nmfx.h must not call in (nmfx.h, NMFX_VERSION) */
+    nmfx_abi_sizes(&sz_p, &sz_r, NULL);
+    if (nmfx_version() != NMFX_VERSION || sz_p != (int32_t)sizeof(nmfx_problem) || sz_r != (int32_t)sizeof(nmfx_result))
+        FAIL("abi", "libnmfx is ABI version %d (nmfx_problem %d bytes), this gateway was compiled against %d (%d bytes): rebuild nmfx_mex",
+             (int)nmfx_version(), (int)sz_p, (int)NMFX_VERSION, (int)sizeof(nmfx_problem));
     if (nrhs < 1 || !mxIsChar(prhs[0]) || mxGetString(prhs[0], algo, sizeof(algo)) != 0) FAIL("usage", "nmfx_mex(algo, ...): algo must be a string");
     if (!strcmp(algo, "nmf") || !strcmp(algo, "cnmf") || !strcmp(algo, "lnmf") || !strcmp(algo, "nmfsc") || !strcmp(algo, "cnmfsc")) {
         factorise(algo, nlhs, plhs, nrhs, prhs);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnmfx.so")
 NMFX_OK, NMFX_ERR_INVALID, NMFX_ERR_NO_DEVICE, NMFX_ERR_HIP, NMFX_ERR_UNSUPPORTED, NMFX_ERR_NOMEM, NMFX_ERR_NEGATIVE = range(7)
 DIV_EUCLIDEAN, DIV_KL, DIV_IS, DIV_AB, DIV_EUCLIDEAN_NOCOST = range(5)
 F32, F64 = 0, 1
+ABI_VERSION = 600   # the NMFX_VERSION of include/nmfx.h the structures below were written against (load() refuses any other library)
 
 # every symbol include/nmfx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "nmfx_engine_profile_read", "nmfx_engine_tag_work", "nmfx_gemm_f32", "nmfx_constrainednmf", "nmfx_sort_dictionary",
     "nmfx_engine_set_constraint", "nmfx_nmfsc_dev", "nmfx_engine_wstep_partial_chunk", "nmfx_engine_packed_chunk",
     "nmfx_engine_between_allreduces", "nmfx_engine_between_allreduces_cost", "nmfx_projfunc_dev", "nmfx_nmfsc_profile", "nmfx_nmfsc_profile_ntags", "nmfx_nmfsc_profile_tag_name", "nmfx_nmfsc_profile_read", "nmfx_last_call_timing", "nmfx_sc_iteration_seconds", "nmfx_engine_cost_lag", "nmfx_engine_sumvv_local", "nmfx_engine_sumvv_set_global",
-    "nmfx_minmax_dev", "nmfx_scale_dev", "nmfx_gemm64", "nmfx_engine_sync_master", "nmfx_engine_master_ptrs", "nmfx_engine_init_f64", "nmfx_last_call_exchange", "nmfx_rccl_library",
+    "nmfx_minmax_dev", "nmfx_scale_dev", "nmfx_gemm64", "nmfx_engine_sync_master", "nmfx_engine_master_ptrs", "nmfx_engine_init_f64", "nmfx_last_call_exchange", "nmfx_rccl_library", "nmfx_abi_sizes",
 ]
 
 
@@ -87,6 +88,15 @@ def load():
     except Exception:
         pass
     lib = C.CDLL(LIB_PATH)
+    # the library reads every field of the structures it is handed: a binding written against another header must not call in
+    ver = lib.nmfx_version() if hasattr(lib, "nmfx_version") else -1
+    if ver != ABI_VERSION:
+        raise ImportError("nmf_toolbox_amd: %s is ABI version %d, this binding was written against %d -- rebuild (python -m nmf_toolbox_amd.build)" % (LIB_PATH, ver, ABI_VERSION))
+    sz = (C.c_int32 * 3)()
+    lib.nmfx_abi_sizes(C.byref(sz, 0), C.byref(sz, 4), C.byref(sz, 8))
+    mine = (C.sizeof(Problem), C.sizeof(Result), C.sizeof(EngineDesc))
+    if tuple(sz) != mine:
+        raise ImportError("nmf_toolbox_amd: structure sizes differ between %s %r and this binding %r (nmfx_problem, nmfx_result, nmfx_engine_desc)" % (LIB_PATH, tuple(sz), mine))
     lib.nmfx_last_error.restype = C.c_char_p
     lib.nmfx_engine_profile_tag_name.restype = C.c_char_p
     lib.nmfx_engine_profile_tag_name.argtypes = [C.c_int32]

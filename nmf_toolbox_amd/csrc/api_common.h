@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -238,10 +239,13 @@ void unpool_event_timed(int device, hipEvent_t ev);
 nmfx_status run_nmfsc_multi(const nmfx_problem *p, nmfx_result *r);   // multi_sc.hip
 // RCCL behind the blocking multi-GPU calls, dlopen'ed (rccl_backend.hip)
 bool rccl_usable(const int *devs, int n, std::string *why);
-nmfx_status rccl_comms(const int *devs, int n, void **comms_out);
+nmfx_status rccl_comms(const int *devs, int n, void **comms_out);   // checks the cached set out for the calling thread ...
+void rccl_release(const int *devs, int n);                          // ... until this
 nmfx_status rccl_allreduce_f32(void *const *comms, const int *devs, hipStream_t const *streams, float *const *bufs, int n, size_t count);
 bool nmfsc_f64_eligible(const nmfx_problem *p);                       // sc64.hip: small problems run nmfsc.m in float64 end to end
 nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r);
 void sc_thread_cleanup();                                              // sc.hip
+void sc_hooks_reset();                                                 // sc.hip: empties this thread's nmfx_sc_iteration_seconds / nmfx_nmfsc_profile_read records
+void sc_hooks_iteration_done(std::chrono::steady_clock::time_point since);
 
 }  // namespace nmfx

@@ -254,6 +254,7 @@ struct MultiDev {
     double *hpin = nullptr;
     bool use_rccl = false;                 // the packed exchange: RCCL (rccl_backend.hip) or the peer reduce-scatter + all-gather below
     void *comms[NMFX_MAX_GPUS] = {};
+    int lease_n = 0;                       // > 0: this call holds the cached RCCL communicator set of dev[0 .. lease_n) (rccl_comms) and hands it back below
     std::vector<hipEvent_t> evX;           // pairs around the first exchanges on device 0's stream (nmfx_last_call_exchange)
     int nx = 0;
     nmfx_status init_host() {
@@ -266,6 +267,7 @@ struct MultiDev {
             if (st[g]) (void)hipStreamSynchronize(st[g]);
         }
         staging_quiesce();   // (the ingest left its DMA-done events recorded on these streams)
+        if (lease_n > 0) rccl_release(dev, lease_n);   // (every collective of this call has completed: the streams are drained)
         for (int g = 0; g < ndev; ++g) {
             (void)hipSetDevice(dev[g]);
             if (eng[g]) nmfx_engine_destroy(eng[g]);
@@ -381,7 +383,7 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             if (!rccl_usable(M.dev, N, &why)) { set_error("multi_backend = rccl: %s", why.c_str()); return NMFX_ERR_UNSUPPORTED; }
             M.use_rccl = true;
         } else M.use_rccl = want == 0 && rccl_usable(M.dev, N, &why);
-        if (M.use_rccl) TRY(rccl_comms(M.dev, N, M.comms));
+        if (M.use_rccl) { TRY(rccl_comms(M.dev, N, M.comms)); M.lease_n = N; }
     }
     for (int g = 0; g < N; ++g)      // peer mappings: the reduce kernel reads the other devices' `packed` in place (and cnmf's halo copies go direct)
         for (int h = 0; h < N; ++h) {
@@ -456,7 +458,11 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         if (ok) break;
         for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); M.ws[g].release(); }
     }
-    // pass 3: ingest and engines
+    // pass 3: ingest and engines.  The clocks of nmfx_last_call_timing belong to THIS call (run_mu stamps the same three spans): ingest = host arrays in +
+    // engines + init, iterate = the loop incl. the closing cost pass, egress = results out
+    IoStats &io = io_stats();
+    io = IoStats{};
+    const auto t0 = std::chrono::steady_clock::now();
     for (int g = 0; g < N; ++g) {
         NMFX_HIP(hipSetDevice(M.dev[g]));
         const long nl = M.lo[g + 1] - M.lo[g], hL = M.hL[g], hR = M.hR[g], nh = hL + nl + hR;
@@ -509,6 +515,8 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         }
     }
     if (lagk == 2 && p->tolerance >= 0 && !Wbak.p) { NMFX_HIP(hipSetDevice(M.dev[0])); TRY(Wbak.alloc(mK * 4)); }
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); }   // closes the ingest clock (init queued its kernels)
+    const auto t1 = std::chrono::steady_clock::now();
     double *hc = M.hpin;   // pinned: the 8-byte read-backs land by DMA, not through the runtime's staging of pageable memory (see MultiDev::hpin)
     auto read_cost = [&](int idx) -> nmfx_status {   // cost = sum of the shards' partials (the lambda*|W| term lives on device 0 only)
         for (int g = 0; g < N; ++g) {
@@ -565,8 +573,9 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
         for (int i = r->iters_run; i < p->maxiter; ++i) r->cost[i] = 0.0;
         r->cost_len = p->maxiter;
     }
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); }   // (a stop leaves the speculative W-step partials of the other shards in flight)
+    const auto t2 = std::chrono::steady_clock::now();
     {   // the exchange as device 0's stream saw it
-        IoStats &io = io_stats();
         io.exchange_backend = M.use_rccl ? 2 : 1; io.exchange_ms = 0; io.exchanges_timed = 0;
         NMFX_HIP(hipSetDevice(M.dev[0]));
         NMFX_HIP(hipStreamSynchronize(M.st[0]));
@@ -585,6 +594,10 @@ nmfx_status run_mu_multi(const nmfx_problem *p, nmfx_result *r, int algorithm) {
             TRY(download(M.st[g], M.tmp[g].as<float>(), p->dtype, Hh, (size_t)Kt * nl));
         } else TRY(download(M.st[g], M.H[g].as<float>() + (size_t)K * M.hL[g], p->dtype, Hh, (size_t)K * nl));
     }
+    for (int g = 0; g < N; ++g) { NMFX_HIP(hipSetDevice(M.dev[g])); NMFX_HIP(hipStreamSynchronize(M.st[g])); }
+    const auto t3 = std::chrono::steady_clock::now();
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    io.ingest_s = sec(t0, t1); io.iterate_s = sec(t1, t2); io.egress_s = sec(t2, t3);
     return NMFX_OK;
 }
 

@@ -862,6 +862,11 @@ extern "C" {
 
 const char *nmfx_last_error(void) { return g_err; }
 int32_t nmfx_version(void) { return NMFX_VERSION; }
+void nmfx_abi_sizes(int32_t *problem_bytes, int32_t *result_bytes, int32_t *engine_desc_bytes) {
+    if (problem_bytes) *problem_bytes = (int32_t)sizeof(nmfx_problem);
+    if (result_bytes) *result_bytes = (int32_t)sizeof(nmfx_result);
+    if (engine_desc_bytes) *engine_desc_bytes = (int32_t)sizeof(nmfx_engine_desc);
+}
 int32_t nmfx_device_count(void) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }

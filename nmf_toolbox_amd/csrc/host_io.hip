@@ -241,6 +241,8 @@ nmfx_status validate_problem(const nmfx_problem *p, const nmfx_result *r, bool n
     if (!p->V || !p->W_init || (need_H_init && !p->H_init) || !r->W || !r->H || !r->cost) { set_error("V, W_init, H_init, result.W, result.H, result.cost are required"); return NMFX_ERR_INVALID; }
     if (p->dtype != NMFX_F32 && p->dtype != NMFX_F64) { set_error("dtype must be NMFX_F32 or NMFX_F64"); return NMFX_ERR_INVALID; }
     if (p->maxiter <= 0) { set_error("maxiter must be positive (the wrapper applies the reference default)"); return NMFX_ERR_INVALID; }
+    if (p->multi_backend < 0 || p->multi_backend > 2) { set_error("multi_backend = %d: 0 (auto), 1 (peer exchange) or 2 (RCCL)", p->multi_backend); return NMFX_ERR_INVALID; }
+    if (p->n_gpus < 0 || p->n_gpus > NMFX_MAX_GPUS) { set_error("n_gpus = %d: 0 .. %d", p->n_gpus, NMFX_MAX_GPUS); return NMFX_ERR_INVALID; }
     if (!nmfsc) {
         if (p->num_sources < 1) { set_error("num_sources must be >= 1"); return NMFX_ERR_INVALID; }
         if (p->num_sources > 1 && !p->K_s) { set_error("K_s is required when num_sources > 1"); return NMFX_ERR_INVALID; }

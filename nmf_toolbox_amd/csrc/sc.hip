@@ -60,6 +60,17 @@ static const char *const kScTagNames[SC_COUNT] = {"fused:objective pass (S=W*H -
 static thread_local Profiler g_sc_prof;
 static thread_local std::vector<double> g_iter_t;   // seconds from the start of the iterations to the end of every outer iteration of the last sc call (bench.py)
 
+}  // namespace
+namespace nmfx {
+// the float64 small-problem path (sc64.hip) has no tagged launch groups: after one of its calls the hooks say "nothing recorded" instead of an earlier call's numbers
+void sc_hooks_reset() {
+    g_iter_t.clear();
+    g_sc_prof.st = nullptr;
+    if (g_sc_prof.on) { g_sc_prof.events.clear(); g_sc_prof.pool_used = 0; }
+}
+void sc_hooks_iteration_done(std::chrono::steady_clock::time_point since) { g_iter_t.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - since).count()); }
+}  // namespace nmfx
+namespace {
 // device-resident inputs of nmfx_nmfsc_dev: a column shard per rank, W replicated, collectives through the caller's callback
 struct ScDev {
     const float *V;      // m x n_local, already divided by the GLOBAL max (nmfsc.m:62)

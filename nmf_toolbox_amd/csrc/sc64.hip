@@ -118,7 +118,19 @@ nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {
     if (vmin < 0) { set_error("Negative values in data!"); return NMFX_ERR_NEGATIVE; }
     DeviceGuard dg_;
     TRY(check_device(p->device));
-    hipStream_t st = nullptr;
+    // an own (pooled, non-blocking) stream: the legacy NULL stream would synchronise implicitly with every other blocking stream of the process, other threads'
+    // engines included.  The measurement hooks of the nmfsc calls (nmfx_last_call_timing, nmfx_sc_iteration_seconds, nmfx_nmfsc_profile_read) describe THIS
+    // call afterwards, not an earlier one: timing and iteration times are filled below, the per-tag profile is emptied (this path has no tagged launch groups)
+    struct PooledStream {
+        int dev; hipStream_t st = nullptr;
+        ~PooledStream() { if (st) { (void)hipStreamSynchronize(st); unpool_stream(dev, st); } }
+    } ps{p->device};
+    TRY(pool_stream(p->device, &ps.st));
+    hipStream_t st = ps.st;
+    IoStats &io = io_stats();
+    io = IoStats{};
+    sc_hooks_reset();
+    const auto t_in = std::chrono::steady_clock::now();
     double sW = p->sc_W_sparsity, sH = p->sc_H_sparsity, L1a = 0, L1s = 0;
     if (sW > 0) { if (sW > 1) sW = 1; L1a = std::sqrt((double)m) - (std::sqrt((double)m) - 1) * sW; }   // nmfsc.m:89-93
     if (sH > 0) { if (sH > 1) sH = 1; L1s = std::sqrt((double)n) - (std::sqrt((double)n) - 1) * sH; }   // nmfsc.m:102-106
@@ -147,16 +159,23 @@ nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {
     double *Wd = W.as<double>(), *Wnew = Wn.as<double>(), *HTd = HT.as<double>(), *HnewT = HnT.as<double>();
     if (sW > 0) TRY(projfunc_cols_f64(st, Wd, m, K, L1a, 1.0, 1, nullptr));    // nmfsc.m:94-96
     if (sH > 0) TRY(projfunc_cols_f64(st, HTd, n, K, L1s, 1.0, 1, nullptr));   // nmfsc.m:107-109
+    struct Pinned { double *p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } pin;   // (declared after drain_: freed before the stream is drained? no -- destructors run in reverse order, and every read of it is followed by a synchronise)
+    NMFX_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin.p), sizeof(double), hipHostMallocDefault));
+    double *hobj = pin.p;
     // V_hat = Wx*Hx and 0.5*||V - V_hat||^2, read by the host (the line searches branch on it)
     auto recon_obj = [&](const double *Wx, const double *HxT, double *obj) -> nmfx_status {
         hipLaunchKernelGGL(sc64_recon_kernel, dim3(nparts), dim3(256), 0, st, Wx, HxT, m, n, K, V.as<double>(), Vh.as<double>(), parts.as<double>());
         hipLaunchKernelGGL(sc64_sum_kernel, dim3(1), dim3(256), 0, st, parts.as<double>(), nparts, 0.5, scal.as<double>());
         NMFX_HIP(hipGetLastError());
-        NMFX_HIP(hipMemcpy(obj, scal.p, sizeof(double), hipMemcpyDeviceToHost));   // (blocking: the line search branches on it)
+        NMFX_HIP(hipMemcpyAsync(hobj, scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
+        NMFX_HIP(hipStreamSynchronize(st));   // (the line search branches on it)
+        *obj = *hobj;
         return NMFX_OK;
     };
     double stepH = p->sc_stepsize_H0 > 0 ? p->sc_stepsize_H0 : 1.0, stepW = p->sc_stepsize_W0 > 0 ? p->sc_stepsize_W0 : 1.0;   // nmfsc.m:133-134
     TRY(recon_obj(Wd, HTd, &r->cost[0]));   // nmfsc.m:138-139
+    const auto t_it = std::chrono::steady_clock::now();
+    io.ingest_s = std::chrono::duration<double>(t_it - t_in).count();
     int ncost = p->maxiter + 1, nH = 0, nW = 0;
     bool early = false;
     for (int it = 1; it <= p->maxiter && !early; ++it) {
@@ -213,6 +232,7 @@ nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {
             NMFX_HIP(hipGetLastError());
         }
         TRY(recon_obj(Wd, HTd, &r->cost[it]));                                                      // nmfsc.m:237-238
+        sc_hooks_iteration_done(t_it);
         if (p->tolerance >= 0 && it > 1 && r->cost[it] < r->cost[it - 1] && r->cost[it - 1] - r->cost[it] < p->tolerance) {   // nmfsc.m:241-244
             ncost = it + 1;
             break;
@@ -224,6 +244,8 @@ nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {
     r->converged_early = early ? 1 : 0;
     if (r->tries_H) for (int i = nH; i < p->maxiter; ++i) r->tries_H[i] = 0;
     if (r->tries_W) for (int i = nW; i < p->maxiter; ++i) r->tries_W[i] = 0;
+    const auto t_out = std::chrono::steady_clock::now();   // (the last objective was read on the host: the iterations are complete)
+    io.iterate_s = std::chrono::duration<double>(t_out - t_it).count();
     hipLaunchKernelGGL(sc64_transpose_kernel, g1((long)Kn), dim3(256), 0, st, HTd, n, (long)K, Hk.as<double>());
     NMFX_HIP(hipGetLastError());
     auto egress = [&](const double *src, size_t count, void *host) -> nmfx_status {
@@ -238,6 +260,7 @@ nmfx_status run_nmfsc_f64(const nmfx_problem *p, nmfx_result *r) {
     TRY(egress(Wd, mK, r->W));
     TRY(egress(Hk.as<double>(), Kn, r->H));
     NMFX_HIP(hipStreamSynchronize(st));
+    io.egress_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count();
     return NMFX_OK;
 }
 

@@ -132,6 +132,18 @@ def _as_data(V):
     return V
 
 
+def _multi_backend(v):
+    """config.nmfx_multi_backend: a name, or the number the MATLAB wrappers pass (0 auto | 1 peer | 2 rccl); anything else is an error, not a silent auto"""
+    names = {None: 0, "auto": 0, "peer": 1, "rccl": 2}
+    if isinstance(v, str) or v is None:
+        if v not in names:
+            raise ValueError("nmfx_multi_backend must be 'auto', 'peer' or 'rccl' (or 0, 1, 2); got %r" % (v,))
+        return names[v]
+    if isinstance(v, (int, np.integer, float)) and not isinstance(v, bool) and float(v) in (0.0, 1.0, 2.0):
+        return int(v)
+    raise ValueError("nmfx_multi_backend must be 'auto', 'peer' or 'rccl' (or 0, 1, 2); got %r" % (v,))
+
+
 def _gpu_ids(cfg):
     gpus = cfg.get("nmfx_gpus", None)
     if gpus is None:
@@ -185,7 +197,7 @@ def _run_mu(fn, V, Ks, T, cfg, W, H, divergence, device):
     if ids is not None:
         p.n_gpus, p.device_ids = int(ids.size), _fptr(ids)
     # extension: the exchange of the packed W-step sums between those GPUs -- "rccl" (ncclAllReduce), "peer" (reduce-scatter + all-gather over peer mappings), default auto
-    p.multi_backend = {None: 0, "auto": 0, "peer": 1, "rccl": 2}.get(cfg.get("nmfx_multi_backend", None), 0)
+    p.multi_backend = _multi_backend(cfg.get("nmfx_multi_backend", None))
     r = _lib.Result()
     r.W, r.H, r.cost = _fptr(Wout), _fptr(Hout), _fptr(cost)
     _lib.check(fn(C.byref(p), C.byref(r)))

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(set(L.EXPORTS)) == declared          # the Python binding list tracks the header
-    assert lib.nmfx_version() == 200
+    assert lib.nmfx_version() == 600
 
 
 def test_struct_layouts_match_header():
@@ -134,3 +134,58 @@ def test_pmc_traffic_stamp_guards_the_bench_line():
         assert got and all(v > 4.4e9 for v in got.values()) and "not measured in this run" in note      # c3: at least the algorithmic 4.45e9 B per launch
     else:
         assert got == {} and "STALE" in note and "withheld" in note
+
+
+def test_abi_version_and_sizes_are_checked_by_the_loaders():
+    """nmfx_problem grew (multi_backend) -- a client built against another header must be turned away, not read past its struct"""
+    L = _lib()
+    lib = L.load()
+    sz = (C.c_int32 * 3)()
+    lib.nmfx_abi_sizes(C.byref(sz, 0), C.byref(sz, 4), C.byref(sz, 8))
+    assert tuple(sz) == (C.sizeof(L.Problem), C.sizeof(L.Result), C.sizeof(L.EngineDesc))
+    hdr = open(os.path.join(ROOT, "include", "nmfx.h")).read()
+    assert int(re.search(r"#define NMFX_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION == lib.nmfx_version()
+    # a binding written against another version refuses the library (fresh interpreter: load() caches)
+    import subprocess
+    code = ("from nmf_toolbox_amd import _lib\n_lib.ABI_VERSION = 200\n"
+            "try:\n    _lib.load()\nexcept ImportError as e:\n    print('refused:', e)\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, text=True)
+    assert "refused:" in out and "ABI version 600" in out
+    # the MEX gateway makes the same check before anything else
+    mex = open(os.path.join(ROOT, "matlab", "nmfx_mex.c")).read()
+    assert "nmfx_version() != NMFX_VERSION" in mex and "nmfx_abi_sizes" in mex
+
+
+def test_multi_backend_is_validated():
+    """values outside {0, 1, 2} are an error at the C ABI (before any device is touched), and unknown names are one in the Python wrapper"""
+    L = _lib()
+    lib = L.load()
+    from nmf_toolbox_amd import toolbox
+    assert [toolbox._multi_backend(v) for v in (None, "auto", "peer", "rccl", 0, 1, 2, 2.0, np.int32(1))] == [0, 0, 1, 2, 0, 1, 2, 2, 1]
+    for bad in ("nccl", 3, -1, 1.5, True):
+        with pytest.raises(ValueError, match="nmfx_multi_backend"):
+            toolbox._multi_backend(bad)
+    V, W0, H0 = (np.ascontiguousarray(a, dtype=np.float32) for a in synth(16, 24, 4))
+    Wo, Ho, cost = np.zeros_like(W0), np.zeros_like(H0), np.zeros(3)
+    for mb, ng in ((7, 0), (-1, 1), (3, 2)):
+        p, r = L.Problem(), L.Result()
+        p.m, p.n, p.K_total, p.T, p.dtype = 16, 24, 4, 1, L.F32
+        p.V, p.W_init, p.H_init = V.ctypes.data, W0.ctypes.data, H0.ctypes.data
+        p.num_sources, p.maxiter, p.tolerance = 1, 3, 1e-3
+        p.multi_backend, p.n_gpus = mb, ng
+        r.W, r.H, r.cost = Wo.ctypes.data, Ho.ctypes.data, cost.ctypes.data
+        assert lib.nmfx_nmf(C.byref(p), C.byref(r)) == L.NMFX_ERR_INVALID
+        assert b"multi_backend" in lib.nmfx_last_error()
+
+
+def test_rccl_lookup_survives_a_library_that_cannot_be_loaded():
+    """ADVICE r5 (high): dlerror() was called twice and the second call's NULL went into a std::string -- SIGSEGV on any dlopen failure.  A bogus
+    NMFX_RCCL_LIB must leave the process alive, and the candidates after it must still be tried"""
+    _lib()
+    import subprocess
+    code = ("import ctypes as C\nfrom nmf_toolbox_amd import _lib\nl = _lib.load()\nv = C.c_int32(0)\n"
+            "p = l.nmfx_rccl_library(C.byref(v))\nprint('path=%r version=%d' % (p, v.value))\n")
+    env = dict(os.environ, NMFX_RCCL_LIB="/nonexistent/librccl.so")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, text=True, capture_output=True)
+    assert res.returncode == 0, (res.returncode, res.stderr[-500:])
+    assert "path=" in res.stdout and "/nonexistent" not in res.stdout
