@@ -408,6 +408,10 @@ def main():
                          "(nmf.m:1 / cnmf.m:1) on float64 host arrays -- prints ingest_s / iterate_s / egress_s / GBps_h2d, not the metric")
     ap.add_argument("--host-dtype", default="f64", choices=["f64", "f32"], help="--api blocking: precision of the host arrays")
     ap.add_argument("--backends", default="", help="--api blocking: comma list of exchange backends to run, one JSON line each (rccl, peer); default with --gpus N > 1: both")
+    ap.add_argument("--numpy-inputs", action="store_true",
+                    help="V, W_init, H_init from numpy.random.RandomState seeds 1000 / 1 / 2 (tests/conftest.py::synth: SURVEY 8(d)'s inputs, the ones every parity test and "
+                         "tests/golden/fullsize_*.npz use) generated on the host and uploaded once, instead of torch.rand on the device; the line then carries "
+                         "`oracle_check`: the run's cost vector against the float64 oracle's fixture for the workload")
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="device spin-up before the W warm-up steps: the W-step partial of the engine (it changes neither W nor H) is launched untimed until this much "
                          "wall time has passed, so that the warm-up and the timed region run at the sustained clock, not on the ramp from idle (rocm-smi: 1.36 -> 2.39 GHz over "
@@ -461,12 +465,22 @@ def main():
     nl = hi - lo
     # synthetic inputs generated in HBM: V = max(U(0,1), eps) per shard (seed 1000+rank), W seed 1, H seed 2+rank
     g = torch.Generator(device=dev)
-    g.manual_seed(1000 + rank)
-    V = torch.rand((nl, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
-    g.manual_seed(1)
-    W = torch.rand((T * K, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)      # identical on every rank
-    g.manual_seed(2 + rank)
-    H = torch.rand((nl, K), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
+    if args.numpy_inputs:
+        # SURVEY 8(d) / tests/conftest.py::synth: the SAME inputs as the oracle fixtures (every rank forms the global arrays and keeps its columns)
+        rs = np.random.RandomState
+        Vn = np.fmax(rs(1000).rand(m, n), 2.0 ** -52)[:, lo:hi]
+        V = torch.from_numpy(np.ascontiguousarray(Vn.T, dtype=np.float32)).to(dev)
+        del Vn
+        Wn = np.fmax(rs(1).rand(m, K) if T == 1 else rs(1).rand(m, K, T), 2.0 ** -52)
+        W = torch.from_numpy(np.ascontiguousarray(Wn.reshape(m, K * T, order="F").T, dtype=np.float32)).to(dev)   # slice t in rows t*K .. t*K+K-1 of the (T*K, m) array
+        H = torch.from_numpy(np.ascontiguousarray(np.fmax(rs(2).rand(K, n), 2.0 ** -52)[:, lo:hi].T, dtype=np.float32)).to(dev)
+    else:
+        g.manual_seed(1000 + rank)
+        V = torch.rand((nl, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
+        g.manual_seed(1)
+        W = torch.rand((T * K, m), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)      # identical on every rank
+        g.manual_seed(2 + rank)
+        H = torch.rand((nl, K), generator=g, device=dev, dtype=torch.float32).clamp_(min=EPS)
     halo = (0, 0)
     if alg == "cnmf" and world > 1 and T > 1:
         # column-sharded cnmf: H gets T-1 halo columns on each inner side, V on the right; the initial halo contents are the
@@ -605,6 +619,20 @@ def main():
             "cost_first_last": [float(c[0]), float(c[-1])], "cost_monotone": bool(np.all(np.diff(c) <= 1e-7 * abs(c[0]))),
             "roofline": roof,
         }
+        out["data"] = "synthetic (numpy RandomState 1000 / 1 / 2, SURVEY 8(d))" if args.numpy_inputs else "synthetic"
+        if args.numpy_inputs:
+            # the run's costs against the float64 oracle's at this geometry (tests/golden/fullsize_*.npz, made by tests/golden/make_fullsize_golden.py; read only --
+            # nothing of oracle/ is executed here).  cost(i) is the cost after iteration i+1 of one uninterrupted run: warm-up and timed steps are one sequence
+            fxname = {"c3": "c3_full", "c2": "c2_full", "c4": "c4_full_euclidean", "c4kl": "c4_full_kl", "c3_shard8": "c3_shard"}.get(args.workload)
+            fxpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "fullsize_%s.npz" % fxname) if fxname else None
+            if fxpath and os.path.exists(fxpath):
+                fc = np.load(fxpath)["cost"]
+                k = int(min(len(fc), len(c)))
+                out["oracle_check"] = {"fixture": "tests/golden/fullsize_%s.npz" % fxname, "entries_compared": k,
+                                       "max_rel_err": float(np.max(np.abs(c[:k] - fc[:k]) / np.abs(fc[:k]))) if k else None,
+                                       "cost_bench": [float(x) for x in c[:k]], "cost_oracle_f64": [float(x) for x in fc[:k]], "contract": 1e-6}
+            else:
+                out["oracle_check"] = {"fixture": None, "note": "no full-size oracle fixture for this workload"}
         out["spinup"] = {"ms": round(spun_ms, 1), "wstep_partial_launches": spun_calls, "note": "untimed, before the warm-up steps; W and H untouched"}
         out["world_size_seen"] = int(dist.get_world_size()) if (world > 1 or force_dist) else 1
         if rank_info:

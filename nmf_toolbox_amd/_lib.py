@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmfx.so")
+# NMFX_LIB_VARIANT=<name>: an A/B build of the kernel switches (build.py --variant), for measurements only
+LIB_PATH = os.path.join(_HERE, "libnmfx_%s.so" % os.environ["NMFX_LIB_VARIANT"] if os.environ.get("NMFX_LIB_VARIANT") else "libnmfx.so")
 
 NMFX_OK, NMFX_ERR_INVALID, NMFX_ERR_NO_DEVICE, NMFX_ERR_HIP, NMFX_ERR_UNSUPPORTED, NMFX_ERR_NOMEM, NMFX_ERR_NEGATIVE = range(7)
 DIV_EUCLIDEAN, DIV_KL, DIV_IS, DIV_AB, DIV_EUCLIDEAN_NOCOST = range(5)

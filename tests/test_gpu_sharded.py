@@ -996,3 +996,27 @@ def test_blocking_api_rccl_backend_refuses_duplicate_devices(gpu_lib):
     used = C.c_int32(0)
     _lib.check(_lib.load().nmfx_last_call_exchange(None, None, C.byref(used)))
     assert used.value == 1
+
+
+def test_blocking_multi_gpu_call_reports_its_own_timing(gpu_lib):
+    """run_mu_multi left nmfx_last_call_timing at whatever an EARLIER call on the thread had written (a warm-up's 4 ms for ten C3 iterations).
+    The three spans now belong to the call: a long sharded call after a short unsharded one reports more iterate time than the short call took in total, at
+    least the time its fused passes need (2 x 2*m*n*K flop per iteration at the fp32 MFMA peak is a floor no run can beat), and they add up to no more than the
+    wall time of the call"""
+    import time
+    from nmf_toolbox_amd import _lib
+    m, n, K, iters = 2048, 8192, 256, 20
+    V, W0, H0 = synth(m, n, K)
+    small = synth(128, 256, 32)
+    gpu_lib.nmf(small[0], 32, dict(divergence="kl", W_init=small[1], H_init=small[2], maxiter=2, tolerance=1e-300))   # what used to be reported afterwards
+    short = _lib.last_call_timing()
+    cfg = dict(divergence="kl", W_init=W0, H_init=H0, maxiter=iters, tolerance=1e-300, nmfx_gpus=[0, 0])
+    t0 = time.perf_counter()
+    gpu_lib.nmf(V, K, cfg)
+    wall = time.perf_counter() - t0
+    tm = _lib.last_call_timing()
+    floor = iters * 8.0 * m * n * K / 157.3e12        # nmf.m:152-153,183-184 on the fused passes: 8*m*n*K flop per iteration
+    assert tm["iterate_s"] >= floor, (tm, floor)
+    assert tm["iterate_s"] > short["iterate_s"] and tm["ingest_s"] > 0 and tm["egress_s"] > 0, (tm, short)
+    assert tm["ingest_s"] + tm["iterate_s"] + tm["egress_s"] <= wall * 1.001, (tm, wall)
+    assert tm["host_bytes_in"] >= 8.0 * (m * n + m * K + K * n), tm
