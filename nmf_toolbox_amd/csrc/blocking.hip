@@ -75,7 +75,8 @@ nmfx_status run_mu(const nmfx_problem *p, nmfx_result *r, int algorithm, const i
     if (algorithm == 1 && p->T > 1 && !fused_supported_T(Kup, p->T))
         for (int kk = Kup + 32; kk <= 256; kk += 32) if (fused_supported_T(kk, p->T)) { Kup = kk; break; }
     const bool pad_cnmf = algorithm == 1 && Kt != Kup && p->T > 1 && fused_supported_T(Kup, p->T) && p->m >= 64 && p->n >= 64 && p->path != 1 &&
-                          (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dv == NMFX_DIV_EUCLIDEAN_NOCOST);
+                          (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dv == NMFX_DIV_EUCLIDEAN_NOCOST ||
+                           ((dv == NMFX_DIV_IS || (dv == NMFX_DIV_AB && p->alpha != 0)) && p->m % 4 == 0));   // (IS / alpha-beta: engine.fusedT_dual, every pair since round 6)
     const bool pad = pad_cnmf || (algorithm != 1 && Kt % 32 != 0 && (Kt <= 256 || ((dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN) && Kt <= 2048 && p->m >= 64 && p->n >= 64)) &&   // (above 256: column blocks, engine.klw / eucw)
                      ((p->m >= 64 && p->n >= 64) || p->path == 2) && p->path != 1 && (dv == NMFX_DIV_KL || dv == NMFX_DIV_EUCLIDEAN || dual_ok));
     const int K = pad ? Kup : Kt;

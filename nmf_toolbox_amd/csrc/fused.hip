@@ -35,12 +35,9 @@ bool fused_supported_T(int Kh, int T) {
     return false;
 }
 
-// ... and the pairs whose S pass also exists in the IS / alpha-beta form that stores both element maps (functors 11 / 13, cost-only form; fused_cnmf_{a,b,c}.hip)
-bool fused_supported_T_dual(int Kh, int T) {
-    static const int ok[][2] = {{64, 8}, {64, 4}, {32, 8}, {32, 16}, {64, 2}, {32, 4}, {128, 2}, {128, 4}};
-    for (const auto &c : ok) if (c[0] == Kh && c[1] == T) return true;
-    return false;
-}
+// ... and the pairs whose S pass also exists in the IS / alpha-beta form that stores both element maps (functors 11 / 13, cost-only form): every pair since
+// round 6 (cnmf.m:179-194,227-231 on the fused passes wherever the euclidean / KL passes run)
+bool fused_supported_T_dual(int Kh, int T) { return fused_supported_T(Kh, T); }
 
 // one translation unit per K group and per extent kind (fused_k*.hip, fused_rag_k*.hip): the instantiations compile in parallel
 #define NMFX_DECL(name) nmfx_status name(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi)

@@ -47,7 +47,9 @@ __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
 //         V tile; nullptr = zeros) and contracts its own <= 256 components: 7 stores the raw partial S (p.Rout), 8 is the last block and goes on
 //         like 3: R = V./S (+ KL cost terms), R stored to p.Rout for the numerator passes; 10 is the last block of a euclidean chain: the residual
 //         sum (V - S).^2 of the accumulated S (functor 1's terms), nothing stored
-//       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc.m:269: the next H step contracts V_hat - V)
+//       1 in the cost-only form with p.Rout: the raw S = V_hat is stored as well (cnmfsc.m:269); 21: the same pass storing the RESIDUAL S - V instead -- all the
+//         sparse-H step of cnmfsc consumes of V_hat (cnmfsc.m:160-168: dH = pos - neg = sum_t W_t' * lshift_t(V_hat - V)): its Q product then streams ONE m x n
+//         operand instead of V_hat and V, and the difference is formed from the fp32 S in registers, before it is rounded to memory
 //       11 / 12 (IS) and 13 / 14 (alpha-beta, alpha ~= 0): the two element maps of functors 4 / 5 as TWO single-map passes, for 192 < K <= 256 where a second
 //         accumulator set no longer fits the register file (nmf.m:154-164,185-195 have no K limit).  11: A = V./S.^2 (+ the IS cost terms), 12: B = 1./S,
 //         13: A = V.^alpha .* S.^(beta-1) (+ the alpha-beta cost terms; D holds V.^alpha), 14: B = S.^(alpha+beta-1).  Each is the KL pass with another map:
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr int BUF = TROWS * LDY;
     constexpr bool NEED_S = FUNC != 0;
     constexpr bool S_IN = FUNC == 7 || FUNC == 8 || FUNC == 10 || FUNC == 19 || FUNC == 20;   // S accumulated over several launches (column blocks of a wide factor)
-    constexpr int MF = FUNC == 8 ? 3 : (FUNC == 10 ? 1 : FUNC);   // the element map
+    constexpr int MF = FUNC == 8 ? 3 : ((FUNC == 10 || FUNC == 21) ? 1 : FUNC);   // the element map
     static_assert(!S_IN || (!DO_G2 && D_RC && TT == 1), "partial-S passes: first product only, W-step form");
     constexpr bool DUAL = FUNC == 4 || FUNC == 5;   // two element maps, two accumulator sets
     // element maps that never look at V (1./S, S.^(a+b-1)): no V loads are issued at all.  They must not merely be left unused: hipcc drops dead loads, and the
@@ -98,6 +100,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S;
+    // the asm form of the first product (NMFX_G1_ASM).  NOT for the chain kernels (S_IN): with it every K > 256 test failed on the hardware (costs off by 3e-4 ... inf,
+    // gpurun_out/r6_01_gputests.log) although the generated code reads right -- the partial-S loads those kernels issue between the MFMAs are the one thing the
+    // other kernels do not have; they keep hipcc's own MFMAs until that is understood (NMFX_G1_ASM_SIN = 1 builds the failing form for experiments)
+    constexpr bool G1A = NMFX_G1_ASM && (NMFX_G1_ASM_SIN || !S_IN);
     constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // packed KL map: micro-ops are per PAIR of elements (8, or 3 without the cost)
     constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the element map (PK: 2*NU per pair)
     constexpr int NUP = PK ? (MF == 3 ? 8 : 3) : 2 * NU;          // micro-ops per pair of elements
@@ -379,7 +385,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 }
             } else {
                 if (u == 0) {
-                    if (MF == 1) { const float e = v - sacc[jb][reg]; tc = live ? fmaf(e, e, tc) : tc; }   // nmf.m:208
+                    if (MF == 1) {   // nmf.m:208
+                        const float e = sacc[jb][reg] - v;
+                        tc = live ? fmaf(e, e, tc) : tc;
+                        if (FUNC == 21) sacc[jb][reg] = e;   // the residual S - V is what this pass leaves in HBM (dead positions: never stored -- row_ok / the store's buffer bounds)
+                    }
                     if (DO_G2 || MF != 1) sacc[jb][reg] = live ? v : 0.0f;   // (cost-only form: S stays, for the optional store below)
                 }
             }
@@ -414,6 +424,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     else if (ph == 0) a_nxt = g1_read(1, 0);
                     auto one = [&](int e, float av) {
 #if NMFX_G1_ASM
+                      if (G1A) {
                         // asm: the S tile in architectural VGPRs (the element map reads it: out of AGPRs that costs one v_accvgpr_read per element) and the
                         // stationary operand in AGPRs (it is only ever an MFMA source; in v0-v127 it left too few VGPRs for the tiles and hipcc shuttled the V tile
                         // through AGPRs).  hipcc itself puts EVERY MFMA result of a kernel that may use more than 256 registers into AGPRs.  Back-to-back MFMAs on
@@ -421,16 +432,16 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                         // (the dual-map kernels at K > 128 hold two output accumulator sets: with the stationary operand as well the AGPR half would overflow)
                         constexpr bool XA = K / 2 + (DO_G2 ? (DUAL ? 2 : 1) * NKB * 16 : 0) <= 256;
                         if (XA) {
-                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
+                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
                             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
                         } else {
-                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
+                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
                             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
                         }
-                        if (ph == 1 && g == 0 && e == 0) mfma_settle(2);   // sacc[0]'s last MFMA is one MFMA back: its 16 passes are over, 2 more until the write has landed
-#else
-                        sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
+                        if (ph == 1 && g == 0 && e == 0) mfma_settle(NMFX_SETTLE_P2);   // sacc[0]'s last MFMA is one MFMA back: its 16 passes are over, 2 more until the write has landed
+                      } else
 #endif
+                        sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
                         if (ph == 1) emap_fill(0, 4 * g + e, 4 * NG);
                         if (ph == 0 && e == 0) dma_some(((g + 1) * ROWS_PER_WAVE + NG - 1) / NG);
                         if (S_IN && ph == 1 && 4 * g + e < 16) load_s_piece(ssn, 4 * g + e);   // partial S of the next tile (sin_ went into sacc at the tile top)
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg) emap_u(1, reg, 0);
         }
 #if NMFX_G1_ASM
-        if (NEED_S) mfma_settle(DO_G2 ? 2 : 18);   // sacc[1]'s last MFMA: one MFMA back when the second product follows (as above), else right behind us (16 passes + 2)
+        if (NEED_S && G1A) mfma_settle(DO_G2 ? NMFX_SETTLE_P2 : 18);   // sacc[1]'s last MFMA: one MFMA back when the second product follows (as above), else right behind us (16 passes + 2)
 #endif
         if (DO_G2) {
             if (STB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA rows (issued under P1) have landed; from here on stores are in flight too
@@ -519,7 +530,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; reg += PK ? 2 : 1)
 #pragma unroll
                 for (int u = 0; u < (PK ? NUP : NU); ++u) emap_u(1, reg, u);
-            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1 || ST2) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
+            if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1 || FUNC == 21 || ST2) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
 #pragma unroll

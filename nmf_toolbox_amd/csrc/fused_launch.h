@@ -35,12 +35,15 @@ static nmfx_status launch_one_T(hipStream_t st, const FusedParams &p, int nsplit
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
-template <int KH, int TT, bool DUALT = false>
+template <int KH, int TT, bool DUALT = true>   // (round 5 instantiated the IS / alpha-beta S pass for eight pairs only; round 6: for every pair)
 static nmfx_status launch_T(hipStream_t st, const FusedParams &p, int nsplit, int func, bool do_g2) {
     if (func == 0 && do_g2) return launch_one_T<KH * TT, 0, true, TT>(st, p, nsplit);
     if (func == 1 && !do_g2) return launch_one_T<KH * TT, 1, false, TT>(st, p, nsplit);
     if (func == 3 && !do_g2) return launch_one_T<KH * TT, 3, false, TT>(st, p, nsplit);   // KL: S pass (cost, optionally R = V./S to HBM)
-    if constexpr (DUALT) {   // IS / alpha-beta: S pass that stores both element maps' values (functors 11 / 13, cost-only form); instantiated for the common pairs only
+    if constexpr (KH <= 128) {   // cnmfsc (K <= 128): the objective pass that leaves the residual S - V in HBM
+        if (func == 21 && !do_g2) return launch_one_T<KH * TT, 21, false, TT>(st, p, nsplit);
+    }
+    if constexpr (DUALT) {   // IS / alpha-beta: S pass that stores both element maps' values (functors 11 / 13, cost-only form)
         if (func == 11 && !do_g2) return launch_one_T<KH * TT, 11, false, TT>(st, p, nsplit);
         if (func == 13 && !do_g2) return launch_one_T<KH * TT, 13, false, TT>(st, p, nsplit);
     }

@@ -718,7 +718,12 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         hpad_of = Hx;
         return NMFX_OK;
     };
-    // (fused) S = sum_t Wx_t * rshift_t(Hx) in registers -> 0.5*||V - S||^2; store: S is kept as V_hat
+    // What the iteration consumes of a stored V_hat: with the sparse-H line search on the fused passes and a W branch that does not read V_hat at all (the
+    // multiplicative branch from the Gram of the stacked shifts, or W fixed) it is ONLY the difference V_hat - V inside dH (cnmfsc.m:160-168).  The objective pass
+    // then leaves that residual in the buffer instead (functor 21): the Q product of dH streams one m x n operand instead of two, and the difference is taken
+    // from the fp32 S in registers instead of from its rounded copy
+    const bool vh_is_resid = fusedsc && !small64h && sH > 0 && !fixH && (gramW || fixW);
+    // (fused) S = sum_t Wx_t * rshift_t(Hx) in registers -> 0.5*||V - S||^2; store: S is kept as V_hat (or S - V, see above)
     auto rfd_fused = [&](const float *Wx, const float *Hx, double *obj, bool store) -> nmfx_status {
         TRY(ensure_hpad(Hx));
         FusedParams f; memset(&f, 0, sizeof(f));
@@ -728,7 +733,7 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
         f.cost_partials = part.as<double>();
         {
             PScope ps(pf, SC_OBJ);
-            TRY(launch_fused(st, f, nsplitT, true, 1, false, 0));
+            TRY(launch_fused(st, f, nsplitT, true, (store && vh_is_resid) ? 21 : 1, false, 0));
         }
         return read_obj(st, part.as<double>(), (int)((m + 127) / 128) * nsplitT, costd.as<double>(), obj);
     };
@@ -800,7 +805,8 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 TRY(transpose_f32(st, H, K, n, HT));                                                 // rows of H / dH contiguous: the projected vectors
                 if (small64h) TRY(resid_hgrad64(st, V.as<float>(), Vh.as<float>(), m, n, W0, K, T, g64h.as<double>()));   // dH' in fp64 (small problems)
                 else {
-                    TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));              // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
+                    if (vh_is_resid) TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));            // dH = sum_t W0_t' * lshift_t(R), R = V_hat - V left by the objective pass
+                    else TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));         // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
                     TRY(transpose_f32(st, G2.as<float>(), K, n, G1.as<float>()));
                 }
                 if (quadsc && (it > 1 || !(sW > 0))) {   // D = W0_flat' * W0_flat, once per search

@@ -12,6 +12,7 @@
 //   NACC     v_accvgpr_read_b32 per tile
 //   BAR      s_barrier per tile
 //   DEP      1: the first product's MFMAs as TWO dependent chains (the kernel) | 0: spread over the eight independent accumulators as well
+//   WHERE    0: the VALU fillers behind all 512 MFMAs | 1: all of them inside the first product (the dependent chains) | 2: all inside the second product
 // Output: one JSON object per variant: ms, TFLOP/s, fraction of the 157.3 TFLOP/s datasheet peak, shader cycles per MFMA (s_memtime) and the shader clock
 // that the s_memtime / s_memrealtime ratio implies.
 #include <hip/hip_runtime.h>
@@ -24,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0>
 __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned long long *clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDY = 260, BUF = 64 * LDY;
@@ -52,10 +53,13 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
         int nv = 0, nt = 0, np = 0, na = 0;
         auto fill = [&]() {   // the fillers due behind MFMA number mf
             ++mf;
-            if (NVALU && nv < NVALU && (long)mf * NVALU / 512 > nv) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv) : "v"(c1)); ++nv; }
-            if (NTRANS && nt < NTRANS && (long)mf * NTRANS / 512 > nt) { asm volatile("v_rcp_f32 %0, %0" : "+v"(ft)); ++nt; }
-            if (NPK && np < NPK && (long)mf * NPK / 512 > np) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(fp) : "v"(fp)); ++np; }
-            if (NACC && na < NACC && (long)mf * NACC / 512 > na) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ar) : "a"(xreg[na & 127])); asm volatile("" :: "v"(ar)); ++na; }
+            if ((WHERE == 1 && mf > 256) || (WHERE == 2 && mf <= 256)) { __builtin_amdgcn_sched_barrier(0); return; }
+            constexpr int SPAN = WHERE == 0 ? 512 : 256;                 // the fillers are spread over this many MFMAs
+            const int mfl = WHERE == 2 ? mf - 256 : mf;
+            if (NVALU && nv < NVALU && (long)mfl * NVALU / SPAN > nv) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv) : "v"(c1)); ++nv; }
+            if (NTRANS && nt < NTRANS && (long)mfl * NTRANS / SPAN > nt) { asm volatile("v_rcp_f32 %0, %0" : "+v"(ft)); ++nt; }
+            if (NPK && np < NPK && (long)mfl * NPK / SPAN > np) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(fp) : "v"(fp)); ++np; }
+            if (NACC && na < NACC && (long)mfl * NACC / SPAN > na) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ar) : "a"(xreg[na & 127])); asm volatile("" :: "v"(ar)); ++na; }
             __builtin_amdgcn_sched_barrier(0);
         };
         // ---- first product: 2 x 128 MFMAs, LDS operand of the next group fetched before this group's MFMAs (as the kernel does)
@@ -130,9 +134,9 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
 
 struct Row { const char *name; double ms, tf; unsigned long long cyc, wall; };
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0>
 Row run(const char *name, int ntiles, float *sink, unsigned long long *clk, int ncu) {
-    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP>;
+    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP, WHERE>;
     const size_t shm = 2 * 64 * 260 * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipEvent_t a, b;
@@ -183,6 +187,11 @@ int main(int argc, char **argv) {
     run<1, 0, 0, 64, 0, 0, 1>("+ LDS b128 + 64 v_pk_fma_f32 per tile", ntiles, sink, clk, ncu);
     run<1, 0, 0, 128, 0, 0, 1>("+ LDS b128 + 128 v_pk_fma_f32 per tile", ntiles, sink, clk, ncu);
     run<1, 0, 0, 0, 64, 0, 1>("+ LDS b128 + 64 v_accvgpr_read per tile", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 1, 1>("+ LDS b128 + 128 v_fma_f32 per tile, ALL inside the first product (dependent MFMA chains)", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 1, 2>("+ LDS b128 + 128 v_fma_f32 per tile, ALL inside the second product (independent accumulators)", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 0, 1>("+ LDS b128 + 128 v_fma_f32 per tile, all inside the first half, first product on independent accumulators", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 0, 0, 0, 1, 1>("+ LDS b128 + 64 v_rcp_f32 per tile, all inside the first product", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 0, 0, 0, 1, 2>("+ LDS b128 + 64 v_rcp_f32 per tile, all inside the second product", ntiles, sink, clk, ncu);
     run<1, 0, 64, 64, 0, 1, 1>("round-6 KL W-step tile without its global loads: LDS b128 + 64 trans + 64 packed + barrier", ntiles, sink, clk, ncu);
     run<2, 64, 64, 0, 64, 1, 1>("round-5 KL W-step tile without its global loads: LDS b32 + 64 trans + 64 fma + 64 accvgpr moves + barrier", ntiles, sink, clk, ncu);
     return 0;

@@ -314,6 +314,53 @@ def test_cnmf_is_and_alpha_beta_on_the_fused_passes(gpu_lib, div, ab, m, n, K, T
     _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1)), ref)
 
 
+# the 17 (K, T) pairs round 5 left on the materialised path for IS / alpha-beta: every pair the euclidean / KL passes serve, fused_supported_T
+_R6_DUAL_PAIRS = [(32, 3), (32, 5), (32, 6), (64, 3), (32, 10), (32, 12), (64, 5), (64, 6), (32, 7), (32, 9), (32, 11), (64, 7), (32, 13), (32, 14), (32, 15), (128, 3), (256, 2)]
+
+
+@pytest.mark.parametrize("K,T", _R6_DUAL_PAIRS)
+def test_cnmf_is_and_alpha_beta_on_the_fused_passes_every_pair(gpu_lib, K, T):
+    """cnmf.m:179-194,227-231 on the fused passes for EVERY instantiated (K, T) pair (round 6): IS on a ragged shape and one alpha-beta pair per case, by name
+    (nmfx_path = 2 refuses a silent materialised V_hat), against the oracle and the materialised path"""
+    from oracle import nmf_oracle as O
+    m, n = 132 + 4 * (K % 7), 300 + 7 * T + K // 2            # m a multiple of 4 (the H-step GEMMs on the stored maps), n ragged
+    V, W0, H0 = synth(m, n, K, T=T)
+    for div, ab in (("is", None), ("ab", [(0.5, 1.5), (2.0, -0.5), (1.0, 0.5)][(K // 32 + T) % 3])):
+        cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=5, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+        if ab:
+            cfg["alpha"], cfg["beta"] = ab
+        ref = O.cnmf(V, K, T, cfg)
+        got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
+        _check(got, ref)
+        dflt = gpu_lib.cnmf(V, K, T, cfg)
+        assert np.array_equal(dflt[0], got[0]) and np.array_equal(dflt[2], got[2])        # the default IS that path
+    _check(gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=1)), ref)
+
+
+@pytest.mark.parametrize("div,ab", [("is", None), ("ab", (0.5, 1.5))])
+@pytest.mark.parametrize("m,n,K,T", [(512, 700, 20, 8), (128, 333, 40, 4), (256, 1024, 100, 2), (200, 600, 7, 16), (256, 700, 20, 2), (200, 500, 96, 4), (300, 900, 150, 2), (256, 600, 30, 13)])
+def test_cnmf_is_and_alpha_beta_any_K_on_the_fused_passes(gpu_lib, div, ab, m, n, K, T):
+    """the parametrisation of test_cnmf_any_K_on_the_fused_passes with div in {is, ab}: K that is not a multiple of 32 (or has no pair of its own) is padded with zero,
+    fixed components up to an instantiated pair by the blocking call, for IS / alpha-beta as for euclidean / KL -- no shape silently materialises V_hat"""
+    from oracle import nmf_oracle as O
+    V, W0, H0 = synth(m, n, K, T=T)
+    cfg = dict(divergence=div, W_init=W0, H_init=H0, maxiter=6, tolerance=1e-12, W_sparsity=0.01, H_sparsity=0.02)
+    if ab:
+        cfg["alpha"], cfg["beta"] = ab
+    ref = O.cnmf(V, K, T, cfg)
+    got = gpu_lib.cnmf(V, K, T, dict(cfg, nmfx_path=2))
+    assert got[0].shape == (m, K, T) and got[1].shape == (K, n)
+    _check(got, ref)
+    _check(gpu_lib.cnmf(V, K, T, cfg), ref)
+    if K >= 7:
+        k1 = K // 3
+        cfg2 = dict(cfg, W_init=[W0[:, :k1], W0[:, k1:]], H_init=[H0[:k1], H0[k1:]], W_sparsity=[0.02, 0.0], H_sparsity=[0.0, 0.0], H_fixed=[False, True], maxiter=4)
+        ref2 = O.cnmf(V, [k1, K - k1], T, cfg2)
+        got2 = gpu_lib.cnmf(V, [k1, K - k1], T, dict(cfg2, nmfx_path=2))
+        assert rel_fro(np.concatenate(got2[0], 1), np.concatenate(ref2[0], 1)) <= 1e-5 and rel_fro(np.vstack(got2[1]), np.vstack(ref2[1])) <= 1e-5
+        assert rel_fro(got2[2], ref2[2]) <= 1e-5
+
+
 def test_cnmf_is_on_the_fused_passes_fixed_factors_sources_and_stop(gpu_lib):
     """the same path with what the engine's generic update kernels add around it: two sources with one fixed W / one fixed H, all of W fixed (the S pass is then
     cost-only), all of H fixed, and the stop rule with the cost lagging one pass"""
