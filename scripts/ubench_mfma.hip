@@ -12,6 +12,8 @@
 //   NACC     v_accvgpr_read_b32 per tile
 //   BAR      s_barrier per tile
 //   DEP      1: the first product's MFMAs as TWO dependent chains (the kernel) | 0: spread over the eight independent accumulators as well
+//   GROUP    the fillers are issued GROUP at a time (behind every GROUP-th of the MFMAs they would otherwise follow one by one): is the cost per instruction
+//            or per interruption of the MFMA stream?
 //   WHERE    0: the VALU fillers behind all 512 MFMAs | 1: all of them inside the first product (the dependent chains) | 2: all inside the second product
 // Output: one JSON object per variant: ms, TFLOP/s, fraction of the 157.3 TFLOP/s datasheet peak, shader cycles per MFMA (s_memtime) and the shader clock
 // that the s_memtime / s_memrealtime ratio implies.
@@ -25,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1>
 __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned long long *clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDY = 260, BUF = 64 * LDY;
@@ -44,6 +46,10 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
     for (int k = 0; k < 8; ++k) asm volatile("" : "+a"(acc[k]));
     float fv = 1.0f + (float)lane, ft = 2.0f + (float)lane, ar = 0.0f;
     float2 fp = {1.0f, 2.0f};
+    float fvs[8], fts[8];
+    float2 fps[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { fvs[q] = fv + (float)q; fts[q] = ft + (float)q; fps[q] = fp; }
     const float c1 = 0.999f;
     const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int t = 0; t < ntiles; ++t) {
@@ -56,9 +62,10 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
             if ((WHERE == 1 && mf > 256) || (WHERE == 2 && mf <= 256)) { __builtin_amdgcn_sched_barrier(0); return; }
             constexpr int SPAN = WHERE == 0 ? 512 : 256;                 // the fillers are spread over this many MFMAs
             const int mfl = WHERE == 2 ? mf - 256 : mf;
-            if (NVALU && nv < NVALU && (long)mfl * NVALU / SPAN > nv) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fv) : "v"(c1)); ++nv; }
-            if (NTRANS && nt < NTRANS && (long)mfl * NTRANS / SPAN > nt) { asm volatile("v_rcp_f32 %0, %0" : "+v"(ft)); ++nt; }
-            if (NPK && np < NPK && (long)mfl * NPK / SPAN > np) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(fp) : "v"(fp)); ++np; }
+            // (independent registers per filler of a group: a group is GROUP issue slots, not a dependent chain)
+            if (NVALU) while (nv < NVALU && (long)mfl * NVALU / SPAN >= nv + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fvs[q & 7]) : "v"(c1)); ++nv; } }
+            if (NTRANS) while (nt < NTRANS && (long)mfl * NTRANS / SPAN >= nt + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_rcp_f32 %0, %0" : "+v"(fts[q & 7])); ++nt; } }
+            if (NPK) while (np < NPK && (long)mfl * NPK / SPAN >= np + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(fps[q & 7]) : "v"(fp)); ++np; } }
             if (NACC && na < NACC && (long)mfl * NACC / SPAN > na) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ar) : "a"(xreg[na & 127])); asm volatile("" :: "v"(ar)); ++na; }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -126,6 +133,8 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
     const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = fv + ft + fp.x + fp.y + ar;
 #pragma unroll
+    for (int q = 0; q < 8; ++q) s += fvs[q] + fts[q] + fps[q].x + fps[q].y;
+#pragma unroll
     for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][7];
     if (DEP) s += sacc[0][0] + sacc[1][3];
     if (s == 12345.678f) sink[0] = s;   // keep everything alive
@@ -134,9 +143,9 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
 
 struct Row { const char *name; double ms, tf; unsigned long long cyc, wall; };
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1>
 Row run(const char *name, int ntiles, float *sink, unsigned long long *clk, int ncu) {
-    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP, WHERE>;
+    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP, WHERE, GROUP>;
     const size_t shm = 2 * 64 * 260 * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipEvent_t a, b;
@@ -192,6 +201,13 @@ int main(int argc, char **argv) {
     run<1, 128, 0, 0, 0, 0, 0, 1>("+ LDS b128 + 128 v_fma_f32 per tile, all inside the first half, first product on independent accumulators", ntiles, sink, clk, ncu);
     run<1, 0, 64, 0, 0, 0, 1, 1>("+ LDS b128 + 64 v_rcp_f32 per tile, all inside the first product", ntiles, sink, clk, ncu);
     run<1, 0, 64, 0, 0, 0, 1, 2>("+ LDS b128 + 64 v_rcp_f32 per tile, all inside the second product", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 1, 0, 2>("+ LDS b128 + 128 v_fma_f32 per tile in groups of 2 (behind every 8th MFMA)", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 1, 0, 4>("+ LDS b128 + 128 v_fma_f32 per tile in groups of 4 (behind every 16th MFMA)", ntiles, sink, clk, ncu);
+    run<1, 128, 0, 0, 0, 0, 1, 0, 8>("+ LDS b128 + 128 v_fma_f32 per tile in groups of 8 (behind every 32nd MFMA)", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 0, 0, 0, 1, 0, 2>("+ LDS b128 + 64 v_rcp_f32 per tile in groups of 2", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 0, 0, 0, 1, 0, 4>("+ LDS b128 + 64 v_rcp_f32 per tile in groups of 4", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 64, 0, 1, 1, 0, 2>("round-6 KL W-step tile, its 64 trans + 64 packed in groups of 2 each", ntiles, sink, clk, ncu);
+    run<1, 0, 64, 64, 0, 1, 1, 0, 4>("round-6 KL W-step tile, its 64 trans + 64 packed in groups of 4 each", ntiles, sink, clk, ncu);
     run<1, 0, 64, 64, 0, 1, 1>("round-6 KL W-step tile without its global loads: LDS b128 + 64 trans + 64 packed + barrier", ntiles, sink, clk, ncu);
     run<2, 64, 64, 0, 64, 1, 1>("round-5 KL W-step tile without its global loads: LDS b32 + 64 trans + 64 fma + 64 accvgpr moves + barrier", ntiles, sink, clk, ncu);
     return 0;
