@@ -17,6 +17,8 @@ constexpr int FT_C = 64;      // streamed rows (contraction tile of the second p
 // written by v_rcp / v_log one instruction earlier needs one wait state on gfx940+ (LLVM: hasTransForwardingHazard) -- the `_t` forms carry it themselves
 __device__ __forceinline__ f32x2 pk_mul_t(f32x2 a, f32x2 b) { f32x2 d; asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_fma_t(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }   // c - a.*b
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
@@ -106,7 +108,6 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     constexpr bool G1A = NMFX_G1_ASM && (NMFX_G1_ASM_SIN || !S_IN);
     constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // packed KL map: micro-ops are per PAIR of elements (8, or 3 without the cost)
     constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the element map (PK: 2*NU per pair)
-    constexpr int NUP = PK ? (MF == 3 ? 8 : 3) : 2 * NU;          // micro-ops per pair of elements
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                                                 : d_srd_fixed;
         float tc = 0.0f;
         float ts = 0.0f;                                      // KL_MODE 1: sum of S - q.*S (natural units; tc is in log2 units)
-        f32x2 tc2 = {0.0f, 0.0f}, ts2 = {0.0f, 0.0f};         // KL_MODE 2: the same two sums, even / odd elements
-        f32x2 es2[2], er2[2], eq2[2];                         // ... and the map's pipeline state per pair
+        f32x2 tc2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, ts2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // KL_MODE 2: the same two sums per pair of a double pair, even / odd elements
+        f32x2 es2[2], er2[2], eq2[2];                         // ... and the map's state for the two pairs of the double pair in flight
         const int cvh = RAG ? tile_rows(t) - 4 * h : 0;       // streamed index 32*jb + (reg&3) + 8*(reg>>2) + 4*h of this tile is real iff its h-free part < cvh
         float es[2], er[2], eq[2];                            // element-map pipeline state: S value, reciprocal / quotient, third temporary
         auto emap_u = [&](int jb, int reg, int u) {           // micro-op u of element (jb, reg); R + divergence terms, nmf.m:152,206-215
@@ -342,34 +343,6 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 if (u == 1) sacc[jb][reg] = live ? __builtin_amdgcn_exp2f(ab_e2 * er[sl]) : 0.0f;
             } else if (FUNC == 6) {                           // residual: R = S - V, cost terms (S - V).^2   (nmfsc.m:139,148)
                 if (u == 0) { const float e = sacc[jb][reg] - v; tc = live ? fmaf(e, e, tc) : tc; sacc[jb][reg] = live ? e : 0.0f; }
-            } else if (PK) {
-                // packed form: `reg` is the EVEN element of the pair (reg, reg + 1), u = 0 .. NUP-1.  sacc[jb][reg], [reg + 1] and d[.. + reg], [.. + reg + 1] are
-                // adjacent registers, so the pairs cost no moves
-                const int ps = (reg >> 1) & 1;
-                const bool live1 = !RAG || (32 * jb + ((reg + 1) & 3) + 8 * ((reg + 1) >> 2)) < cvh;
-                const f32x2 vv = {v, NO_V ? 0.0f : d[jb * 16 + reg + 1]};
-                if (u == 0) { es2[ps].x = sacc[jb][reg]; er2[ps].x = __builtin_amdgcn_rcpf(es2[ps].x); }
-                if (u == 1) { es2[ps].y = sacc[jb][reg + 1]; er2[ps].y = __builtin_amdgcn_rcpf(es2[ps].y); }
-                if (u == 2) {                                                                     // q = V ./ V_hat, both elements
-                    er2[ps] = pk_mul_t(vv, er2[ps]);
-                    sacc[jb][reg] = live ? er2[ps].x : 0.0f;
-                    sacc[jb][reg + 1] = live1 ? er2[ps].y : 0.0f;
-                }
-                if (MF == 3) {
-                    if (u == 3) eq2[ps] = pk_fnma(er2[ps], es2[ps], es2[ps]);                      // S - q.*S  (= S - V up to the rounding of q, see NMFX_KL_MODE)
-                    if (u == 4) er2[ps].x = __builtin_amdgcn_logf(er2[ps].x);                      // log2(q)
-                    if (u == 5) er2[ps].y = __builtin_amdgcn_logf(er2[ps].y);
-                    if (u == 6) {
-                        const f32x2 t = pk_fma_t(vv, er2[ps], tc2);
-                        if (RAG) { tc2.x = live ? t.x : tc2.x; tc2.y = live1 ? t.y : tc2.y; } else tc2 = t;
-                        asm volatile("" : "+v"(tc2));
-                    }
-                    if (u == 7) {
-                        const f32x2 t = pk_add(ts2, eq2[ps]);
-                        if (RAG) { ts2.x = live ? t.x : ts2.x; ts2.y = live1 ? t.y : ts2.y; } else ts2 = t;
-                        asm volatile("" : "+v"(ts2));
-                    }
-                }
             } else if (MF >= 2) {
                 if (u == 0) { es[sl] = sacc[jb][reg]; er[sl] = __builtin_amdgcn_rcpf(es[sl]); }
                 if (u == 1) { er[sl] = v * er[sl]; sacc[jb][reg] = live ? er[sl] : 0.0f; }      // q = V ./ V_hat
@@ -395,13 +368,61 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             }
             if (((MF == 1 || FUNC == 6) && u == 0) || (MF == 3 && NMFX_KL_MODE == 0 && u == 3)) asm volatile("" : "+v"(tc));   // keep the cost terms in place
         };
+        // The packed KL map (PK) in BURSTS.  What an element-map instruction costs the MFMA stream is the interruption, not the instruction: on the skeleton of this
+        // tile (scripts/ubench_mfma.hip, profiles/r6_ubench.md) 128 v_fma_f32 spread one by one take 8.7 points of the MFMA rate, the same 128 in groups of eight 2.8;
+        // 64 v_rcp_f32 3.1 points one by one, 2.6 in groups of four -- as long as a group fits the 64-cycle shadow of the MFMA in front of it (a transcendental is 16
+        // cycles, a packed or plain fp32 instruction 4).  So the map of a half-tile runs per DOUBLE PAIR (4 elements) in three bursts of 48-64 cycles:
+        //   b = 0   4 x v_rcp                                              b = 1   2 x v_pk_mul (q), 2 x v_pk_fma (S - q.*S), 2 x v_log
+        //   b = 2   2 x v_log, 2 x v_pk_fma (V.*log q), 2 x v_pk_add        (functor 2, no cost terms: b = 0 and the two v_pk_mul)
+        // twelve interruptions per half-tile instead of 64.  sacc[jb][reg .. reg + 3] and d[.. + reg ..] are adjacent registers: the pairs cost no moves.
+        constexpr int NBD = MF == 3 ? 3 : 2;                  // bursts per double pair
+        auto emap_burst = [&](int jb, int dp, int b) {
+            const int reg = 4 * dp;
+            const bool lv[4] = {!RAG || (32 * jb + (reg & 3) + 8 * (reg >> 2)) < cvh, !RAG || (32 * jb + ((reg + 1) & 3) + 8 * ((reg + 1) >> 2)) < cvh,
+                                !RAG || (32 * jb + ((reg + 2) & 3) + 8 * ((reg + 2) >> 2)) < cvh, !RAG || (32 * jb + ((reg + 3) & 3) + 8 * ((reg + 3) >> 2)) < cvh};
+            const f32x2 vv[2] = {{NO_V ? 0.0f : d[jb * 16 + reg], NO_V ? 0.0f : d[jb * 16 + reg + 1]}, {NO_V ? 0.0f : d[jb * 16 + reg + 2], NO_V ? 0.0f : d[jb * 16 + reg + 3]}};
+            if (b == 0) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    es2[pr].x = sacc[jb][reg + 2 * pr]; es2[pr].y = sacc[jb][reg + 2 * pr + 1];
+                    er2[pr].x = __builtin_amdgcn_rcpf(es2[pr].x); er2[pr].y = __builtin_amdgcn_rcpf(es2[pr].y);
+                }
+            }
+            if (b == 1) {
+                er2[0] = pk_mul(vv[0], er2[0]);                                               // q = V ./ V_hat  (the reciprocals are a burst old: no transcendental-use hazard)
+                er2[1] = pk_mul(vv[1], er2[1]);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    sacc[jb][reg + 2 * pr] = lv[2 * pr] ? er2[pr].x : 0.0f;
+                    sacc[jb][reg + 2 * pr + 1] = lv[2 * pr + 1] ? er2[pr].y : 0.0f;
+                }
+                if (MF == 3) {
+                    eq2[0] = pk_fnma(er2[0], es2[0], es2[0]);                                 // S - q.*S  (= S - V up to the rounding of q, see NMFX_KL_MODE)
+                    eq2[1] = pk_fnma(er2[1], es2[1], es2[1]);
+                    er2[0].x = __builtin_amdgcn_logf(er2[0].x); er2[0].y = __builtin_amdgcn_logf(er2[0].y);   // log2(q), first pair
+                }
+            }
+            if (b == 2 && MF == 3) {
+                er2[1].x = __builtin_amdgcn_logf(er2[1].x); er2[1].y = __builtin_amdgcn_logf(er2[1].y);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const f32x2 t = pr == 0 ? pk_fma(vv[0], er2[0], tc2[0]) : pk_fma_t(vv[1], er2[1], tc2[1]);   // (the second pair's logarithms were issued just above)
+                    const f32x2 u = pk_add(ts2[pr], eq2[pr]);
+                    if (RAG) {
+                        tc2[pr].x = lv[2 * pr] ? t.x : tc2[pr].x; tc2[pr].y = lv[2 * pr + 1] ? t.y : tc2[pr].y;
+                        ts2[pr].x = lv[2 * pr] ? u.x : ts2[pr].x; ts2[pr].y = lv[2 * pr + 1] ? u.y : ts2[pr].y;
+                    } else { tc2[pr] = t; ts2[pr] = u; }
+                    asm volatile("" : "+v"(tc2[pr]), "+v"(ts2[pr]));
+                }
+            }
+        };
         // fillers behind the i-th MFMA of a phase with M MFMAs that hosts the 16 elements x NU micro-ops of half jb: slot i runs
         // micro-ops [16*NU*i/M, 16*NU*(i+1)/M) in element order (NU = 4: one every other MFMA at K = 256, one each at 128, two at 64, four at 32)
         auto emap_fill = [&](int jb, int i, int M) {
-            if (PK) {   // 8 pairs x NUP micro-ops, pair by pair
-                const int q0 = 8 * NUP * i / M, q1 = 8 * NUP * (i + 1) / M;
+            if (PK) {   // 4 double pairs x NBD bursts: burst q sits behind MFMA (2q + 1) * M / (2 * 4 * NBD) of the phase
 #pragma unroll
-                for (int q = q0; q < q1; ++q) emap_u(jb, 2 * (q / NUP), q % NUP);
+                for (int q = 0; q < 4 * NBD; ++q)
+                    if ((2 * q + 1) * M / (8 * NBD) == i) emap_burst(jb, q / NBD, q % NBD);
                 return;
             }
             const int q0 = 16 * NU * i / M, q1 = 16 * NU * (i + 1) / M;
@@ -526,10 +547,15 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // are in flight (the R stores and V loads below would push the count past what s_waitcnt can express at the tile top)
             if (S_IN) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (PK) {
 #pragma unroll
-            for (int reg = 0; reg < 16; reg += PK ? 2 : 1)
+                for (int q = 0; q < 4 * NBD; ++q) emap_burst(1, q / NBD, q % NBD);
+            } else {
 #pragma unroll
-                for (int u = 0; u < (PK ? NUP : NU); ++u) emap_u(1, reg, u);
+                for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) emap_u(1, reg, u);
+            }
             if (D_RC && ((MF >= 2 && MF <= 3) || FUNC == 7 || FUNC == 1 || FUNC == 21 || ST2) && p.Rout) {   // wave-uniform: this pass also leaves R = V./S in HBM (KL cnmf: the numerator passes read it)
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.Rout + p.ldd * (cbeg + (long)t * FT_C)), 0, (int)(unsigned)(tile_rows(t) * p.ldd * 4), 0x00020000);
                 if (row_ok) {
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         }
         dma_some(ROWS_PER_WAVE);
         // rows past R hold garbage (possibly NaN): theirs alone, never summed.  KL (modes 1 / 2): tc is in log2 units, ts in natural ones
-        if (MF == 3 && NMFX_KL_MODE == 2) cost += row_ok ? ((double)tc2.x + (double)tc2.y) * 0.6931471805599453 + ((double)ts2.x + (double)ts2.y) : 0.0;
+        if (MF == 3 && NMFX_KL_MODE == 2) cost += row_ok ? ((double)tc2[0].x + (double)tc2[0].y + (double)tc2[1].x + (double)tc2[1].y) * 0.6931471805599453 + ((double)ts2[0].x + (double)ts2[0].y + (double)ts2[1].x + (double)ts2[1].y) : 0.0;
         else if (MF == 3 && NMFX_KL_MODE == 1) cost += row_ok ? (double)tc * 0.6931471805599453 + (double)ts : 0.0;
         else cost += row_ok ? (double)tc : 0.0;
     }

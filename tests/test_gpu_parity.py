@@ -1105,7 +1105,10 @@ def test_cnmf_fused_fixed_factors_frobenius_and_refusals(gpu_lib):
     _check_stop(got[2], ref[2], 2.0)
     if len(got[2]) == len(ref[2]):
         assert rel_fro(got[0], ref[0]) <= TOL and rel_fro(got[1], ref[1]) <= TOL
-    with pytest.raises(Exception, match="not eligible"):
-        gpu_lib.cnmf(V[:, :300], 32, 3, dict(divergence="is", maxiter=1, nmfx_path=2))                  # IS / alpha-beta on the fused passes: the eight common (K, T) pairs only
+    # (round 5 refused IS / alpha-beta by name outside eight (K, T) pairs; since round 6 every pair has the S pass: test_cnmf_is_and_alpha_beta_on_the_fused_passes_every_pair)
+    rs = np.random.RandomState(7)
+    Wi, Hi = np.fmax(rs.rand(V.shape[0], 32, 3), 1e-3), np.fmax(rs.rand(32, 300), 1e-3)
+    cfg_is = dict(divergence="is", W_init=Wi, H_init=Hi, maxiter=2, tolerance=1e-12)
+    _check(gpu_lib.cnmf(V[:, :300], 32, 3, dict(cfg_is, nmfx_path=2)), O.cnmf(V[:, :300], 32, 3, cfg_is))
     with pytest.raises(Exception, match="not eligible"):
         gpu_lib.cnmf(V[:, :300], 100, 7, dict(maxiter=1, nmfx_path=2))                                  # no pair with T = 7 reaches K = 100, padded or not
