@@ -17,8 +17,6 @@ constexpr int FT_C = 64;      // streamed rows (contraction tile of the second p
 // written by v_rcp / v_log one instruction earlier needs one wait state on gfx940+ (LLVM: hasTransForwardingHazard) -- the `_t` forms carry it themselves
 __device__ __forceinline__ f32x2 pk_mul_t(f32x2 a, f32x2 b) { f32x2 d; asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_fma_t(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }   // c - a.*b
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
@@ -389,8 +387,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 }
             }
             if (b == 1) {
-                er2[0] = pk_mul(vv[0], er2[0]);                                               // q = V ./ V_hat  (the reciprocals are a burst old: no transcendental-use hazard)
-                er2[1] = pk_mul(vv[1], er2[1]);
+                // q = V ./ V_hat.  (Always the `_t` forms behind a transcendental, however far back it was issued in the source: with few MFMAs per phase (K <= 64), in
+                // the cost-only form, or when hipcc sinks a v_rcp to its use, producer and consumer end up adjacent -- round 6's first burst version returned NaN there)
+                er2[0] = pk_mul_t(vv[0], er2[0]);
+                er2[1] = pk_mul_t(vv[1], er2[1]);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     sacc[jb][reg + 2 * pr] = lv[2 * pr] ? er2[pr].x : 0.0f;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 er2[1].x = __builtin_amdgcn_logf(er2[1].x); er2[1].y = __builtin_amdgcn_logf(er2[1].y);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    const f32x2 t = pr == 0 ? pk_fma(vv[0], er2[0], tc2[0]) : pk_fma_t(vv[1], er2[1], tc2[1]);   // (the second pair's logarithms were issued just above)
+                    const f32x2 t = pk_fma_t(vv[pr], er2[pr], tc2[pr]);
                     const f32x2 u = pk_add(ts2[pr], eq2[pr]);
                     if (RAG) {
                         tc2[pr].x = lv[2 * pr] ? t.x : tc2[pr].x; tc2[pr].y = lv[2 * pr + 1] ? t.y : tc2[pr].y;
