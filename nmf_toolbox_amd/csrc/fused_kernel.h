@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // tile-top wait below counts on exactly 32 V loads standing behind the DMA rows in the in-order counter -- with fewer, `vmcnt(32)` returns before the rows
     // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
     constexpr bool NO_V = FUNC == 12 || FUNC == 14;
+    constexpr int NVL = (!D_RC && !RAG) ? 8 : 32;   // V-load instructions per tile (load_d_piece)
     constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
     // 19 / 20: the LAST block of an IS / alpha-beta chain over a factor wider than 256 (like 8 for KL): the accumulated S goes through map 11 / 13 and both maps'
     // values are stored
@@ -205,6 +206,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         } else if ((i & 1) == 0) {
             const int f = i >> 1, jb = f >> 2, q = f & 3;
             const int soff = (int)((cbeg + (long)t * FT_C + 32 * jb + 8 * q) * 4);
+            if (!RAG) {   // tile-aligned extents: the four floats are one 16-byte load (8 VMEM instructions a tile instead of 32)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(srd, d_voff, soff, 0);
+                d[jb * 16 + 4 * q + 0] = __builtin_bit_cast(float, q4.x); d[jb * 16 + 4 * q + 1] = __builtin_bit_cast(float, q4.y);
+                d[jb * 16 + 4 * q + 2] = __builtin_bit_cast(float, q4.z); d[jb * 16 + 4 * q + 3] = __builtin_bit_cast(float, q4.w);
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 d[jb * 16 + 4 * q + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, soff + 4 * e, 0));
@@ -249,7 +257,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // hipcc places its own, conservative vmcnt waits before the first use of d[] (it does not count the asm DMA loads).
             // EARLY: the DMA rows of tile t > 0 were waited for behind P2 of tile t-1 (see there)
             if (EARLY || STB) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            else if (NEED_S && !NO_V) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (NEED_S && !NO_V) {
+                // (NVL = the V-load INSTRUCTIONS of a tile: 32 dword loads, or 8 dwordx4 in the H-step form on tile-aligned extents -- the count this wait hangs on)
+                if (NVL == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // everyone's rows landed; buffer b^1 is free again
         }

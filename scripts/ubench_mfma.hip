@@ -14,6 +14,8 @@
 //   DEP      1: the first product's MFMAs as TWO dependent chains (the kernel) | 0: spread over the eight independent accumulators as well
 //   GROUP    the fillers are issued GROUP at a time (behind every GROUP-th of the MFMAs they would otherwise follow one by one): is the cost per instruction
 //            or per interruption of the MFMA stream?
+//   NVM      global loads per tile (buffer_load_dword from an L2-resident array, results unused until the end of the tile), GROUP at a time: what the V tile's 32
+//            loads and the 16 LDS-DMA rows of the real kernel cost as instructions in the stream
 //   WHERE    0: the VALU fillers behind all 512 MFMAs | 1: all of them inside the first product (the dependent chains) | 2: all inside the second product
 // Output: one JSON object per variant: ms, TFLOP/s, fraction of the 157.3 TFLOP/s datasheet peak, shader cycles per MFMA (s_memtime) and the shader clock
 // that the s_memtime / s_memrealtime ratio implies.
@@ -27,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1, int NVM = 0>
 __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned long long *clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LDY = 260, BUF = 64 * LDY;
@@ -51,12 +53,18 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
 #pragma unroll
     for (int q = 0; q < 8; ++q) { fvs[q] = fv + (float)q; fts[q] = ft + (float)q; fps[q] = fp; }
     const float c1 = 0.999f;
+    const __amdgpu_buffer_rsrc_t gsrd = __builtin_amdgcn_make_buffer_rsrc((void *)(sink + 64 + 2048 * (blockIdx.x & 7)), 0, 16384 * 4, 0x00020000);
+    const int gvoff = lane * 4;
+    float vsum = 0.0f;
     const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int t = 0; t < ntiles; ++t) {
         if (BAR) __syncthreads();
         const float *Yt = lds + (t & 1) * BUF;
         int mf = 0;   // MFMAs issued so far in this tile (compile time after unrolling)
-        int nv = 0, nt = 0, np = 0, na = 0;
+        int nv = 0, nt = 0, np = 0, na = 0, nm = 0;
+        float vm[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) vm[q] = 0.0f;
         auto fill = [&]() {   // the fillers due behind MFMA number mf
             ++mf;
             if ((WHERE == 1 && mf > 256) || (WHERE == 2 && mf <= 256)) { __builtin_amdgcn_sched_barrier(0); return; }
@@ -66,6 +74,7 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
             if (NVALU) while (nv < NVALU && (long)mfl * NVALU / SPAN >= nv + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fvs[q & 7]) : "v"(c1)); ++nv; } }
             if (NTRANS) while (nt < NTRANS && (long)mfl * NTRANS / SPAN >= nt + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_rcp_f32 %0, %0" : "+v"(fts[q & 7])); ++nt; } }
             if (NPK) while (np < NPK && (long)mfl * NPK / SPAN >= np + GROUP) { for (int q = 0; q < GROUP; ++q) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(fps[q & 7]) : "v"(fp)); ++np; } }
+            if (NVM) while (nm < NVM && (long)mfl * NVM / SPAN >= nm + GROUP) { for (int q = 0; q < GROUP; ++q) { vm[nm & 31] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gsrd, gvoff, 256 * (nm & 31), 0)); ++nm; } }
             if (NACC && na < NACC && (long)mfl * NACC / SPAN > na) { asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(ar) : "a"(xreg[na & 127])); asm volatile("" :: "v"(ar)); ++na; }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -129,6 +138,10 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) y_cur[kb] = y_nxt[kb];
         }
+        if (NVM) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) asm volatile("" :: "v"(vm[q]));   // the loads must happen; their values are not needed
+        }
     }
     const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = fv + ft + fp.x + fp.y + ar;
@@ -143,9 +156,9 @@ __global__ __launch_bounds__(256, 1) void skel(int ntiles, float *sink, unsigned
 
 struct Row { const char *name; double ms, tf; unsigned long long cyc, wall; };
 
-template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1>
+template <int LDS, int NVALU, int NTRANS, int NPK, int NACC, int BAR, int DEP, int WHERE = 0, int GROUP = 1, int NVM = 0>
 Row run(const char *name, int ntiles, float *sink, unsigned long long *clk, int ncu) {
-    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP, WHERE, GROUP>;
+    auto k = skel<LDS, NVALU, NTRANS, NPK, NACC, BAR, DEP, WHERE, GROUP, NVM>;
     const size_t shm = 2 * 64 * 260 * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipEvent_t a, b;
@@ -181,7 +194,7 @@ int main(int argc, char **argv) {
     printf("{\"device\": \"%s\", \"CUs\": %d, \"clockRate_kHz\": %d, \"tiles\": %d}\n", prop.gcnArchName, ncu, prop.clockRate, ntiles);
     float *sink;
     unsigned long long *clk;
-    CK(hipMalloc(&sink, 64)); CK(hipMalloc(&clk, 64));
+    CK(hipMalloc(&sink, 64 + 4 * (64 + 8 * 2048 + 16384))); CK(hipMemset(sink, 0, 64 + 4 * (64 + 8 * 2048 + 16384))); CK(hipMalloc(&clk, 64));
     //    LDS NVALU NTRANS NPK NACC BAR DEP
     run<0, 0, 0, 0, 0, 0, 0>("mfma only, 8 independent accumulators", ntiles, sink, clk, ncu);
     run<0, 0, 0, 0, 0, 0, 1>("mfma only, first product as two dependent chains (the kernel's dependency structure)", ntiles, sink, clk, ncu);
@@ -206,6 +219,10 @@ int main(int argc, char **argv) {
     run<1, 128, 0, 0, 0, 0, 1, 0, 8>("+ LDS b128 + 128 v_fma_f32 per tile in groups of 8 (behind every 32nd MFMA)", ntiles, sink, clk, ncu);
     run<1, 0, 64, 0, 0, 0, 1, 0, 2>("+ LDS b128 + 64 v_rcp_f32 per tile in groups of 2", ntiles, sink, clk, ncu);
     run<1, 0, 64, 0, 0, 0, 1, 0, 4>("+ LDS b128 + 64 v_rcp_f32 per tile in groups of 4", ntiles, sink, clk, ncu);
+    run<1, 0, 0, 0, 0, 0, 1, 0, 1, 32>("+ LDS b128 + 32 global loads per tile, one by one", ntiles, sink, clk, ncu);
+    run<1, 0, 0, 0, 0, 0, 1, 0, 2, 32>("+ LDS b128 + 32 global loads per tile in groups of 2 (the kernel's V loads)", ntiles, sink, clk, ncu);
+    run<1, 0, 0, 0, 0, 0, 1, 0, 8, 32>("+ LDS b128 + 32 global loads per tile in groups of 8", ntiles, sink, clk, ncu);
+    run<1, 0, 0, 0, 0, 0, 1, 2, 2, 32>("+ LDS b128 + 32 global loads per tile in groups of 2, all inside the second product", ntiles, sink, clk, ncu);
     run<1, 0, 64, 64, 0, 1, 1, 0, 2>("round-6 KL W-step tile, its 64 trans + 64 packed in groups of 2 each", ntiles, sink, clk, ncu);
     run<1, 0, 64, 64, 0, 1, 1, 0, 4>("round-6 KL W-step tile, its 64 trans + 64 packed in groups of 4 each", ntiles, sink, clk, ncu);
     run<1, 0, 64, 64, 0, 1, 1>("round-6 KL W-step tile without its global loads: LDS b128 + 64 trans + 64 packed + barrier", ntiles, sink, clk, ncu);
