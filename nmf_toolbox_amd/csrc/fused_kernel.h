@@ -208,9 +208,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             const int soff = (int)((cbeg + (long)t * FT_C + 32 * jb + 8 * q) * 4);
             if (!RAG) {   // tile-aligned extents: the four floats are one 16-byte load (8 VMEM instructions a tile instead of 32)
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(srd, d_voff, soff, 0);
-                d[jb * 16 + 4 * q + 0] = __builtin_bit_cast(float, q4.x); d[jb * 16 + 4 * q + 1] = __builtin_bit_cast(float, q4.y);
-                d[jb * 16 + 4 * q + 2] = __builtin_bit_cast(float, q4.z); d[jb * 16 + 4 * q + 3] = __builtin_bit_cast(float, q4.w);
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                // (the WHOLE vector is cast: a bit_cast applied to one element of an ext_vector value reads element 0 for every index -- hipcc 7.2, -O3; the same trap
+                // as in the R store below)
+                const f32x4 q4 = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(srd, d_voff, soff, 0));
+                d[jb * 16 + 4 * q + 0] = q4.x; d[jb * 16 + 4 * q + 1] = q4.y; d[jb * 16 + 4 * q + 2] = q4.z; d[jb * 16 + 4 * q + 3] = q4.w;
                 return;
             }
 #pragma unroll
