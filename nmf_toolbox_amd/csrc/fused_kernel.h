@@ -617,10 +617,16 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     }
         } else {
             // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
+            // Order of the sweep (NMFX_G2_VEC): the four MFMAs of a 128-float chunk carry k = 128*c + 4*i + {0, 1, 2, 3}, so they are visited innermost -- a lane's
+            // consecutive accesses are then 16 (H) / 32 (master) contiguous bytes, and registers reg .. reg + 3 of both half-waves complete a 128-byte line of column r
+            // within a few instructions.  Visited MFMA by MFMA, every 4-byte store was its own partial line: 1.23e9 B written per H-step pass at C3 where the
+            // arrays are 2.0e8 B (profiles/r6_07_c3_pmc.md)
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
+            for (int q = 0; q < 16 * NKB; ++q) {
+                    // G2_VEC: q -> (chunk c, reg, j) with kb = 4*c + j inside the full chunks, then the remainder MFMAs reg-major; else kb-major as before
+                    const int full = 4 * G2_NFULL * 16;                                  // (kb, reg) pairs inside full chunks
+                    const int kb = !NMFX_G2_VEC ? q / 16 : (q < full ? 4 * (q / 64) + (q & 3) : 4 * G2_NFULL + (q - full) % (G2_WREM > 0 ? G2_WREM : 1));
+                    const int reg = !NMFX_G2_VEC ? q % 16 : (q < full ? (q % 64) >> 2 : (q - full) / (G2_WREM > 0 ? G2_WREM : 1));
                     const int k = g2_kloc(kb, rowmap(reg, h));   // (EPI 1: TT == 1, one block)
                     if (!row_ok || (p.fix && p.fix[k])) continue;
                     const long idx = (long)k + (long)K * r;
