@@ -621,10 +621,37 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             // consecutive accesses are then 16 (H) / 32 (master) contiguous bytes, and registers reg .. reg + 3 of both half-waves complete a 128-byte line of column r
             // within a few instructions.  Visited MFMA by MFMA, every 4-byte store was its own partial line: 1.23e9 B written per H-step pass at C3 where the
             // arrays are 2.0e8 B (profiles/r6_07_c3_pmc.md)
+            // The common case (float64 master, no fixed rows, the ratio rule) in whole lines: registers 4*rg .. 4*rg + 3 of the four MFMAs of chunk c are 16 CONSECUTIVE
+            // k of column r -- k0 = 128*c + 32*rg + 16*h, offset 4*(reg & 3) + j -- i.e. one 128-byte line of the master and half a line of H per lane: all loads, then
+            // the arithmetic, then the stores back to back, so that a line is written while it is still whole in the L2 (same formulas, element by element)
+            bool lines_done = false;
+            if (NMFX_G2_VEC && !DUAL && G2_NFULL > 0 && p.H64 && !p.fix && !p.sqrt_rule) {   // (wave-uniform)
+                lines_done = true;
+#pragma unroll
+                for (int c = 0; c < G2_NFULL; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if (!row_ok) continue;
+                        const int k0 = 128 * c + 32 * rg + 16 * h;
+                        const long idx0 = (long)k0 + (long)K * r;
+                        double hv[16], dn[16];
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) hv[o] = p.H64[idx0 + o];
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) dn[o] = (p.den ? (double)p.den[idx0 + o] : p.denvec[k0 + o]) + (p.lam ? (double)p.lam[k0 + o] : 0.0);
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) hv[o] = hv[o] * ((double)acc[4 * c + (o & 3)][4 * rg + (o >> 2)] / fmax(dn[o], 2.220446049250313e-16));
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) p.H64[idx0 + o] = hv[o];
+#pragma unroll
+                        for (int o = 0; o < 16; ++o) p.Hio[idx0 + o] = (float)hv[o];
+                    }
+            }
 #pragma unroll
             for (int q = 0; q < 16 * NKB; ++q) {
                     // G2_VEC: q -> (chunk c, reg, j) with kb = 4*c + j inside the full chunks, then the remainder MFMAs reg-major; else kb-major as before
                     const int full = 4 * G2_NFULL * 16;                                  // (kb, reg) pairs inside full chunks
+                    if (lines_done && q < full) continue;
                     const int kb = !NMFX_G2_VEC ? q / 16 : (q < full ? 4 * (q / 64) + (q & 3) : 4 * G2_NFULL + (q - full) % (G2_WREM > 0 ? G2_WREM : 1));
                     const int reg = !NMFX_G2_VEC ? q % 16 : (q < full ? (q % 64) >> 2 : (q - full) / (G2_WREM > 0 ? G2_WREM : 1));
                     const int k = g2_kloc(kb, rowmap(reg, h));   // (EPI 1: TT == 1, one block)
