@@ -88,6 +88,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // have landed and the tile is read half-written (found in round 4 as run-to-run differences of IS with K = 256 on three shards)
     constexpr bool NO_V = FUNC == 12 || FUNC == 14;
     constexpr int NVL = (!D_RC && !RAG) ? 8 : 32;   // V-load instructions per tile (load_d_piece)
+    // H-step form (D_RC false): the two sources of the second product's MFMA change places, which TRANSPOSES the accumulator -- acc[kb][reg] = O(k <-> lane, r <->
+    // register) instead of O(k <-> register, r <-> lane).  The output of this form is K-contiguous (H, or a K x n slab), so a lane then owns 4 consecutive k of a column and
+    // 32 lanes write 512 contiguous bytes of it; with r on the lanes every store instruction scattered 64 four-byte pieces at stride K, and once NMFX_G2_VEC had
+    // changed which k a register holds the L2 no longer merged them: 1.2e9 B written per H-step pass at C3 for 2.0e8 B of H and its master (profiles/r6_10_*_pmc.md)
+    constexpr bool SWAP = !D_RC && NMFX_G2_VEC;
     constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
     // 19 / 20: the LAST block of an IS / alpha-beta chain over a factor wider than 256 (like 8 for KL): the accumulated S goes through map 11 / 13 and both maps'
     // values are stored
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 const float rr2 = DUAL ? sacc2[jb][reg] : 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
-                    acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
+                    acc[kb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(rr, y_cur[kb], acc[kb], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
                     if (jb == 0 && NEED_S) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
                     if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 24 < ROWS_PER_WAVE ? (st + 1) * ROWS_PER_WAVE / 24 : ROWS_PER_WAVE);   // no first product: the DMA rides here, done by step 24
                     if (kb == NKB / 2 && jb == (NEED_S ? 1 : 0)) load_d_piece(dsn, tn, reg);   // V tile of the next step, in flight under P4 (no first product: under P3 already)
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (DUAL) {
-                        acc2[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr2, acc2[kb], 0, 0, 0);
+                        acc2[kb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(rr2, y_cur[kb], acc2[kb], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr2, acc2[kb], 0, 0, 0);
                         if (jb == 0) emap_fill(1, (reg * NKB + kb) * 2 + 1, 32 * NKB);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -602,61 +607,58 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         else cost += row_ok ? (double)tc : 0.0;
     }
 
-    // epilogue: acc[kb][reg] = O(k = (kb / G2_KB)*KH + g2_kloc(kb % G2_KB, rowmap(reg,h)), r)
+    // epilogue: acc[kb][reg] = O(k, r) with k = (kb / G2_KB)*KH + g2_kloc(kb % G2_KB, i), where i = rowmap(reg, h) and r = this lane's row -- or, SWAP, i = the lane and
+    // r = r0 + rowmap(reg, h)
+    auto e_kloc = [&](int kb, int reg) -> int { return g2_kloc(kb % G2_KB, SWAP ? l31 : rowmap(reg, h)); };
+    auto e_row = [&](int reg) -> long { return SWAP ? r0 + rowmap(reg, h) : r; };
+    auto e_ok = [&](int reg) -> bool { return !RAG || e_row(reg) < p.R; };
     if (DO_G2) {
         if (EPI == 0) {
             float *out = p.out + (long)blockIdx.y * p.slab_stride + (TT == 1 ? (long)blockIdx.z * p.oz_stride : 0L);
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    if (row_ok) {
-                        const long oi = r * p.os_r + (long)g2_kloc(kb % G2_KB, rowmap(reg, h)) * p.os_k + (long)(TT - 1 - kb / G2_KB) * p.os_t;
-                        out[oi] = acc[kb][reg];
-                        if (DUAL) p.out2[(long)blockIdx.y * p.slab_stride + oi] = acc2[kb][reg];
-                    }
+            for (int q = 0; q < 16 * NKB; ++q) {
+                const int kb = SWAP ? q % NKB : q / 16, reg = SWAP ? q / NKB : q % 16;   // SWAP: the MFMAs innermost -- a lane's consecutive k
+                if (e_ok(reg)) {
+                    const long oi = e_row(reg) * p.os_r + (long)e_kloc(kb, reg) * p.os_k + (long)(TT - 1 - kb / G2_KB) * p.os_t;
+                    out[oi] = acc[kb][reg];
+                    if (DUAL) p.out2[(long)blockIdx.y * p.slab_stride + oi] = acc2[kb][reg];
+                }
+            }
         } else {
             // H(k, j=r) <- H .* (G ./ max(den + lambda, eps))      nmf.m:199   (den: matrix K x n, or per-row vector for KL)
-            // Order of the sweep (NMFX_G2_VEC): the four MFMAs of a 128-float chunk carry k = 128*c + 4*i + {0, 1, 2, 3}, so they are visited innermost -- a lane's
-            // consecutive accesses are then 16 (H) / 32 (master) contiguous bytes, and registers reg .. reg + 3 of both half-waves complete a 128-byte line of column r
-            // within a few instructions.  Visited MFMA by MFMA, every 4-byte store was its own partial line: 1.23e9 B written per H-step pass at C3 where the
-            // arrays are 2.0e8 B (profiles/r6_07_c3_pmc.md)
-            // The common case (float64 master, no fixed rows, the ratio rule) in whole lines: registers 4*rg .. 4*rg + 3 of the four MFMAs of chunk c are 16 CONSECUTIVE
-            // k of column r -- k0 = 128*c + 32*rg + 16*h, offset 4*(reg & 3) + j -- i.e. one 128-byte line of the master and half a line of H per lane: all loads, then
-            // the arithmetic, then the stores back to back, so that a line is written while it is still whole in the L2 (same formulas, element by element)
+            // (EPI 1 is the H-step form: SWAP whenever NMFX_G2_VEC.)  The common case -- float64 master, no fixed rows, the ratio rule -- in vectors: the four MFMAs of
+            // chunk c hold k = 128*c + 4*lane + {0, 1, 2, 3} of column r(reg): 32 bytes of the master and 16 of H per lane, 1 KB / 512 B contiguous per half-wave
             bool lines_done = false;
-            if (NMFX_G2_VEC && !DUAL && G2_NFULL > 0 && p.H64 && !p.fix && !p.sqrt_rule) {   // (wave-uniform)
+            if (SWAP && !DUAL && G2_NFULL > 0 && p.H64 && !p.fix && !p.sqrt_rule) {   // (wave-uniform)
                 lines_done = true;
 #pragma unroll
-                for (int c = 0; c < G2_NFULL; ++c)
+                for (int reg = 0; reg < 16; ++reg) {
+                    if (!e_ok(reg)) continue;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        if (!row_ok) continue;
-                        const int k0 = 128 * c + 32 * rg + 16 * h;
-                        const long idx0 = (long)k0 + (long)K * r;
-                        double hv[16], dn[16];
+                    for (int c = 0; c < G2_NFULL; ++c) {
+                        const int k0 = 128 * c + 4 * l31;
+                        const long idx0 = (long)k0 + (long)K * e_row(reg);
+                        double hv[4], dn[4];
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) hv[o] = p.H64[idx0 + o];
+                        for (int o = 0; o < 4; ++o) hv[o] = p.H64[idx0 + o];
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) dn[o] = (p.den ? (double)p.den[idx0 + o] : p.denvec[k0 + o]) + (p.lam ? (double)p.lam[k0 + o] : 0.0);
+                        for (int o = 0; o < 4; ++o) dn[o] = (p.den ? (double)p.den[idx0 + o] : p.denvec[k0 + o]) + (p.lam ? (double)p.lam[k0 + o] : 0.0);
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) hv[o] = hv[o] * ((double)acc[4 * c + (o & 3)][4 * rg + (o >> 2)] / fmax(dn[o], 2.220446049250313e-16));
+                        for (int o = 0; o < 4; ++o) hv[o] = hv[o] * ((double)acc[4 * c + o][reg] / fmax(dn[o], 2.220446049250313e-16));
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) p.H64[idx0 + o] = hv[o];
+                        for (int o = 0; o < 4; ++o) p.H64[idx0 + o] = hv[o];
 #pragma unroll
-                        for (int o = 0; o < 16; ++o) p.Hio[idx0 + o] = (float)hv[o];
+                        for (int o = 0; o < 4; ++o) p.Hio[idx0 + o] = (float)hv[o];
                     }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 16 * NKB; ++q) {
-                    // G2_VEC: q -> (chunk c, reg, j) with kb = 4*c + j inside the full chunks, then the remainder MFMAs reg-major; else kb-major as before
-                    const int full = 4 * G2_NFULL * 16;                                  // (kb, reg) pairs inside full chunks
-                    if (lines_done && q < full) continue;
-                    const int kb = !NMFX_G2_VEC ? q / 16 : (q < full ? 4 * (q / 64) + (q & 3) : 4 * G2_NFULL + (q - full) % (G2_WREM > 0 ? G2_WREM : 1));
-                    const int reg = !NMFX_G2_VEC ? q % 16 : (q < full ? (q % 64) >> 2 : (q - full) / (G2_WREM > 0 ? G2_WREM : 1));
-                    const int k = g2_kloc(kb, rowmap(reg, h));   // (EPI 1: TT == 1, one block)
-                    if (!row_ok || (p.fix && p.fix[k])) continue;
-                    const long idx = (long)k + (long)K * r;
+                    const int kb = SWAP ? q % NKB : q / 16, reg = SWAP ? q / NKB : q % 16;
+                    if (lines_done && kb < 4 * G2_NFULL) continue;                       // (the full chunks went out above; what is left is the K % 128 remainder)
+                    const int k = e_kloc(kb, reg);   // (EPI 1: TT == 1, one block)
+                    if (!e_ok(reg) || (p.fix && p.fix[k])) continue;
+                    const long idx = (long)k + (long)K * e_row(reg);
                     const float lam = p.lam ? p.lam[k] : 0.0f;
                     if (p.H64) {   // float64 master copy of H: the update in double, both arrays written
                         const double hv = p.H64[idx];
