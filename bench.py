@@ -57,7 +57,7 @@ CPU_SAMPLE_COLS = {"c3": 4096, "c2": 8192, "c2is": 8192, "c2is256": 4096, "c2is5
 
 
 # what decides a launch's HBM traffic: the kernels, and the files that set grid / column-split geometry (the workgroup order over the XCDs decides L2 reuse)
-PMC_KERNEL_SOURCES = ("fused_kernel.h", "fused_launch.h", "fused.hip", "gemm_pipe.h", "gemm_common.h", "engine.hip", "sc.hip")
+PMC_KERNEL_SOURCES = ("fused_kernel.h", "fused_launch.h", "fused.hip", "gemm_pipe.h", "gemm_common.h", "engine.hip", "sc.hip", "nmfx_internal.h")
 
 
 def kernel_sources_sha16():
