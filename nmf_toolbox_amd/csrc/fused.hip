@@ -71,6 +71,9 @@ nmfx_status launch_fused(hipStream_t st, const FusedParams &p, int nsplit, bool 
         return launch_fused_cnmf_c(st, p, nsplit, func, do_g2);
     }
     if (!fused_supported(p.K)) { set_error("launch_fused: K=%d not supported (multiples of 32 up to 256)", p.K); return NMFX_ERR_UNSUPPORTED; }
+    // the no-first-product pass of the W-step form writing a K-CONTIGUOUS output (os_k == 1: the transposed products (V'*W)' and (V'*W_flat)' of the euclidean H
+    // steps): the accumulator transposed, so that lanes run along k (fused_kernel.h, SWAP).  Anything else keeps the row-contiguous form
+    if (d_rc && do_g2 && func == 0 && epi == 0 && p.os_k == 1 && p.os_r != 1 && NMFX_G2_VEC) epi = 2;
     const bool rag = p.R % FT_ROWS != 0 || p.Cn % FT_C != 0;
     if (p.K <= 96) return rag ? launch_fused_rag_k32_96(st, p, nsplit, d_rc, func, do_g2, epi) : launch_fused_k32_96(st, p, nsplit, d_rc, func, do_g2, epi);
     if (p.K <= 192) return rag ? launch_fused_rag_k128_192(st, p, nsplit, d_rc, func, do_g2, epi) : launch_fused_k128_192(st, p, nsplit, d_rc, func, do_g2, epi);

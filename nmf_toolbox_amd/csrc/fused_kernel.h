@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // register) instead of O(k <-> register, r <-> lane).  The output of this form is K-contiguous (H, or a K x n slab), so a lane then owns 4 consecutive k of a column and
     // 32 lanes write 512 contiguous bytes of it; with r on the lanes every store instruction scattered 64 four-byte pieces at stride K, and once NMFX_G2_VEC had
     // changed which k a register holds the L2 no longer merged them: 1.2e9 B written per H-step pass at C3 for 2.0e8 B of H and its master (profiles/r6_10_*_pmc.md)
-    constexpr bool SWAP = !D_RC && NMFX_G2_VEC;
+    // EPI 2 = EPI 0 of the W-step form with the transposed accumulator as well: the no-first-product passes whose output is K-contiguous -- the H-step numerators
+    // of the euclidean paths as transposed products, (V'*W)' and cnmf's Q = (V'*W_flat)' (launch_fused picks it from the output strides)
+    constexpr bool SWAP = (!D_RC || EPI == 2) && NMFX_G2_VEC;
+    static_assert(EPI != 2 || (D_RC && DO_G2 && FUNC == 0 && TT == 1), "EPI 2: W-step form, no first product");
     constexpr bool STB = FUNC == 15 || FUNC == 16;                                   // first map + store of the second map's values
     // 19 / 20: the LAST block of an IS / alpha-beta chain over a factor wider than 256 (like 8 for KL): the accumulated S goes through map 11 / 13 and both maps'
     // values are stored
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     auto e_row = [&](int reg) -> long { return SWAP ? r0 + rowmap(reg, h) : r; };
     auto e_ok = [&](int reg) -> bool { return !RAG || e_row(reg) < p.R; };
     if (DO_G2) {
-        if (EPI == 0) {
+        if (EPI == 0 || EPI == 2) {
             float *out = p.out + (long)blockIdx.y * p.slab_stride + (TT == 1 ? (long)blockIdx.z * p.oz_stride : 0L);
 #pragma unroll
             for (int q = 0; q < 16 * NKB; ++q) {

@@ -82,6 +82,10 @@ static nmfx_status launch_f(hipStream_t st, const FusedParams &p, int nsplit, in
 template <int K, bool RAG>
 static nmfx_status launch_k(hipStream_t st, const FusedParams &p, int nsplit, bool d_rc, int func, bool do_g2, int epi) {
     if (!do_g2) return d_rc ? launch_f<K, true, false, 0, RAG>(st, p, nsplit, func) : NMFX_ERR_UNSUPPORTED;   // cost-only pass
+    if (d_rc && epi == 2) {   // W-step form, K-contiguous output: transposed accumulator (functor 0 only)
+        if (func == 0) return launch_one<K, true, 0, true, 2, RAG>(st, p, nsplit);
+        return NMFX_ERR_UNSUPPORTED;
+    }
     if (d_rc) return launch_f<K, true, true, 0, RAG>(st, p, nsplit, func);                                    // W step: slabs out
     if (epi == 1) return launch_f<K, false, true, 1, RAG>(st, p, nsplit, func);                               // H step, fused update
     return launch_f<K, false, true, 0, RAG>(st, p, nsplit, func);                                             // H step, slabs out
