@@ -78,9 +78,9 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False, va
     out = os.path.join(HERE, "libnmfx_asan.so") if sanitize else (os.path.join(HERE, "libnmfx_%s.so" % variant) if variant else OUT)
     vdefs = VARIANTS[variant] if variant else []
     # (-g / -fno-omit-frame-pointer for the HOST pass only: handed to the device pass as well they change the gfx950 code objects -- frame pointer, CFI spills --
-    # and the register-stationary kernels then return garbage: measured, profiles/r4_01_host_asan.md)
+    # and the register-stationary kernels then return garbage: measured, profiles/archive/r4_01_host_asan.md)
     # -fno-sanitize=function: UBSan's indirect-call check and HIP's kernel handles do not mix -- `auto kern = some_kernel<...>; hipLaunchKernelGGL(kern, ...)`
-    # (every templated launch of this library) is then silently NOT launched (hipcc 7.2; reproduced in 40 lines, profiles/r4_01_host_asan.md)
+    # (every templated launch of this library) is then silently NOT launched (hipcc 7.2; reproduced in 40 lines, profiles/archive/r4_01_host_asan.md)
     san = ["-fsanitize=address,undefined", "-fno-sanitize=function", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-Xarch_host", "-g", "-Xarch_host", "-fno-omit-frame-pointer"] if sanitize else []
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

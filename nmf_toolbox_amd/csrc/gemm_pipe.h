@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pipe_kernel(const GemmParams
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest) and each XCD has its own L2.  XCD k gets
     // the k-th CONTIGUOUS eighth of the (x fastest) tile order instead of every eighth tile, so the tiles an XCD runs together share their
     // B panel (all i tiles of a column block) and walk the contraction in step: a skinny product (Q = W_flat' * V: 4 x 128 tiles) then
-    // fetches each column block of V into ONE L2 instead of four (HBM read per launch 1.11e9 -> see profiles/r2_13_c4_pmc.md).
+    // fetches each column block of V into ONE L2 instead of four (HBM read per launch 1.11e9 -> see profiles/archive/r2_13_c4_pmc.md).
     unsigned bx = blockIdx.x, by = blockIdx.y;
     {
         const unsigned nt = gridDim.x * gridDim.y;

@@ -110,7 +110,7 @@ struct ResPool {
 ResPool g_res;
 
 // NMFX_NO_POOL=1 (development switch, read once): streams and events are created per call and destroyed when handed back, as in round 3 before the pool --
-// the configuration the host-sanitizer campaign runs in (tests/host_asan/, profiles/r4_*): the pool must not be what keeps a lifetime bug from showing
+// the configuration the host-sanitizer campaign runs in (tests/host_asan/, profiles/archive/r4_*): the pool must not be what keeps a lifetime bug from showing
 bool pool_off() {
     static const bool off = [] { const char *e = getenv("NMFX_NO_POOL"); return e && e[0] == '1'; }();
     return off;

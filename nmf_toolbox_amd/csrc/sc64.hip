@@ -1,7 +1,7 @@
 // nmfsc.m:57-245 in float64 end to end, for the problem sizes at which results get compared with MATLAB by eye (m*n*K <= 2^27 multiply-adds per product,
 // one GPU): V, W, H, V_hat, every gradient, the Hoyer projection and the objective are doubles on the device, so the accept tests of the line searches
 // (nmfsc.m:164, :215) are decided on the same numbers the reference decides them on.  With fp32 storage of W a CONVERGED line search -- its objective moving by
-// 1e-10 relative per try -- took a different number of tries than the reference (round 4: K = 3 with H fixed, profiles/r4_19); parity here is 1e-12 and the
+// 1e-10 relative per try -- took a different number of tries than the reference (round 4: K = 3 with H fixed, profiles/archive/r4_19); parity here is 1e-12 and the
 // try counts are the reference's.  Everything is VALU work (one thread per output element): these problems are a few hundred microseconds per product either way.
 #include "api_common.h"
 

@@ -3,7 +3,7 @@
 // Built by nmf_toolbox_amd/build.py::build_sanitized() with -fsanitize=address,undefined on the HOST pass only (device code objects are the
 // normal gfx950 ones: GPU ASan / xnack+ are not available on this pool) and linked against the equally instrumented libnmfx_asan.so.  It
 // drives what scripts/fuzz_campaign_r3.py `multi_edge` drove when a rare host-heap corruption showed up in round 3
-// (profiles/r3_40_multi_edge_crash.md): nmf / cnmf / lnmf through nmfx_problem.n_gpus on awkward geometry at a high call rate, while other
+// (profiles/archive/r3_40_multi_edge_crash.md): nmf / cnmf / lnmf through nmfx_problem.n_gpus on awkward geometry at a high call rate, while other
 // threads of the process churn the malloc heap the way the NumPy oracle's temporaries did.  Run with NMFX_NO_POOL=1 to put the per-call
 // stream / event create + destroy of round 3 back.  Every multi-device result is compared with the one-device result of the same call
 // (no oracle needed: the property is "sharding changes only the summation order").

@@ -1,6 +1,6 @@
 // hipcc 7.2: with -fsanitize=undefined (which includes -fsanitize=function) the launch through `auto kern = kern_t<...>` below is silently dropped --
 // "template via auto: b[5] = 0 (want 31)"; with -fno-sanitize=function it prints 31.  Build: hipcc --offload-arch=gfx950 -O3 -fPIC -fsanitize=undefined -fno-gpu-sanitize -c; link into a
-// shared object and call run_k(1000) from an executable built with the same -fsanitize (profiles/r4_01_host_asan.md).
+// shared object and call run_k(1000) from an executable built with the same -fsanitize (profiles/archive/r4_01_host_asan.md).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 namespace nmfx {

@@ -1,4 +1,4 @@
-"""The two problem classes that sat OUTSIDE the contract until round 4 (found by the campaigns, profiles/r3_28, r4_18, r4_19), now inside the suite (-m gpu):
+"""The two problem classes that sat OUTSIDE the contract until round 4 (found by the campaigns, profiles/archive/r3_28, r4_18, r4_19), now inside the suite (-m gpu):
 
 (i)  euclidean nmf with H fixed for ~10 iterations (nmf.m:146-169 with H_fixed; over-complete K > min(m, n) was where it showed first): W came out at
      1.06e-5 ... 1.7e-5.  What carried the error was the K-long fp32 accumulation of P = W*(H*H') (V_hat*H' of nmf.m:150 in Gram form), re-rounded differently
@@ -12,7 +12,7 @@ from conftest import record_err, rel_fro, synth
 
 pytestmark = pytest.mark.gpu
 
-# the eight cases of profiles/r4_18_fuzz_campaign_nmf_cnmf.log (m, n, K, iterations, W_sparsity, H_sparsity, shards); planted / random data both
+# the eight cases of profiles/archive/r4_18_fuzz_campaign_nmf_cnmf.log (m, n, K, iterations, W_sparsity, H_sparsity, shards); planted / random data both
 R4_18 = [(493, 383, 640, 10, 0.0883035381731506, 0.0631358004042333, 1), (366, 562, 320, 11, 0.05122370003302588, 0.019178388546800165, 1), (358, 791, 640, 9, 0.0, 0.0, 1),
          (353, 1352, 448, 11, 0.0, 0.0, 1), (181, 1162, 448, 11, 0.0, 0.0, 4), (422, 378, 512, 11, 0.0, 0.0, 1), (152, 985, 400, 11, 0.0, 0.0, 1),
          (293, 235, 257, 11, 0.038302790951008386, 0.028375087137691924, 1)]
@@ -116,7 +116,7 @@ def test_cnmf_euclidean_h_fixed(gpu_lib, m, n, K, T, iters):
     assert e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6, e
 
 
-# profiles/r4_19_fuzz_campaign_sc_*.log: the K = 3, H-fixed problems whose last try count differed (with the campaign's data scalings)
+# profiles/archive/r4_19_fuzz_campaign_sc_*.log: the K = 3, H-fixed problems whose last try count differed (with the campaign's data scalings)
 @pytest.mark.parametrize("scale", [1.0, 0.01, 3.0, 100.0])
 @pytest.mark.parametrize("m,n,iters", [(377, 694, 5), (116, 593, 6), (257, 129, 8)])
 def test_nmfsc_k3_h_fixed_converged_w_search(gpu_lib, m, n, iters, scale):
