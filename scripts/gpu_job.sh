@@ -14,6 +14,8 @@
 #   campaign:<script>:<seed>:<seconds>[:args]   scripts/<script>.py in the BACKGROUND (joined at the end)          -> <tag>_<script>_<seed>.log
 #   py:<file>[:args]                python <file> <args>                                                           -> <tag>_<basename>.log
 #   bgpy:<file>[:args]              the same in the background (host-only work next to the GPU steps: the full-size oracle fixtures)
+#   asan:<seconds>:<seed>:<kinds>:<pool on|off>   tests/host_asan/fuzz_multi against libnmfx_asan.so (python -m nmf_toolbox_amd.build --sanitize; both must be let
+#                                   through .gpurunignore for the run)                                             -> <tag>_asan_<kinds>_<pool>.log
 #   wait                            join the background campaigns here instead of at the end
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 TAG=$1; shift
@@ -46,6 +48,12 @@ except Exception as e: print('$a$sfx: no line', e)" ;;
     campaign) python scripts/$a.py $b $c $d > gpurun_out/${TAG}_${a}_$b.log 2>&1 & ;;
     bgpy) python $a $b $c $d > gpurun_out/${TAG}_$(basename $a .py).log 2>&1 & ;;
     py) python $a $b $c $d > gpurun_out/${TAG}_$(basename $a .py).log 2>&1; tail -5 gpurun_out/${TAG}_$(basename $a .py).log | cut -c1-300 ;;
+    asan)
+      log=gpurun_out/${TAG}_asan_${c}_${d:-off}.log
+      ( export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=0:print_stacktrace=1:symbolize=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 ASAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer
+        [ "${d:-off}" = off ] && export NMFX_NO_POOL=1
+        FUZZ_NO_WATCHDOG=1 timeout $(( a + 180 )) ./tests/host_asan/fuzz_multi "$a" "$b" "$c" > $log 2>&1; echo "exit $?" >> $log )
+      echo "sanitizer reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error' $log)"; grep "fuzz_multi seed\|^exit\|BAD" $log | tail -3 | cut -c1-300 ;;
     wait) wait ;;
     *) echo "unknown step $step" ;;
   esac
