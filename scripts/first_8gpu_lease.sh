@@ -39,5 +39,5 @@ for N in 2 8; do
   run c5_n$N --workload c5 --gpus $N --steps 20 --warmup 5 --no-cpu-baseline
   run c2_n$N --workload c2 --gpus $N --steps 20 --warmup 5 --no-cpu-baseline
 done
-[ $NG -ge 2 ] && timeout 900 python scripts/multi_gpu_parity.py $NG > $OUT/parity_real_devices.log 2>&1; tail -5 $OUT/parity_real_devices.log
+if [ $NG -ge 2 ]; then timeout 900 python scripts/multi_gpu_parity.py $NG > $OUT/parity_real_devices.log 2>&1; tail -5 $OUT/parity_real_devices.log; fi
 echo "done: $OUT"
