@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // gpurun_out/r6_01_gputests.log) although the generated code reads right -- the partial-S loads those kernels issue between the MFMAs are the one thing the
     // other kernels do not have; they keep hipcc's own MFMAs until that is understood (NMFX_G1_ASM_SIN = 1 builds the failing form for experiments)
     constexpr bool G1A = NMFX_G1_ASM && (NMFX_G1_ASM_SIN || !S_IN);
-    constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // packed KL map: micro-ops are per PAIR of elements (8, or 3 without the cost)
-    constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the element map (PK: 2*NU per pair)
+    constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // the packed KL map, in bursts per double pair (emap_burst below)
+    constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the one-by-one element maps (everything but PK)
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
     constexpr int NG = K / 8;              // ds_read_b128 groups (4 MFMAs each) per half of the first product
     constexpr int ROWS_PER_WAVE = (TROWS + 3) / 4;  // LDS rows each wave moves per tile
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
         // P4  second product, half 1    || V loads of the next tile, two per step
         // A wave issues in order and a 32x32x2 f32 MFMA occupies the pipe for 64 cycles, so whatever sits between two MFMAs
         // in program order must finish (dependency latencies included) inside 64 cycles or the matrix pipe idles.  The
-        // element map is therefore cut into four micro-ops (rcp | mul | log | accumulate) that are placed behind DIFFERENT
-        // MFMAs, LDS operands are fetched one step ahead, and a sched_barrier after every MFMA pins this order (left
+        // element maps are therefore cut into micro-ops placed behind chosen MFMAs (the KL map: bursts of 4-6 instructions that fit that shadow, emap_burst; the
+        // other divergences: one micro-op at a time, emap_u), LDS operands are fetched one step ahead, and a sched_barrier after every MFMA pins this order (left
         // alone, hipcc clusters the VALU/VMEM work: probe runs lost 9-19 % of the MFMA rate that way).
         f32x16 sacc[2];
         f32x16 sacc2[DUAL ? 2 : 1];                           // the second map's tile (B)
