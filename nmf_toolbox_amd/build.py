@@ -65,7 +65,6 @@ VARIANTS = {
     "r5": ["-DNMFX_KL_MODE=0", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],     # the round-5 kernels: scalar KL map, closed-form sum(S), ds_read_b32 second product
     "kl1": ["-DNMFX_KL_MODE=1", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],    # consistent KL cost on scalar VALU instructions (6 per element)
     "kl2": ["-DNMFX_KL_MODE=2", "-DNMFX_G2_VEC=0", "-DNMFX_G1_ASM=0"],    # ... on packed instructions (8 per pair)
-    "sinasm": ["-DNMFX_G1_ASM_SIN=1", "-DNMFX_SETTLE_P2=18"],             # experiment: asm first product in the chain kernels too, with the full 18 wait states before the map of half 0
     "kl2g2": ["-DNMFX_KL_MODE=2", "-DNMFX_G2_VEC=1", "-DNMFX_G1_ASM=0"],  # + vector LDS reads of the second product
 }
 

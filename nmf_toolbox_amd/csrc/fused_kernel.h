@@ -20,11 +20,12 @@ __device__ __forceinline__ f32x2 pk_fma_t(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; 
 __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }   // c - a.*b
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
-// wait states between an asm MFMA and the first VALU / store that reads its result (the hazard recogniser cannot see into the asm; a 16-pass MFMA needs 18)
-__device__ __forceinline__ void mfma_settle(int n) {
-    if (n > 16) asm volatile("s_nop 15\n\ts_nop 3");
-    else asm volatile("s_nop 3");
-}
+// Wait states between an asm MFMA and the first VALU / store that reads its result: the hazard recogniser cannot see into the asm, and a 16-pass MFMA needs 18.
+// The accumulator is an in/out operand of the waiting asm, so that NOTHING that reads it can be moved in front of the wait (a pure builtin such as v_rcp has no other
+// reason to stay behind an asm volatile).  Where another MFMA follows the chain anyway, the wait is part of THAT MFMA's asm statement (its 16 passes + `s_nop 3`);
+// this full form is for the cost-only passes, where nothing follows.  What the kernel cannot prevent -- a register copy of the tuple that hipcc itself places
+// right behind an asm MFMA -- is checked in the built objects: scripts/mfma_asm_lint.py (tests/test_abi_and_host.py)
+__device__ __forceinline__ void mfma_settle_full(f32x16 &t) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(t)); }
 __device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 // raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit raw format
 __device__ __forceinline__ i32x4 make_srd(const void *base, unsigned bytes) {
@@ -109,10 +110,12 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // the R / S stores of this tile would stand between them and the V loads in the in-order counter and get waited for as well (an HBM write round
     // trip per tile: c4kl's S pass)
     constexpr bool EARLY = !DO_G2 && NEED_S;
-    // the asm form of the first product (NMFX_G1_ASM).  NOT for the chain kernels (S_IN): with it every K > 256 test failed on the hardware (costs off by 3e-4 ... inf,
-    // gpurun_out/r6_01_gputests.log) although the generated code reads right -- the partial-S loads those kernels issue between the MFMAs are the one thing the
-    // other kernels do not have; they keep hipcc's own MFMAs until that is understood (NMFX_G1_ASM_SIN = 1 builds the failing form for experiments)
-    constexpr bool G1A = NMFX_G1_ASM && (NMFX_G1_ASM_SIN || !S_IN);
+    // the asm form of the first product (NMFX_G1_ASM).  Chain kernels (S_IN): the chain starts from zero like everywhere else and the partial sums of the blocks before
+    // are ADDED once it has settled (SADD) -- with the partial S as the chain's initial value the accumulator tuple is loop-carried through the prefetch registers,
+    // and hipcc re-homed it with `v_mov_b64` copies right behind an asm MFMA, i.e. read it 1-2 wait states after an instruction that delivers 18 later: every
+    // K > 256 test failed on the hardware (round 6; scripts/chain_kernel_check.hip reproduces it, scripts/mfma_asm_lint.py finds it in the objects)
+    constexpr bool G1A = NMFX_G1_ASM;
+    constexpr bool SADD = S_IN && G1A;
     constexpr bool PK = NMFX_KL_MODE == 2 && (MF == 2 || MF == 3) && !DUAL && EF == FUNC;   // the packed KL map, in bursts per double pair (emap_burst below)
     constexpr int NU = (DUAL || EF == 11 || EF == 13) ? 8 : ((MF == 3 && NMFX_KL_MODE == 1) ? 6 : 4);   // micro-ops per element of the one-by-one element maps (everything but PK)
     static_assert(!DUAL || (K <= 192 && TT == 1), "dual-map kernels: K <= 192 (two accumulator sets + the stationary operand must fit 512 VGPRs: 501 at K = 192, spills at 224)");
@@ -232,14 +235,17 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
     // partial S of the same tile (S_IN), same register layout as d[]: a descriptor of zero bytes (no p.Sin) reads zeros, so the first launch
     // of a chain runs the same instruction stream
     float sin_[S_IN ? 32 : 1];
+    float sin_n[(S_IN && NMFX_G1_ASM) ? 32 : 1];   // SADD: the next tile's partial S (sin_ stays live until it has been added at the end of P2)
     auto s_srd = [&](int t) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(p.Sin ? p.Sin + p.ldd * (cbeg + (long)t * FT_C) : p.D), 0, p.Sin ? (int)(unsigned)(tile_rows(t) * p.ldd * 4) : 0, 0x00020000);
     };
-    auto load_s_piece = [&](const __amdgpu_buffer_rsrc_t srd, int i) {
+    auto load_s_piece = [&](const __amdgpu_buffer_rsrc_t srd, int i, bool nxt = false) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = 2 * i + u, jb = e >> 4, reg = e & 15;
-            sin_[S_IN ? e : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0));
+            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, d_voff, (int)(p.ldd * (32 * jb + (reg & 3) + 8 * (reg >> 2)) * 4), 0));
+            if (S_IN && NMFX_G1_ASM && nxt) sin_n[(S_IN && NMFX_G1_ASM) ? e : 0] = sv;
+            else sin_[S_IN ? e : 0] = sv;
         }
     };
 
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[jb][e] = S_IN ? sin_[S_IN ? jb * 16 + e : 0] : 0.0f;
+                for (int e = 0; e < 16; ++e) sacc[jb][e] = (S_IN && !SADD) ? sin_[S_IN ? jb * 16 + e : 0] : 0.0f;   // (asm form: dead -- the chains start with C = 0)
             float4 a_cur = g1_read(0, 0);
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {                          // P1 (ph 0), P2 (ph 1)
@@ -474,20 +480,34 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                         // one accumulator need no wait states; what reads the tile afterwards is kept away from the last MFMA by mfma_settle() below
                         // (the dual-map kernels at K > 128 hold two output accumulator sets: with the stationary operand as well the AGPR half would overflow)
                         constexpr bool XA = K / 2 + (DO_G2 ? (DUAL ? 2 : 1) * NKB * 16 : 0) <= 256;
-                        if (XA) {
-                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
+                        const bool first = g == 0 && e == 0 && (!S_IN || SADD);   // chain start: C = 0
+                        if (ph == 1 && g == 0 && e == 0) {
+                            // the first MFMA of the second chain, and behind it -- in the SAME statement -- what the first chain still needs: that MFMA's 16 passes +
+                            // `s_nop 3` after the last MFMA of sacc[0], which rides along as an in/out operand (see mfma_settle_full)
+                            if (XA) {
+                                if (first) asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, 0\n\ts_nop 3" : "=&v"(sacc[1]), "+v"(sacc[0]) : "v"(av), "a"(xreg[0]));
+                                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 3" : "+v"(sacc[1]), "+v"(sacc[0]) : "v"(av), "a"(xreg[0]));
+                            } else {
+                                if (first) asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, 0\n\ts_nop 3" : "=&v"(sacc[1]), "+v"(sacc[0]) : "v"(av), "v"(xreg[0]));
+                                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 3" : "+v"(sacc[1]), "+v"(sacc[0]) : "v"(av), "v"(xreg[0]));
+                            }
+                            if (SADD) {   // the partial sums of the blocks before, half 0
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) sacc[0][q] += sin_[S_IN ? q : 0];
+                            }
+                        } else if (XA) {
+                            if (first) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
                             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "a"(xreg[4 * g + e]));
                         } else {
-                            if (!S_IN && g == 0 && e == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
+                            if (first) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
                             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(sacc[ph]) : "v"(av), "v"(xreg[4 * g + e]));
                         }
-                        if (ph == 1 && g == 0 && e == 0) mfma_settle(NMFX_SETTLE_P2);   // sacc[0]'s last MFMA is one MFMA back: its 16 passes are over, 2 more until the write has landed
                       } else
 #endif
                         sacc[ph] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xreg[4 * g + e], sacc[ph], 0, 0, 0);
                         if (ph == 1) emap_fill(0, 4 * g + e, 4 * NG);
                         if (ph == 0 && e == 0) dma_some(((g + 1) * ROWS_PER_WAVE + NG - 1) / NG);
-                        if (S_IN && ph == 1 && 4 * g + e < 16) load_s_piece(ssn, 4 * g + e);   // partial S of the next tile (sin_ went into sacc at the tile top)
+                        if (S_IN && ph == 1 && 4 * g + e < 16) load_s_piece(ssn, 4 * g + e, true);   // partial S of the next tile (builtin form: sin_ went into sacc at the tile top; asm form: into sin_n)
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     one(0, a_cur.x); one(1, a_cur.y); one(2, a_cur.z); one(3, a_cur.w);
@@ -504,7 +524,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int reg = 0; reg < 16; ++reg) emap_u(1, reg, 0);
         }
 #if NMFX_G1_ASM
-        if (NEED_S && G1A) mfma_settle(DO_G2 ? NMFX_SETTLE_P2 : 18);   // sacc[1]'s last MFMA: one MFMA back when the second product follows (as above), else right behind us (16 passes + 2)
+        if (NEED_S && G1A && !DO_G2) {   // cost-only form: nothing follows the second chain (with a second product, its first MFMA carries the wait: below)
+            mfma_settle_full(sacc[1]);
+            if (SADD) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc[1][q] += sin_[S_IN ? 16 + q : 0];
+            }
+        }
 #endif
         if (DO_G2) {
             if (STB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA rows (issued under P1) have landed; from here on stores are in flight too
@@ -542,6 +568,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
                 const float rr2 = DUAL ? sacc2[jb][reg] : 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
+#if NMFX_G1_ASM
+                    if (NEED_S && G1A && st == 0 && kb == 0) {
+                        // the first MFMA of the second product carries the wait for the second chain (sacc[1], in/out): its 16 passes + `s_nop 3` (see mfma_settle_full)
+                        if (SWAP) asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 3" : "+a"(acc[0]), "+v"(sacc[1]) : "v"(rr), "v"(y_cur[0]));
+                        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\ts_nop 3" : "+a"(acc[0]), "+v"(sacc[1]) : "v"(y_cur[0]), "v"(rr));
+                    } else
+#endif
                     acc[kb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(rr, y_cur[kb], acc[kb], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(y_cur[kb], rr, acc[kb], 0, 0, 0);
                     if (jb == 0 && NEED_S) emap_fill(1, (reg * NKB + kb) * (DUAL ? 2 : 1), 16 * NKB * (DUAL ? 2 : 1));   // element map of half 1 under the MFMAs of half 0
                     if (kb == 0 && !NEED_S) dma_some((st + 1) * ROWS_PER_WAVE / 24 < ROWS_PER_WAVE ? (st + 1) * ROWS_PER_WAVE / 24 : ROWS_PER_WAVE);   // no first product: the DMA rides here, done by step 24
@@ -604,6 +637,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && FUNC != 4 && FUNC != 5) ? 2 : 1)
             for (int i = 0; i < 16; ++i) load_d_piece(dsn, tn, i);
         }
         dma_some(ROWS_PER_WAVE);
+        if (SADD) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) sin_[S_IN ? e : 0] = sin_n[(S_IN && NMFX_G1_ASM) ? e : 0];
+        }
         // rows past R hold garbage (possibly NaN): theirs alone, never summed.  KL (modes 1 / 2): tc is in log2 units, ts in natural ones
         if (MF == 3 && NMFX_KL_MODE == 2) cost += row_ok ? ((double)tc2[0].x + (double)tc2[0].y + (double)tc2[1].x + (double)tc2[1].y) * 0.6931471805599453 + ((double)ts2[0].x + (double)ts2[0].y + (double)ts2[1].x + (double)ts2[1].y) : 0.0;
         else if (MF == 3 && NMFX_KL_MODE == 1) cost += row_ok ? (double)tc * 0.6931471805599453 + (double)ts : 0.0;

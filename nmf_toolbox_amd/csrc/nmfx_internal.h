@@ -131,12 +131,6 @@ size_t gemm_scratch_bytes(long M, long N, long Kc);
 #ifndef NMFX_G1_ASM
 #define NMFX_G1_ASM 1
 #endif
-#ifndef NMFX_G1_ASM_SIN
-#define NMFX_G1_ASM_SIN 0
-#endif
-#ifndef NMFX_SETTLE_P2
-#define NMFX_SETTLE_P2 2
-#endif
 constexpr bool KL_CONSISTENT_COST = NMFX_KL_MODE != 0;   // engine.hip: the finishers add the closed form only when the kernel does not sum it
 struct FusedParams {
     const float *X;       // stationary factor: X(r, k) = X[r*xs_r + k*xs_k]   (W step: W; H step: H^T i.e. H with xs_r = K, xs_k = 1)

@@ -189,3 +189,45 @@ def test_rccl_lookup_survives_a_library_that_cannot_be_loaded():
     res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, text=True, capture_output=True)
     assert res.returncode == 0, (res.returncode, res.stderr[-500:])
     assert "path=" in res.stdout and "/nonexistent" not in res.stdout
+
+
+def test_no_instruction_reads_an_asm_mfma_result_too_early():
+    """The first product's MFMAs are inline asm (fused_kernel.h, NMFX_G1_ASM): hipcc's hazard recogniser does not see them, and a register copy it places right behind one
+    reads a result that arrives 18 wait states later -- that is what broke every K > 256 test on the hardware in round 6 with code that read right.  scripts/mfma_asm_lint.py
+    walks the BUILT objects; here: (a) it finds the pattern in a disassembly that has it, and lets a clean chain pass, (b) the shipped fused kernels have none."""
+    _lib()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import mfma_asm_lint as L
+    bad = """0000000000001000 <k>:
+	v_mfma_f32_32x32x2_f32 v[18:33], v36, a126, v[18:33]
+	v_mov_b64_e32 v[48:49], v[32:33]
+	v_mfma_f32_32x32x2_f32 v[34:49], v55, a127, v[34:49]
+	s_endpgm
+"""
+    good = """0000000000001000 <k>:
+	v_mfma_f32_32x32x2_f32 v[18:33], v36, a126, v[18:33]
+	v_mfma_f32_32x32x2_f32 v[18:33], v37, a127, v[18:33]
+	v_mfma_f32_32x32x2_f32 v[2:17], v56, a0, 0
+	s_nop 3
+	v_rcp_f32_e32 v60, v18
+	s_branch 12
+	v_mov_b32_e32 v18, v60
+	s_endpgm
+"""
+    fb, nb = L.lint_text(bad)
+    fg, ng = L.lint_text(good)
+    assert nb == 2 and len(fb) == 1 and "v_mov_b64" in fb[0][2] and ng == 3 and not fg, (fb, fg)
+    early = good.replace("s_nop 3\n", "").replace("v_mfma_f32_32x32x2_f32 v[2:17], v56, a0, 0\n", "")   # the reader right behind the chain's last MFMA
+    assert len(L.lint_text(early)[0]) >= 1
+    objdir = os.path.join(ROOT, "nmf_toolbox_amd", "csrc", "_obj")
+    if not os.path.isdir(objdir) or not any(f.startswith("fused") for f in os.listdir(objdir)):
+        pytest.skip("no built objects in this tree (only the shared library travelled)")
+    import glob
+    from kernel_resources import code_objects
+    findings, n = [], 0
+    for f in sorted(glob.glob(os.path.join(objdir, "fused*.o"))):
+        for co in code_objects(f):
+            fnd, k = L.lint_code_object(co)
+            findings += fnd
+            n += k
+    assert n > 50000 and not findings, (n, findings[:3])
