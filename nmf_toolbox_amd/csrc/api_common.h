@@ -42,7 +42,6 @@ int fused_split(long blocks, long extent, int K, long *c_per_split);
 
 }  // namespace nmfx
 
-#define TRY(x) do { nmfx_status s_ = (x); if (s_ != NMFX_OK) return s_; } while (0)
 
 struct ProfEvent {
     int tag;

@@ -8,11 +8,8 @@ template <int K, bool D_RC, int FUNC, bool DO_G2, int EPI, bool RAG>
 static nmfx_status launch_one(hipStream_t st, const FusedParams &p, int nsplit) {
     const size_t ldsb = sizeof(float) * 2 * FT_C * (K + 4);
     auto kern = fused_kernel<K, D_RC, FUNC, DO_G2, EPI, RAG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_attr;
+    TRY(lds_attr.set(reinterpret_cast<const void *>(kern), (int)ldsb));
     dim3 grid((unsigned)((p.R + FT_ROWS - 1) / FT_ROWS), (unsigned)nsplit, (unsigned)(p.nz > 1 ? p.nz : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
     NMFX_HIP(hipGetLastError());
@@ -25,11 +22,8 @@ template <int K, int FUNC, bool DO_G2, int TT>
 static nmfx_status launch_one_T(hipStream_t st, const FusedParams &p, int nsplit) {
     const size_t ldsb = sizeof(float) * 2 * (FT_C + TT - 1) * (K / TT + 4);
     auto kern = fused_kernel<K, true, FUNC, DO_G2, 0, true, TT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_attr;
+    TRY(lds_attr.set(reinterpret_cast<const void *>(kern), (int)ldsb));
     dim3 grid((unsigned)((p.R + FT_ROWS - 1) / FT_ROWS), (unsigned)nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, st, p);
     NMFX_HIP(hipGetLastError());

@@ -248,11 +248,8 @@ static nmfx_status launch_cfg(hipStream_t st, const GemmParams &p) {
     constexpr int A_SZ_AL = (BK * LA::LDS_STRIDE + 3) & ~3, B_SZ_AL = (BK * LB::LDS_STRIDE + 3) & ~3;
     const size_t lds = sizeof(float) * 2 * (A_SZ_AL + B_SZ_AL);
     auto kern = gemm_kernel<BM, BN, A_KC, B_KC, FAST, HEAVY>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_attr;
+    TRY(lds_attr.set(reinterpret_cast<const void *>(kern), (int)lds));
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN), (unsigned)(p.splitk > 1 ? p.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, p);
     NMFX_HIP(hipGetLastError());

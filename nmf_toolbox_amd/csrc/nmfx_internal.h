@@ -20,6 +20,23 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+#define TRY(x) do { nmfx_status s_ = (x); if (s_ != NMFX_OK) return s_; } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device: the attribute belongs to the device's copy of the code object, and one process may drive
+// several GPUs (the blocking multi-GPU call).  One static instance per launcher instantiation; a lost race sets it twice; a larger request than the last one sets it again.
+struct LdsAttrOnce {
+    int set_bytes[64] = {};   // per device: the largest size asked for so far
+    nmfx_status set(const void *fn, int bytes) {
+        int dev = 0;
+        NMFX_HIP(hipGetDevice(&dev));
+        const bool tracked = dev >= 0 && dev < 64;
+        if (tracked && set_bytes[dev] >= bytes) return NMFX_OK;
+        NMFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (tracked) set_bytes[dev] = bytes;
+        return NMFX_OK;
+    }
+};
+
 // Declared AFTER the host vectors / device buffers an entry point copies to or from asynchronously: whichever way the function is left -- an NMFX_HIP / TRY
 // early return included -- the stream is drained before that memory goes away, so no DMA is ever in flight into (or out of) a dead std::vector or a freed buffer
 struct StreamDrain {

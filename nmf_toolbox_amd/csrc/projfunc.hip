@@ -213,11 +213,8 @@ template <int THREADS, int ER, int EL, typename TIO, int DM>
 static nmfx_status launch_pf_dm(hipStream_t st, TIO *X, long len, int count, double k1, double k2, int nn, int *usediters, const float *dir, double mu, const TIO *src, const double *dir64) {
     auto kern = projfunc_kernel<THREADS, ER, EL, TIO, DM>;
     const size_t ldsb = sizeof(double) * EL * THREADS;
-    static bool attr_done = false;
-    if (ldsb > 48 * 1024 && !attr_done) {
-        NMFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr_done = true;
-    }
+    static LdsAttrOnce lds_attr;
+    TRY(lds_attr.set(reinterpret_cast<const void *>(kern), (int)ldsb));
     hipLaunchKernelGGL(kern, dim3(count), dim3(THREADS), ldsb, st, X, len, k1, k2, nn, usediters, dir, mu, src, dir64);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;

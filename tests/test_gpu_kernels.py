@@ -111,7 +111,8 @@ def test_projfunc_signed(gpu_lib):
     assert it == it0 and rel_fro(v, v0) < 1e-12
 
 
-@pytest.mark.parametrize("M,N,Kc", [(64, 64, 16), (128, 192, 64), (358, 640, 640), (8192, 128, 128), (1000, 37, 53), (1, 1, 1), (65, 129, 17), (4096, 512, 512)])
+@pytest.mark.parametrize("M,N,Kc", [(64, 64, 16), (128, 192, 64), (358, 640, 640), (8192, 128, 128), (1000, 37, 53), (1, 1, 1), (65, 129, 17), (4096, 512, 512),
+                                    (300, 77, 112), (1000, 130, 256), (257, 33, 16), (2111, 512, 496)])   # (the last four: ragged edges of the panel kernel)
 @pytest.mark.parametrize("a64,b64", [(True, False), (False, False), (True, True), (False, True)])
 def test_gemm64(gpu_lib, M, N, Kc, a64, b64):
     """the float64 matrix-core product behind P = W*(H*H') (gemm64.hip): every operand-type combination against NumPy float64, float64 and fp32 results;
