@@ -50,39 +50,50 @@ __global__ void reduce_slabs_kernel(const float *slabs, int nslab, long stride, 
         }
     }
 }
-// first level of the two-level reduction: group y sums its `g` consecutive slabs into the first of them (in place)
-__global__ void reduce_slab_groups_kernel(float *slabs, int nslab, int g, long stride, long count) {
-    const int s0 = blockIdx.y * g, ns = nslab - s0 < g ? nslab - s0 : g;
-    float *base = slabs + (long)s0 * stride;
-    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (idx + 3 < count && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (stride & 3) == 0) {
-        float4 s = *reinterpret_cast<const float4 *>(base + idx);
-        for (int z = 1; z < ns; ++z) {
-            const float4 t = *reinterpret_cast<const float4 *>(base + z * stride + idx);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+// Many slabs of a small output (the K x K Gram products: 128 x 128 floats in up to 256 split-K slabs): one thread per output quad gave 16 workgroups to pull 16 MB
+// through (31 us at C2), a two-level pair of launches 11 us (rounds 3-5).  ONE launch: 16 threads share an output quad and split the slabs among themselves (thread
+// l takes slabs l, l + 16, ...: 16 consecutive threads read 256 contiguous bytes of a slab), LDS combines their 16 float64 partial sums in lane order.  count / 64
+// workgroups.  The order of the sum is fixed by (nslab, count) alone: run-to-run deterministic.
+__global__ __launch_bounds__(256) void reduce_slabs_lanes_kernel(const float *__restrict__ slabs, int nslab, long stride, long count, float *__restrict__ out, int accumulate) {
+    __shared__ double part[16][16][4 + 1];
+    const int qd = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long idx = ((long)blockIdx.x * 16 + qd) * 4;
+    const bool vec = idx + 3 < count && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0 && (stride & 3) == 0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (vec) {
+#pragma unroll 4
+        for (int z = sl; z < nslab; z += 16) {
+            const float4 t = *reinterpret_cast<const float4 *>(slabs + z * stride + idx);
+            s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
         }
-        *reinterpret_cast<float4 *>(base + idx) = s;
     } else {
-        for (long e = idx; e < idx + 4 && e < count; ++e) {
-            float s = base[e];
-            for (int z = 1; z < ns; ++z) s += base[z * stride + e];
-            base[e] = s;
+        for (int e = 0; e < 4; ++e)
+            if (idx + e < count)
+                for (int z = sl; z < nslab; z += 16) s[e] += slabs[z * stride + idx + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[sl][qd][e] = s[e];
+    __syncthreads();
+    if (sl != 0) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += part[l][qd][e];
+    if (vec) {
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4 *>(out + idx);
+            s[0] += o.x; s[1] += o.y; s[2] += o.z; s[3] += o.w;
         }
+        *reinterpret_cast<float4 *>(out + idx) = make_float4((float)s[0], (float)s[1], (float)s[2], (float)s[3]);
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (idx + e < count) out[idx + e] = (float)(accumulate ? s[e] + out[idx + e] : s[e]);
     }
 }
 nmfx_status reduce_slabs(hipStream_t st, const float *slabs, int nslab, long slab_stride, long count, float *out, int accumulate) {
     if (count <= 0) return NMFX_OK;
-    // Small outputs with many slabs (the K x K Gram products: 128 x 128 floats, up to 256 split-K slabs) gave the single-level kernel 16
-    // workgroups to pull 16 MB through (31 us at C2).  Two levels: ~sqrt(nslab) groups summed in place by their own workgroups, then the
-    // group heads.  The summation order is fixed by (nslab, count) alone: results stay run-to-run deterministic.  The slabs are scratch.
-    if (nslab >= 16 && count <= (1L << 18) && (long)nslab * count >= (1L << 20)) {   // (below 4 MB of slabs the second launch costs more than it saves)
-        int g = 4;
-        while (g * g < nslab) g *= 2;
-        const int ngroups = (nslab + g - 1) / g;
-        const long nthr1 = (count + 3) / 4;
-        hipLaunchKernelGGL(reduce_slab_groups_kernel, dim3((unsigned)((nthr1 + 255) / 256), (unsigned)ngroups), dim3(256), 0, st, const_cast<float *>(slabs), nslab, g, slab_stride, count);
-        NMFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((nthr1 + 255) / 256)), dim3(256), 0, st, slabs, ngroups, slab_stride * g, count, out, accumulate);
+    if (nslab >= 16 && count <= (1L << 18)) {
+        hipLaunchKernelGGL(reduce_slabs_lanes_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, slabs, nslab, slab_stride, count, out, accumulate);
         NMFX_HIP(hipGetLastError());
         return NMFX_OK;
     }
