@@ -43,6 +43,21 @@ def test_gemm_plain(gpu_lib, M, N, Kc, opA, opB):
     assert rel_fro(got, ref) < 2e-6  # fp32 fmaf chains, contraction up to 4096
 
 
+@pytest.mark.parametrize("M,N,Kc,acc", [(37, 21, 40000, 0), (37, 21, 40000, 1), (128, 128, 32768, 0), (64, 512, 16384, 1), (5, 5, 100000, 0), (130, 126, 20000, 1)])
+def test_gemm_many_slabs_small_output(gpu_lib, M, N, Kc, acc):
+    """small outputs over long contractions -- the K x K Gram products of a euclidean iteration: split into many slabs and summed by ONE launch in which 16 threads
+    share an output quad (aux.hip::reduce_slabs_lanes_kernel).  Odd element counts take its scalar path, `accumulate` its read-modify-write."""
+    import torch
+    from nmf_toolbox_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(M + N + Kc + acc)
+    A, B = rs.rand(M, Kc) - 0.3, rs.rand(Kc, N) - 0.3
+    C0 = rs.rand(M, N) if acc else None
+    got = _gemm(lib, torch, 0, 0, M, N, Kc, A, B, accumulate=acc, C0=C0)
+    ref = A.astype(np.float32).astype(np.float64) @ B.astype(np.float32).astype(np.float64) + (C0.astype(np.float32).astype(np.float64) if acc else 0.0)
+    assert rel_fro(got, ref) < 3e-6
+
+
 def test_gemm_is_transpose_safe(gpu_lib):
     """A = I with an ASYMMETRIC B catches a swapped C write (guide rule 16)."""
     import torch
