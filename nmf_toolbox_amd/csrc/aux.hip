@@ -1434,19 +1434,41 @@ nmfx_status smallk_grad(hipStream_t st, int Kv, const float *V, long m, long n, 
 // output element and column chunk.  The columns of W are short there and the Hoyer projection amplifies the fp32 accumulation noise of
 // an MFMA contraction over n (W off by 1.3e-5 on 71 x 218 and 388 x 156 problems in scripts/fuzz_campaign_sc.py); the work is m*n*K
 // fp64 FMAs, so this is for small problems only (the caller decides).
-__global__ __launch_bounds__(256) void resid_xht64_kernel(const float *V, const float *Vh, long m, long n, const float *H, int K, int t, long cpc, double *slabs) {
+// ... and, since round 6, the residual those contractions run on: R64 = sum_{t < Tn} W_t * rshift_t(H) - V in float64 (one thread per element, K*Tn fp64 FMAs), instead of
+// the difference of the fp32 V_hat and V.  On ill-conditioned sparse-W problems the search amplifies what its gradient carries by 200x and more PER ITERATION
+// (scripts/cnmfsc_sparse_w_outlier.py: 222 x 100, K = 32, T = 2 moves 5.6e-6 in three iterations under a 3e-8 rounding of its inputs in the float64 algorithm
+// itself); the rounding of V_hat to fp32 was seven times that perturbation, and W ended at 4.4e-5 (round 5's one campaign problem outside the contract).
+__global__ __launch_bounds__(256) void recon_resid64_kernel(const float *V, const float *W, long m, long n, int K, int Tn, const float *H, double *R64) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= m) return;
+    double acc = 0.0;
+    for (int t = 0; t < Tn && t <= j; ++t) {
+        const float *w = W + i + m * (long)K * t, *h = H + (long)K * (j - t);
+        for (int k = 0; k < K; ++k) acc = fma((double)w[m * k], (double)h[k], acc);
+    }
+    R64[i + m * j] = acc - (double)V[i + m * j];
+}
+nmfx_status recon_resid64(hipStream_t st, const float *V, const float *W, long m, long n, int K, int Tn, const float *H, double *R64) {
+    if (m <= 0 || n <= 0) return NMFX_OK;
+    if (n > 65535) { set_error("recon_resid64: n = %ld (small problems only)", n); return NMFX_ERR_INVALID; }
+    hipLaunchKernelGGL(recon_resid64_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)n), dim3(256), 0, st, V, W, m, n, K, Tn, H, R64);
+    NMFX_HIP(hipGetLastError());
+    return NMFX_OK;
+}
+__global__ __launch_bounds__(256) void resid_xht64_kernel(const float *V, const float *Vh, const double *R64, long m, long n, const float *H, int K, int t, long cpc, double *slabs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     if (i >= m) return;
     long c0 = (long)blockIdx.z * cpc, c1 = c0 + cpc < n ? c0 + cpc : n;
     if (c0 < t) c0 = t;                                   // rshift_t(H)(:, j) = H(:, j - t), zero for j < t
     double acc = 0.0;
-    for (long j = c0; j < c1; ++j) acc = fma((double)Vh[i + m * j] - (double)V[i + m * j], (double)H[k + (long)K * (j - t)], acc);
+    if (R64) { for (long j = c0; j < c1; ++j) acc = fma(R64[i + m * j], (double)H[k + (long)K * (j - t)], acc); }
+    else for (long j = c0; j < c1; ++j) acc = fma((double)Vh[i + m * j] - (double)V[i + m * j], (double)H[k + (long)K * (j - t)], acc);
     slabs[(long)blockIdx.z * m * K + i + m * k] = acc;
 }
-nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out) {
+nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, const double *R64, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out) {
     const long cpc = (n + nch - 1) / nch;
-    hipLaunchKernelGGL(resid_xht64_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)K, (unsigned)nch), dim3(256), 0, st, V, Vh, m, n, H, K, t, cpc, nch == 1 ? out : slabs);
+    hipLaunchKernelGGL(resid_xht64_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)K, (unsigned)nch), dim3(256), 0, st, V, Vh, R64, m, n, H, K, t, cpc, nch == 1 ? out : slabs);
     NMFX_HIP(hipGetLastError());
     if (nch > 1) {
         hipLaunchKernelGGL(sum_slabs_f64_kernel, dim3((unsigned)((m * K + 255) / 256)), dim3(256), 0, st, slabs, nch, m * K, out);
@@ -1457,7 +1479,7 @@ nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m,
 
 // ... and the sparse-H branch: dH'(j, k) = sum_t sum_i W_t(i, k) * (V_hat - V)(i, j + t), j + t < n (cnmfsc.m:160-168), in fp64: one wave per
 // output element, lanes along i (the columns of V_hat / V and of W_t are contiguous there); out is n x K (the layout projfunc reads)
-__global__ __launch_bounds__(256) void resid_hgrad64_kernel(const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT) {
+__global__ __launch_bounds__(256) void resid_hgrad64_kernel(const float *V, const float *Vh, const double *R64, long m, long n, const float *W, int K, int T, double *outT) {
     const int lane = threadIdx.x & 63;
     const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // o = j + n * k
     if (o >= n * K) return;
@@ -1465,14 +1487,20 @@ __global__ __launch_bounds__(256) void resid_hgrad64_kernel(const float *V, cons
     const int k = (int)(o / n);
     double acc = 0.0;
     for (int t = 0; t < T && j + t < n; ++t) {
-        const float *v = V + m * (j + t), *vh = Vh + m * (j + t), *w = W + m * ((long)k + (long)K * t);
+        const float *w = W + m * ((long)k + (long)K * t);
+        if (R64) {
+            const double *rr = R64 + m * (j + t);
+            for (long i = lane; i < m; i += 64) acc = fma((double)w[i], rr[i], acc);
+            continue;
+        }
+        const float *v = V + m * (j + t), *vh = Vh + m * (j + t);
         for (long i = lane; i < m; i += 64) acc = fma((double)w[i], (double)vh[i] - (double)v[i], acc);
     }
     acc = wave_sum(acc);
     if (lane == 0) outT[o] = acc;
 }
-nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT) {
-    hipLaunchKernelGGL(resid_hgrad64_kernel, dim3((unsigned)((n * K + 3) / 4)), dim3(256), 0, st, V, Vh, m, n, W, K, T, outT);
+nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, const double *R64, long m, long n, const float *W, int K, int T, double *outT) {
+    hipLaunchKernelGGL(resid_hgrad64_kernel, dim3((unsigned)((n * K + 3) / 4)), dim3(256), 0, st, V, Vh, R64, m, n, W, K, T, outT);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }

@@ -297,9 +297,11 @@ nmfx_status pow_map(hipStream_t st, const float *in, float *out, long count, flo
 nmfx_status sum_vec(hipStream_t st, const double *v, long count, double *out);
 // nmfsc with K <= smallk_max(): residual-form gradients and objective in fp64 (aux.hip)
 // out (m x K doubles) = (Vh - V) * rshift_t(H)' in fp64; slabs: nch * m * K doubles (nch column chunks)
-nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out);
+// R64 (m x n float64, or nullptr): the residual itself, used instead of Vh - V (recon_resid64 forms it: sum_{t < Tn} W_t * rshift_t(H) - V in float64)
+nmfx_status recon_resid64(hipStream_t st, const float *V, const float *W, long m, long n, int K, int Tn, const float *H, double *R64);
+nmfx_status resid_xht64(hipStream_t st, const float *V, const float *Vh, const double *R64, long m, long n, const float *H, int K, int t, double *slabs, int nch, double *out);
 // outT (n x K doubles) = (sum_t W_t' * lshift_t(Vh - V))' in fp64
-nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, long m, long n, const float *W, int K, int T, double *outT);
+nmfx_status resid_hgrad64(hipStream_t st, const float *V, const float *Vh, const double *R64, long m, long n, const float *W, int K, int T, double *outT);
 // nmfsc on small problems, any K: R64 = W*H - V (m x n doubles, or nullptr: objective only) + sum of squares per workgroup; then dH' = (W'*R64)' and dW = R64*H'
 int resid64_blocks(long m, long n);
 nmfx_status resid64(hipStream_t st, const float *V, long m, long n, const float *W, const float *H, int K, int ldh, double *R64, double *partials, int *nparts);

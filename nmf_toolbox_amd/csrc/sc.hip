@@ -651,6 +651,9 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
     DevBuf g64h;   // the same for the sparse-H gradient (aux.hip::resid_hgrad64): m*n*K*T fp64 FMAs
     const bool small64h = p->sc_H_sparsity > 0 && (double)p->m * (double)p->n * (double)p->K_total * (double)p->T <= (double)(1 << 27);
     if (small64h) TRY(g64h.alloc(sizeof(double) * (size_t)p->n * p->K_total));
+    DevBuf r64c;   // the float64 residual both of them contract (aux.hip::recon_resid64)
+    if ((small64 || small64h) && p->n <= 65535) TRY(r64c.alloc(sizeof(double) * (size_t)p->m * p->n));
+    double *R64c = r64c.p ? r64c.as<double>() : nullptr;
     // Fused passes (the register-stationary kernels of cnmf) for every evaluation that is a whole-matrix contraction: objectives without a
     // stored V_hat inside the H line search, V_hat + objective in one pass where the algorithm keeps V_hat, all T products V*rshift_t(H)' in one pass,
     // the multiplicative W branch from the Gram of the stacked shifts (no V_hat: gramW below), dH through Q = W_flat'*(V_hat - V) + shift-sum.  Default for problems
@@ -803,7 +806,11 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
                 const double begobj = r->cost[it - 1];
                 int tries = 0;
                 TRY(transpose_f32(st, H, K, n, HT));                                                 // rows of H / dH contiguous: the projected vectors
-                if (small64h) TRY(resid_hgrad64(st, V.as<float>(), Vh.as<float>(), m, n, W0, K, T, g64h.as<double>()));   // dH' in fp64 (small problems)
+                if (small64h) {   // dH' in fp64 (small problems), from the float64 image of the V_hat the reference holds here: RFD(W, H) -- W, not W0: in the first
+                                  // iteration that is the PROJECTED W of cnmfsc.m:105-109,152 while the gradient contracts W0; from the second on the two are equal (cnmfsc.m:266)
+                    if (R64c) TRY(recon_resid64(st, V.as<float>(), W, m, n, K, T, H, R64c));
+                    TRY(resid_hgrad64(st, V.as<float>(), Vh.as<float>(), R64c, m, n, W0, K, T, g64h.as<double>()));
+                }
                 else {
                     if (vh_is_resid) TRY(hgrad(W0, Vh.as<float>(), G2.as<float>()));            // dH = sum_t W0_t' * lshift_t(R), R = V_hat - V left by the objective pass
                     else TRY(hgrad(W0, V.as<float>(), G2.as<float>(), Vh.as<float>()));         // dH = pos - neg = sum_t W0_t' * lshift_t(V_hat - V)   cnmfsc.m:160-168
@@ -890,7 +897,11 @@ nmfx_status run_cnmfsc(const nmfx_problem *p, nmfx_result *r) {
             for (int t = 0; t < T && !early && !gramW; ++t) {
                 float *W0t = W0 + (size_t)t * mK, *Wt = W + (size_t)t * mK;
                 if (sW > 0) {
-                    if (small64) TRY(resid_xht64(st, V.as<float>(), Vh.as<float>(), m, n, H, K, t, s64.as<double>(), nch64, g64.as<double>()));   // dW in fp64 (small problems)
+                    if (small64) {   // dW in fp64 (small problems), from the float64 image of the V_hat the reference holds here: RFD(W0, H) before the first slice,
+                                     // the PLAIN product Wnew_{t-1} * H behind it (cnmfsc.m:235 hands RFD a 2-D Wnew)
+                        if (R64c) TRY(recon_resid64(st, V.as<float>(), t == 0 ? W0 : W + (size_t)(t - 1) * mK, m, n, K, t == 0 ? T : 1, H, R64c));
+                        TRY(resid_xht64(st, V.as<float>(), Vh.as<float>(), R64c, m, n, H, K, t, s64.as<double>(), nch64, g64.as<double>()));
+                    }
                     else TRY(xht(V.as<float>(), H, t, G2.as<float>(), Vh.as<float>()));          // dW = pos - neg = (V_hat - V) * Hs'   cnmfsc.m:221-224
                     int tries = 0;
                     double newobj = 0;
