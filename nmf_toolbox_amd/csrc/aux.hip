@@ -389,7 +389,11 @@ size_t row_reduce_scratch_bytes(int rows) { return sizeof(double) * (size_t)RR_B
 //   dn = sum_i W.*P  (= diag(H*B'*W)),  dp = sum_i W.*N
 //   W <- W .* ((N + W*dn).^e ./ max((P + W*dp).^e + lambda, eps))          nmf.m:168 / cnmf.m:193
 // the same update on the float64 master copy of W: every sweep in double, both arrays written (the fp32 one is what the MFMA passes contract)
+// NW waves per workgroup (BT threads): one workgroup per column; 16 waves where the columns are long and few (C2: 128 columns of 8192 rows -- a sweep is one trip to
+// HBM instead of two, and a launch is three dependent sweeps)
+template <int NW>
 __device__ void w_update64_body(const WUpdateParams &p, double *red) {
+    constexpr int BT = 64 * NW;
     const int c = blockIdx.x, k = c % p.K;
     double *w = p.W64 + p.m * c;
     float *w32 = p.W + p.m * c;
@@ -407,37 +411,37 @@ __device__ void w_update64_body(const WUpdateParams &p, double *red) {
     if (p.stats_in) { dn = p.dndp[c]; dp = p.dndp[KT + c]; }
     else if (p.dndp || (!fixed && !plain)) {
         // (every sweep: four elements per thread and trip, all loads issued before the first use -- the same elements in the same order as one per trip, but four
-        // loads in flight per array instead of one: a column is m / 256 dependent trips to HBM otherwise, and the update was 0.11 ms at C3)
-        for (long i0 = threadIdx.x; i0 < p.m; i0 += 1024) {
+        // loads in flight per array instead of one: a column is m / BT dependent trips to HBM otherwise, and the update was 0.11 ms at C3)
+        for (long i0 = threadIdx.x; i0 < p.m; i0 += (4 * BT)) {
             double wv[4], nv[4], qv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const long i = i0 + 256 * u; const bool ok = i < p.m; wv[u] = ok ? w[i] : 0.0; nv[u] = ok ? nat(i) : 0.0; qv[u] = ok ? pat(i) : 0.0; }
+            for (int u = 0; u < 4; ++u) { const long i = i0 + BT * u; const bool ok = i < p.m; wv[u] = ok ? w[i] : 0.0; nv[u] = ok ? nat(i) : 0.0; qv[u] = ok ? pat(i) : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (i0 + 256 * u < p.m) { dn = fma(wv[u], qv[u], dn); dp = fma(wv[u], nv[u], dp); }
+            for (int u = 0; u < 4; ++u) if (i0 + BT * u < p.m) { dn = fma(wv[u], qv[u], dn); dp = fma(wv[u], nv[u], dp); }
         }
-        dn = block_sum<4>(dn, red);
-        dp = block_sum<4>(dp, red);
+        dn = block_sum<NW>(dn, red);
+        dp = block_sum<NW>(dp, red);
         if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
     }
     if (p.stats_only) return;
     if (fixed) {
         if (p.fuse_norm != 0 && p.colsum_out) {   // fixed column: untouched, but its sum is still part of the H-step denominator
             double cs = 0.0;
-            for (long i = threadIdx.x; i < p.m; i += 256) cs += w[i];
-            cs = block_sum<4>(cs, red);
+            for (long i = threadIdx.x; i < p.m; i += BT) cs += w[i];
+            cs = block_sum<NW>(cs, red);
             if (threadIdx.x == 0) p.colsum_out[c] = cs;
         }
         return;
     }
     const double lam = p.lamW ? (double)p.lamW[k] : 0.0, eps = 2.220446049250313e-16, ie = (double)p.inv_exp;
     double ss = 0.0;
-    for (long i0 = threadIdx.x; i0 < p.m; i0 += 1024) {
+    for (long i0 = threadIdx.x; i0 < p.m; i0 += (4 * BT)) {
         double wv[4], nv[4], qv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long i = i0 + 256 * u; const bool ok = i < p.m; wv[u] = ok ? w[i] : 0.0; nv[u] = ok ? nat(i) : 0.0; qv[u] = ok ? pat(i) : 0.0; }
+        for (int u = 0; u < 4; ++u) { const long i = i0 + BT * u; const bool ok = i < p.m; wv[u] = ok ? w[i] : 0.0; nv[u] = ok ? nat(i) : 0.0; qv[u] = ok ? pat(i) : 0.0; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long i = i0 + 256 * u;
+            const long i = i0 + BT * u;
             if (i >= p.m) continue;
             const double wi = wv[u], ni = nv[u], pi = qv[u];
             double neg = plain ? ni : fma(wi, dn, ni);
@@ -449,45 +453,47 @@ __device__ void w_update64_body(const WUpdateParams &p, double *red) {
             ss += plain ? wn : wn * wn;
         }
     }
-    ss = block_sum<4>(ss, red);
+    ss = block_sum<NW>(ss, red);
     if (threadIdx.x == 0) p.sumsq[c] = ss;
     if (p.fuse_norm == 0) return;
     const double f = p.fuse_norm == 2 ? 1.0 / ss : 1.0 / sqrt(ss);   // nmf.m:169 / lnmf.m:70
     double cs = 0.0;
-    for (long i0 = threadIdx.x; i0 < p.m; i0 += 1024) {
+    for (long i0 = threadIdx.x; i0 < p.m; i0 += (4 * BT)) {
         double wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long i = i0 + 256 * u; wv[u] = i < p.m ? w[i] : 0.0; }
+        for (int u = 0; u < 4; ++u) { const long i = i0 + BT * u; wv[u] = i < p.m ? w[i] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long i = i0 + 256 * u; if (i < p.m) { const double v = wv[u] * f; w[i] = v; w32[i] = (float)v; cs += v; } }
+        for (int u = 0; u < 4; ++u) { const long i = i0 + BT * u; if (i < p.m) { const double v = wv[u] * f; w[i] = v; w32[i] = (float)v; cs += v; } }
     }
     if (p.colsum_out) {
-        cs = block_sum<4>(cs, red);
+        cs = block_sum<NW>(cs, red);
         if (threadIdx.x == 0) p.colsum_out[c] = cs;
     }
 }
 
-__global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
-    __shared__ double red[4];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void w_update_kernel(const WUpdateParams p) {
+    constexpr int BT = 64 * NW;
+    __shared__ double red[NW];
     const int c = blockIdx.x;
     const int k = c % p.K;
     float *w = p.W + p.m * c;
     if (p.fin_on && blockIdx.x == gridDim.x - 1) {   // the cost of the state this W step started from (gram_cost_finish_kernel, same arithmetic and order)
         const bool exact = *p.fin_exact_flag != 0;
         double s = 0.0, t = 0.0;
-        if (exact) { for (int i = threadIdx.x; i < p.fin_nparts; i += 256) s += p.fin_partials[i]; }
-        else if (p.fin_rank0) { for (int cc = threadIdx.x; cc < p.fin_nc; cc += 256) s += 0.5 * p.dndp[cc] - p.dndp[p.fin_nc + cc]; }
-        s = block_sum<4>(s, red);
-        if (p.fin_l1W) for (int cc = threadIdx.x; cc < p.fin_nW; cc += 256) t += (double)p.fin_lamW[cc % p.fin_K] * p.fin_l1W[cc];
-        if (p.fin_l1H) for (int kk = threadIdx.x; kk < p.fin_K; kk += 256) t += (double)p.fin_lamH[kk] * p.fin_l1H[kk];
-        t = block_sum<4>(t, red);
+        if (exact) { for (int i = threadIdx.x; i < p.fin_nparts; i += BT) s += p.fin_partials[i]; }
+        else if (p.fin_rank0) { for (int cc = threadIdx.x; cc < p.fin_nc; cc += BT) s += 0.5 * p.dndp[cc] - p.dndp[p.fin_nc + cc]; }
+        s = block_sum<NW>(s, red);
+        if (p.fin_l1W) for (int cc = threadIdx.x; cc < p.fin_nW; cc += BT) t += (double)p.fin_lamW[cc % p.fin_K] * p.fin_l1W[cc];
+        if (p.fin_l1H) for (int kk = threadIdx.x; kk < p.fin_K; kk += BT) t += (double)p.fin_lamH[kk] * p.fin_l1H[kk];
+        t = block_sum<NW>(t, red);
         if (threadIdx.x == 0) {
             const double cst = (exact ? 0.5 * s : 0.5 * p.fin_sumVV[0] + s) + t;
             *p.fin_out = cst;
             if (p.fin_out2) *p.fin_out2 = cst;
         }
     }
-    if (p.W64) { w_update64_body(p, red); return; }
+    if (p.W64) { w_update64_body<NW>(p, red); return; }
     if (p.fixW && p.fixW[k]) {
         if (p.dndp && !p.stats_in) {   // fixed column: untouched, but <W, N> and <W, P> of the Gram-form cost run over every column
             const float *pp = p.P ? p.P + p.m * c : nullptr;
@@ -495,21 +501,21 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
             const int nch = p.n_chunks > 1 ? p.n_chunks : 1;
             const long cr = p.m / nch, KT = (long)p.K * p.T;
             double dn = 0.0, dp = 0.0;
-            for (long i = threadIdx.x; i < p.m; i += 256) {
+            for (long i = threadIdx.x; i < p.m; i += BT) {
                 const long ch = i / cr;
                 const double wi = (double)w[i];
                 dn += wi * (double)(pp ? pp[i] : pv);
                 dp += wi * (double)p.N[ch * cr * KT + cr * c + (i - ch * cr)];
             }
-            dn = block_sum<4>(dn, red);
-            dp = block_sum<4>(dp, red);
+            dn = block_sum<NW>(dn, red);
+            dp = block_sum<NW>(dp, red);
             if (threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
         }
         if (p.stats_only) return;
         if (p.fuse_norm != 0 && p.colsum_out) {   // fixed column: untouched, but its sum is still part of the H-step denominator
             double cs = 0.0;
-            for (long i = threadIdx.x; i < p.m; i += 256) cs += (double)w[i];
-            cs = block_sum<4>(cs, red);
+            for (long i = threadIdx.x; i < p.m; i += BT) cs += (double)w[i];
+            cs = block_sum<NW>(cs, red);
             if (threadIdx.x == 0) p.colsum_out[c] = cs;
         }
         return;
@@ -539,14 +545,14 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         for (int ch = 0; ch < nch; ++ch) {
             const float4 *w4 = reinterpret_cast<const float4 *>(w + ch * cr), *n4 = reinterpret_cast<const float4 *>(p.N + ch * cr * KT + cr * c);
             const float4 *p4 = reinterpret_cast<const float4 *>(pp ? pp + ch * cr : nullptr);
-            for (long i = threadIdx.x; i < c4n; i += 256) {
+            for (long i = threadIdx.x; i < c4n; i += BT) {
                 const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
                 dn += ((double)a.x * c4.x + (double)a.y * c4.y) + ((double)a.z * c4.z + (double)a.w * c4.w);
                 dp += ((double)a.x * b.x + (double)a.y * b.y) + ((double)a.z * b.z + (double)a.w * b.w);
             }
         }
-        dn = block_sum<4>(dn, red);
-        dp = block_sum<4>(dp, red);
+        dn = block_sum<NW>(dn, red);
+        dp = block_sum<NW>(dp, red);
         if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
         if (p.stats_only) return;
         }
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
             float4 *w4 = reinterpret_cast<float4 *>(w + ch * cr);
             const float4 *n4 = reinterpret_cast<const float4 *>(p.N + ch * cr * KT + cr * c);
             const float4 *p4 = reinterpret_cast<const float4 *>(pp ? pp + ch * cr : nullptr);
-            for (long i = threadIdx.x; i < c4n; i += 256) {
+            for (long i = threadIdx.x; i < c4n; i += BT) {
                 const float4 a = w4[i], b = n4[i], c4 = pp ? p4[i] : pvv;
                 float4 o;
                 o.x = upd(a.x, b.x, c4.x, fdn, fdp); o.y = upd(a.y, b.y, c4.y, fdn, fdp);
@@ -568,24 +574,24 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
         auto nat = [&](long i) { const long ch = i / cr; return p.N[ch * cr * KT + cr * c + (i - ch * cr)]; };
         if (p.stats_in) { dn = p.dndp[c]; dp = p.dndp[KT + c]; }
         else {
-        for (long i = threadIdx.x; i < p.m; i += 256) {
+        for (long i = threadIdx.x; i < p.m; i += BT) {
             const float wi = w[i];
             dn += (double)wi * (double)(pp ? pp[i] : pv);
             dp += (double)wi * (double)nat(i);
         }
-        dn = block_sum<4>(dn, red);
-        dp = block_sum<4>(dp, red);
+        dn = block_sum<NW>(dn, red);
+        dp = block_sum<NW>(dp, red);
         if (p.dndp && threadIdx.x == 0) { p.dndp[c] = dn; p.dndp[KT + c] = dp; }
         if (p.stats_only) return;
         }
         const float fdn = (float)dn, fdp = (float)dp;
-        for (long i = threadIdx.x; i < p.m; i += 256) {
+        for (long i = threadIdx.x; i < p.m; i += BT) {
             const float wn = upd(w[i], nat(i), pp ? pp[i] : pv, fdn, fdp);
             w[i] = wn;
             ss += plain ? (double)wn : (double)wn * (double)wn;
         }
     }
-    ss = block_sum<4>(ss, red);
+    ss = block_sum<NW>(ss, red);
     if (threadIdx.x == 0) p.sumsq[c] = ss;
     if (p.fuse_norm == 0) return;
     // nmf.m:169 / lnmf.m:70 on the column just written: every thread re-reads exactly the elements it stored (same factor expression as
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
     if (vec) {
         for (int ch = 0; ch < nch; ++ch) {
             float4 *w4 = reinterpret_cast<float4 *>(w + ch * cr);
-            for (long i = threadIdx.x; i < cr / 4; i += 256) {
+            for (long i = threadIdx.x; i < cr / 4; i += BT) {
                 float4 v = w4[i];
                 v.x *= f; v.y *= f; v.z *= f; v.w *= f;
                 w4[i] = v;
@@ -603,15 +609,16 @@ __global__ __launch_bounds__(256) void w_update_kernel(const WUpdateParams p) {
             }
         }
     } else {
-        for (long i = threadIdx.x; i < p.m; i += 256) { const float v = w[i] * f; w[i] = v; cs += (double)v; }
+        for (long i = threadIdx.x; i < p.m; i += BT) { const float v = w[i] * f; w[i] = v; cs += (double)v; }
     }
     if (p.colsum_out) {
-        cs = block_sum<4>(cs, red);
+        cs = block_sum<NW>(cs, red);
         if (threadIdx.x == 0) p.colsum_out[c] = cs;
     }
 }
 nmfx_status w_update(hipStream_t st, const WUpdateParams &p) {
-    hipLaunchKernelGGL(w_update_kernel, dim3(p.K * p.T), dim3(256), 0, st, p);
+    if (p.m >= 4096 && p.K * p.T <= 256) hipLaunchKernelGGL(w_update_kernel<16>, dim3(p.K * p.T), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL(w_update_kernel<4>, dim3(p.K * p.T), dim3(256), 0, st, p);
     NMFX_HIP(hipGetLastError());
     return NMFX_OK;
 }
