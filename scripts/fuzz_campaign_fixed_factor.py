@@ -1,7 +1,7 @@
 """One-off campaign (not part of the suite) for the class that was outside the contract until round 4: nmf / cnmf with ONE factor fixed for 9-14 iterations,
 over-complete or not, random or planted data, on every kernel path (register-stationary kernels, K > 256 in column blocks, Gram form on the GEMM, materialised,
 column shards) -- against the float64 oracle.     scripts/fuzz_campaign_fixed_factor.py <seed> <seconds> [kind,kind,...]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from conftest import synth, rel_fro
@@ -44,6 +44,8 @@ while time.time() - t0 < budget:
     for k in worst: worst[k] = max(worst[k], e[k])
     if e["W"] <= 1e-5 and e["H"] <= 1e-5 and 1e-6 < e["cost"] <= 1e-5:
         cost_only += 1   # inside north_star's 1e-5 on every output; past this repo's own 1e-6 on the cost (KL, W fixed, near-perfect fits: cost << sum(V))
+    if max(e["W"], e["H"]) > float(os.environ.get("NMFX_FUZZ_REPORT_ABOVE", "1")):   # (inside the contract, but worth a look)
+        print("NOTE", (kind, m, n, K, T, planted, fixed, it, extra, {k: v for k, v in cfg.items() if k.endswith("sparsity")}), e, flush=True)
     if not (e["W"] <= 1e-5 and e["H"] <= 1e-5 and e["cost"] <= 1e-6):
         bad += 1; print("BAD", (kind, m, n, K, T, planted, fixed, it, extra, {k: v for k, v in cfg.items() if k.endswith("sparsity")}), e, flush=True)
 print("seed", seed, "cases", counts, "total", sum(counts.values()), "worst", worst, "bad", bad, "of which only the cost, between 1e-6 and 1e-5:", cost_only)
